@@ -1,0 +1,75 @@
+"""ctypes binding of libchameleon_nar.so (include/chameleon_nar.h).  No CPU fallback: if the library is
+missing or a kernel call fails this raises - the product path never silently degrades."""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchameleon_nar.so")
+
+P = c_void_p
+
+_SIGNATURES = {
+    "cham_neg_sample_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cham_neg_sample": (c_int, [P, c_int, c_int, P, c_int, c_uint32, c_uint32, c_int, c_int, c_int, c_int, P, P, P, P, P,
+                                P, c_size_t, P]),
+    "cham_ctx_assemble": (c_int, [P, P, c_int, P, c_int, P, P, P, P, P, P]),
+    "cham_item_dynamic_raw": (c_int, [P, P, c_int, P, P, P, P, P]),
+    "cham_norm_stats_from_recent": (c_int, [P, c_int, c_int64, P, P, P, P, P]),
+    "cham_norm_stats_from_rows": (c_int, [P, P, P, c_int, P, P]),
+    "cham_row_weights": (c_int, [P, c_int, P, c_size_t, c_int, P, P, P, P]),
+    "cham_item_assemble": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "cham_feature_bwd": (c_int, [P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P]),
+    "cham_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int,
+                              P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
+    "cham_combine_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "cham_combine_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "cham_transpose_f32": (c_int, [P, c_int, c_int, P, P]),
+    "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, P]),
+    "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, P]),
+    "cham_sumsq_partial": (c_int, [P, c_size_t, P, P]),
+    "cham_loss_finalize": (c_int, [P, c_int, c_float, P, c_float, P, P]),
+    "cham_adam_tf": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    "cham_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cham_colsum": (c_int, [P, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+class ChameleonLibError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises ChameleonLibError when it has not been built (python -m chameleon_recsys_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ChameleonLibError(
+            "HIP extension %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ChameleonLibError("%s failed with code %d" % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()

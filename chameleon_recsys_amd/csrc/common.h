@@ -1,0 +1,81 @@
+// Shared device helpers for the CHAMELEON NAR kernels (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHAM_OK 0
+#define CHAM_ERR_ARG 22       /* EINVAL */
+#define CHAM_ERR_LAUNCH 5     /* EIO    */
+
+#define CHAM_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return -CHAM_ERR_LAUNCH;      \
+    } while (0)
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_TANH = 2 };
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative expressed through the saved POST-activation value y
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+    if (act == ACT_LEAKY) return y > 0.f ? 1.f : 0.2f;
+    if (act == ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// ---- Philox4x32-10, word 0 (contract: oracle/philox.py) -------------------------------------
+__device__ __forceinline__ uint32_t philox_rand32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+#define CHAM_INF_KEY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ uint64_t philox_sort_key(uint32_t q, uint32_t j, uint32_t b, uint32_t stage,
+                                                    uint32_t seed, uint32_t step) {
+    return ((uint64_t)philox_rand32(q, j, b, stage, seed, step) << 32) | (uint64_t)q;
+}
+
+// ---- wave64 / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// deterministic block sum (fixed tree); `red` = >= blockDim/64 floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

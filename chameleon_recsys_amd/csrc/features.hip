@@ -1,0 +1,279 @@
+// Feature gather / assemble (+ backward) for the NAR step.
+//
+// Replaces nar_module/nar/nar_model.py:730-773 (get_features: one-hot / embedding / numeric),
+// :921-994 (get_item_features: metadata embeddings, ACE row, trainable item embedding),
+// :1055-1131 (recency), :1134-1193 (novelty), :996-1039 (normalize_values / min_max_normalization)
+// and :887-907 (scale_center_features, x*gamma+beta).
+//
+// MI355X design: item features depend only on the item id (positives / negatives are computed against
+// the scalar max_event_timestamp, nar_model.py:343,356) and negatives are drawn from a pool of <= 20*N
+// ids, so features are assembled ONCE per row of a small "item row set"
+//     [ clicked inputs (B*T, per-click reference timestamp) ; positives (B*T) ; pool slots (20*N + 1) ]
+// instead of once per [B,T,N] occurrence (409 MB -> ~10 MB of gathers at G1 shape).  The PreCAR layer is
+// then applied to these rows (V = X_item * W1_item) and combined per candidate in scorer.hip.
+//
+// HBM-bound; rows are <= ~16k so one thread per (row, column) with column descriptors is enough:
+// consecutive threads walk consecutive columns of one row -> the 1000-byte ACE row and the embedding
+// rows are read as contiguous, coalesced segments.
+#include "common.h"
+
+enum { COL_ZERO = 0, COL_OHE = 1, COL_EMB = 2, COL_NUM = 3, COL_ACE = 4, COL_ITEMEMB = 5, COL_RECENCY = 6, COL_NOVELTY = 7 };
+// descriptor = 5 x int64: kind, feat, sub, dim, param_offset
+#define DESC_W 5
+
+__device__ __forceinline__ float recency_raw(int64_t ref_ts, int64_t created) {
+    // nar_model.py:1055-1060: int64 -> float32 BEFORE the subtraction; then log_{1.3}(1+x) (:33-34, 1074)
+    const float d = ((float)ref_ts - (float)created) / 86400000.0f;
+    return logf(fmaxf(d, 0.f) + 1.0f) / logf(1.3f);
+}
+__device__ __forceinline__ float novelty_raw(float pop_norm) {
+    return -(logf(pop_norm) / logf(2.0f));      // nar_model.py:1147-1148
+}
+__device__ __forceinline__ float norm_apply(float x, const float* st) {
+    // st = {mean, sd, zmin, zmax}  (nar_model.py:1031-1037, 1007-1008)
+    const float z = (x - st[0]) / st[1];
+    const float scaled = (z - st[2] + 1e-24f) / fmaxf(st[3] - st[2], 2e-24f);
+    return scaled * 2.0f - 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// user-context rows  (nar_model.py:315-317)
+__global__ __launch_bounds__(256) void k_ctx_assemble(const int64_t* __restrict__ cat, const float* __restrict__ num, int R,
+                                                      const int64_t* __restrict__ desc, int F,
+                                                      const float* __restrict__ params, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ xraw, float* __restrict__ xs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * F) return;
+    const int r = (int)(i / F), c = (int)(i % F);
+    const int64_t* d = desc + (size_t)c * DESC_W;
+    const int kind = (int)d[0], feat = (int)d[1], sub = (int)d[2], dim = (int)d[3];
+    float v = 0.f;
+    if (kind == COL_OHE) v = (cat[(size_t)feat * R + r] == sub) ? 1.f : 0.f;
+    else if (kind == COL_EMB) v = params[d[4] + cat[(size_t)feat * R + r] * dim + sub];
+    else if (kind == COL_NUM) v = num[(size_t)feat * R + r];
+    xraw[i] = v;
+    xs[i] = v * gamma[c] + beta[c];
+}
+
+// raw (un-normalised) recency / novelty per item row
+__global__ __launch_bounds__(256) void k_item_dynamic_raw(const int64_t* __restrict__ ids, const int64_t* __restrict__ ref_ts, int R,
+                                                          const int64_t* __restrict__ created, const float* __restrict__ pop_norm,
+                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int64_t id = ids[r];
+    rec_raw[r] = recency_raw(ref_ts[r], created[id]);
+    nov_raw[r] = novelty_raw(pop_norm[id]);
+}
+
+// same, for the "last N recent clicks" used as normalisation population (nar_model.py:1066-1071, 1156-1158)
+__global__ __launch_bounds__(256) void k_last_dynamic_raw(const int64_t* __restrict__ last_ids, int n, int64_t max_ts,
+                                                          const int64_t* __restrict__ created, const float* __restrict__ pop_norm,
+                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int64_t id = last_ids[r];
+    rec_raw[r] = recency_raw(max_ts, created[id]);
+    nov_raw[r] = novelty_raw(pop_norm[id]);
+}
+
+// weighted population stats -> {mean, sd, zmin, zmax}; single workgroup, fixed reduction tree.
+// (tf.nn.moments population variance, sd = sqrt(var + 1e-24); nar_model.py:1014-1025, 1001-1002)
+__global__ __launch_bounds__(1024) void k_norm_stats(const float* __restrict__ vals, const float* __restrict__ wts, int n,
+                                                     float* __restrict__ out, int n_copies) {
+    __shared__ float red[16];
+    float sw = 0.f, swx = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float w = wts ? wts[i] : 1.f;
+        if (w > 0.f) { const float x = vals[i]; sw += w; swx += w * x; mn = fminf(mn, x); mx = fmaxf(mx, x); }
+    }
+    sw = block_sum(sw, red);
+    swx = block_sum(swx, red);
+    const float mean = swx / sw;
+    float sv = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float w = wts ? wts[i] : 1.f;
+        if (w > 0.f) { const float d = vals[i] - mean; sv += w * d * d; }
+    }
+    sv = block_sum(sv, red);
+    mn = wave_min(mn); mx = wave_max(mx);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float rmn[16], rmx[16];
+    if (lane == 0) { rmn[w] = mn; rmx[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) { mn = fminf(mn, rmn[i]); mx = fmaxf(mx, rmx[i]); }
+        mn = fminf(mn, rmn[0]); mx = fmaxf(mx, rmx[0]);
+        const float sd = sqrtf(sv / sw + 1e-24f);
+        for (int c = 0; c < n_copies; ++c) {
+            out[c * 8 + 0] = mean; out[c * 8 + 1] = sd;
+            out[c * 8 + 2] = (mn - mean) / sd; out[c * 8 + 3] = (mx - mean) / sd;
+        }
+    }
+}
+
+// item rows: concat(metadata feats, ACE, item embedding, recency, novelty) * gamma + beta  (nar_model.py:921-994)
+// stats: [3 groups][8] = {rec mean, sd, zmin, zmax, nov mean, sd, zmin, zmax}; group by row range.
+__global__ __launch_bounds__(256) void k_item_assemble(const int64_t* __restrict__ ids, int R, int g1_begin, int g2_begin,
+                                                       const int64_t* __restrict__ meta_cat, int n_items,
+                                                       const float* __restrict__ ace, int ld_ace,
+                                                       const float* __restrict__ rec_raw, const float* __restrict__ nov_raw,
+                                                       const float* __restrict__ stats,
+                                                       const int64_t* __restrict__ desc, int F,
+                                                       const float* __restrict__ params, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       float* __restrict__ xraw, float* __restrict__ xs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * F) return;
+    const int r = (int)(i / F), c = (int)(i % F);
+    const int64_t* d = desc + (size_t)c * DESC_W;
+    const int kind = (int)d[0], feat = (int)d[1], sub = (int)d[2], dim = (int)d[3];
+    const int64_t id = ids[r];
+    const int g = r < g1_begin ? 0 : (r < g2_begin ? 1 : 2);
+    float v = 0.f;
+    if (kind == COL_OHE) v = (meta_cat[(size_t)feat * n_items + id] == sub) ? 1.f : 0.f;
+    else if (kind == COL_EMB) v = params[d[4] + meta_cat[(size_t)feat * n_items + id] * dim + sub];
+    else if (kind == COL_NUM) v = (float)meta_cat[(size_t)feat * n_items + id];
+    else if (kind == COL_ACE) v = ace[(size_t)id * ld_ace + sub];
+    else if (kind == COL_ITEMEMB) v = params[d[4] + id * dim + sub];
+    else if (kind == COL_RECENCY) v = norm_apply(rec_raw[r], stats + g * 8);
+    else if (kind == COL_NOVELTY) v = norm_apply(nov_raw[r], stats + g * 8 + 4);
+    xraw[i] = v;
+    xs[i] = v * gamma[c] + beta[c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: dgamma / dbeta column sums (deterministic, one workgroup per column) ...
+__global__ __launch_bounds__(256) void k_scale_bwd_cols(const float* __restrict__ dxs, const float* __restrict__ xraw, int R, int F,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float sg = 0.f, sb = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float g = dxs[(size_t)r * F + c];
+        sg += g * xraw[(size_t)r * F + c]; sb += g;
+    }
+    sg = block_sum(sg, red);
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+}
+// ... and the embedding scatter-add (the IndexedSlices of tf.nn.embedding_lookup, nar_model.py:741, 918).
+// src_kind 0: per-row categorical values cat[feat][r];  1: item rows, meta_cat[feat][ids[r]] / ids[r].
+__global__ __launch_bounds__(256) void k_emb_scatter_add(const float* __restrict__ dxs, int R, int F,
+                                                         const int64_t* __restrict__ desc, const float* __restrict__ gamma,
+                                                         int src_kind, const int64_t* __restrict__ cat, const int64_t* __restrict__ ids,
+                                                         const int64_t* __restrict__ meta_cat, int n_items,
+                                                         float* __restrict__ grads) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * F) return;
+    const int r = (int)(i / F), c = (int)(i % F);
+    const int64_t* d = desc + (size_t)c * DESC_W;
+    const int kind = (int)d[0], feat = (int)d[1], sub = (int)d[2], dim = (int)d[3];
+    if (kind != COL_EMB && kind != COL_ITEMEMB) return;
+    const float g = dxs[i] * gamma[c];
+    if (g == 0.f) return;
+    int64_t row;
+    if (kind == COL_ITEMEMB) row = ids[r];
+    else row = src_kind == 0 ? cat[(size_t)feat * R + r] : meta_cat[(size_t)feat * n_items + ids[r]];
+    atomicAdd(grads + d[4] + row * dim + sub, g);
+}
+
+// occurrence counts of pool slots over the sampled negatives (only used for the empty-buffer first batch,
+// where the normalisation population is "this call's non-pad ids WITH repetition", nar_model.py:1078-1084)
+__global__ __launch_bounds__(256) void k_slot_weights(const int* __restrict__ neg_slot, size_t n, int pmax,
+                                                      const int64_t* __restrict__ pool, float* __restrict__ w /*[pmax+1], zeroed*/) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = neg_slot[i];
+    if (s >= 0 && s < pmax && pool[s] != 0) atomicAdd(w + s, 1.0f);   // integer-valued floats: order independent
+}
+__global__ __launch_bounds__(256) void k_nonzero_weights(const int64_t* __restrict__ ids, int n, float* __restrict__ w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) w[i] = ids[i] != 0 ? 1.f : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int cham_ctx_assemble(const int64_t* cat, const float* num, int R, const int64_t* desc, int F,
+                                 const float* params, const float* gamma, const float* beta,
+                                 float* xraw, float* xs, void* stream) {
+    if (!desc || !params || !gamma || !beta || !xraw || !xs || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    const size_t n = (size_t)R * F;
+    hipLaunchKernelGGL(k_ctx_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cat, num, R, desc, F, params, gamma, beta, xraw, xs);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, int R, const int64_t* created,
+                                     const float* pop_norm, float* rec_raw, float* nov_raw, void* stream) {
+    if (!ids || !ref_ts || !created || !pop_norm || !rec_raw || !nov_raw || R <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_item_dynamic_raw, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       ids, ref_ts, R, created, pop_norm, rec_raw, nov_raw);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// stats from the recent-clicks population (buffer non-empty): same stats for the 3 call groups
+extern "C" int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, int64_t max_ts, const int64_t* created,
+                                           const float* pop_norm, float* scratch /*2*n_last*/, float* stats /*[3][8]*/,
+                                           void* stream) {
+    if (!last_ids || n_last <= 0 || !created || !pop_norm || !scratch || !stats) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_last + 255) / 256), dim3(256), 0, st, last_ids, n_last, max_ts, created,
+                       pop_norm, scratch, scratch + n_last);
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)nullptr, n_last, stats, 3);
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_last, (const float*)nullptr, n_last, stats + 4, 3);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// stats from the call's own rows (empty buffer = very first batch): one group at a time
+extern "C" int cham_norm_stats_from_rows(const float* rec_raw, const float* nov_raw, const float* weights, int n,
+                                         float* stats_group /*[8]*/, void* stream) {
+    if (!rec_raw || !nov_raw || !weights || n <= 0 || !stats_group) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, rec_raw, weights, n, stats_group, 1);
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, nov_raw, weights, n, stats_group + 4, 1);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_row_weights(const int64_t* ids, int n_ids, const int32_t* neg_slot, size_t n_neg, int pmax,
+                                const int64_t* pool, float* w_ids, float* w_slots, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ids && n_ids > 0) hipLaunchKernelGGL(k_nonzero_weights, dim3((n_ids + 255) / 256), dim3(256), 0, st, ids, n_ids, w_ids);
+    if (neg_slot && n_neg > 0) {
+        if (hipMemsetAsync(w_slots, 0, (size_t)(pmax + 1) * sizeof(float), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_slot_weights, dim3((unsigned)((n_neg + 255) / 256)), dim3(256), 0, st, neg_slot, n_neg, pmax, pool, w_slots);
+    }
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_item_assemble(const int64_t* ids, int R, int g1_begin, int g2_begin, const int64_t* meta_cat, int n_items,
+                                  const float* ace, int ld_ace, const float* rec_raw, const float* nov_raw,
+                                  const float* stats, const int64_t* desc, int F, const float* params,
+                                  const float* gamma, const float* beta, float* xraw, float* xs, void* stream) {
+    if (!ids || !desc || !params || !gamma || !beta || !xraw || !xs || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    const size_t n = (size_t)R * F;
+    hipLaunchKernelGGL(k_item_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ids, R, g1_begin, g2_begin, meta_cat, n_items, ace, ld_ace, rec_raw, nov_raw, stats, desc, F,
+                       params, gamma, beta, xraw, xs);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, const int64_t* desc, const float* gamma,
+                                int src_kind, const int64_t* cat, const int64_t* ids, const int64_t* meta_cat, int n_items,
+                                float* dgamma, float* dbeta, float* grads, void* stream) {
+    if (!dxs || !xraw || !desc || !gamma || !dgamma || !dbeta || !grads || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scale_bwd_cols, dim3(F), dim3(256), 0, st, dxs, xraw, R, F, dgamma, dbeta);
+    const size_t n = (size_t)R * F;
+    hipLaunchKernelGGL(k_emb_scatter_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxs, R, F, desc, gamma,
+                       src_kind, cat, ids, meta_cat, n_items, grads);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

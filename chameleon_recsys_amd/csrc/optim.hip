@@ -1,0 +1,153 @@
+// L2 regularisation, TF-flavoured Adam, bias-gradient column sums, loss finalisation (HBM-bound).
+//
+// Replaces nar_module/nar/nar_model.py:655 (tf.losses.get_regularization_loss: sum of scale * l2_loss over
+// Dense kernels, embeddings, gamma/beta - NOT biases, NOT the RNN cell), :660-667 (loss) and :708-722
+// (tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients).  TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+// p -= lr_t * m / (sqrt(v) + eps); embedding tables are updated DENSELY (IndexedSlices + dense L2 term are
+// densified by TF; m, v of every row decay every step).  All parameters live in ONE flat fp32 buffer with the
+// regularised tensors first, so the whole optimizer is a single streaming pass: 28 B/param/step.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void k_adam_tf(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, size_t n4, size_t n_reg4, float lambda, float lr_t,
+                                                 float b1, float b2, float eps) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const float l = i < n_reg4 ? lambda : 0.f;           // d/dw (lambda * |w|^2 / 2) = lambda * w
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = G[k] + l * P[k];
+            M[k] = b1 * M[k] + (1.f - b1) * gr;
+            V[k] = b2 * V[k] + (1.f - b2) * gr * gr;
+            P[k] = P[k] - lr_t * M[k] / (sqrtf(V[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ p, size_t n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = reinterpret_cast<const float4*>(p)[i];
+        s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// loss[0] = xe + reg, loss[1] = xe = sum(nll)/sum_mask, loss[2] = reg = lambda/2 * sum(w^2)
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ nll, int BT, float inv_sum_mask,
+                                                       const float* __restrict__ sumsq_partial, int n_partial, float lambda,
+                                                       float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < BT; i += 256) s += nll[i];
+    s = block_sum(s, red);
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) q += sumsq_partial[i];
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        const float xe = s * inv_sum_mask, reg = 0.5f * lambda * q;
+        loss[0] = xe + reg; loss[1] = xe; loss[2] = reg;
+    }
+}
+
+// out[c] = sum_r w[r] * X[r, c]   (w optional).  Stage 1: fixed row chunks -> partial[chunk][F]; stage 2 sums
+// the chunks in order.  Deterministic; X is streamed once with float4 loads when F/4 divides 256.
+__global__ __launch_bounds__(256) void k_colsum_vec(const float* __restrict__ X, int ld, int R, int F, const float* __restrict__ w,
+                                                    int rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float4 sm[256];
+    const int nf4 = F / 4, rpi = 256 / nf4;
+    const int c4 = threadIdx.x % nf4, rl = threadIdx.x / nf4;
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + rl; r < r1; r += rpi) {
+        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ld + c4 * 4);
+        const float ww = w ? w[r] : 1.f;
+        acc.x += ww * x.x; acc.y += ww * x.y; acc.z += ww * x.z; acc.w += ww * x.w;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rpi; ++k) {
+            const float4 y = sm[k * nf4 + c4];
+            acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
+        }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * F + c4 * 4) = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_colsum_gen(const float* __restrict__ X, int ld, int R, int F, const float* __restrict__ w,
+                                                    int rows_per_chunk, float* __restrict__ partial) {
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    for (int c = threadIdx.x; c < F; c += 256) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += (w ? w[r] : 1.f) * X[(size_t)r * ld + c];
+        partial[(size_t)blockIdx.x * F + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nchunks, int F, float* __restrict__ out,
+                                                      int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * F + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
+                            float lr_t, float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grads || !m || !v || (n & 3) || (n_reg & 3) || n_reg > n) return -CHAM_ERR_ARG;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) return CHAM_OK;
+    hipLaunchKernelGGL(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n4, n_reg / 4,
+                       lambda, lr_t, beta1, beta2, eps);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_sumsq_partial(const float* params, size_t n_reg, float* partial /*[1024]*/, void* stream) {
+    if (!params || !partial || (n_reg & 3)) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, params, n_reg / 4, partial);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_loss_finalize(const float* nll, int BT, float sum_mask, const float* sumsq_partial, float lambda,
+                                  float* loss /*[3]*/, void* stream) {
+    if (!nll || !sumsq_partial || !loss || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, BT, 1.0f / sum_mask, sumsq_partial,
+                       SUMSQ_BLOCKS, lambda, loss);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" size_t cham_colsum_workspace_bytes(int R, int F) {
+    int rpc = (R + 1023) / 1024; if (rpc < 64) rpc = 64;
+    const int nchunks = (R + rpc - 1) / rpc;
+    return (size_t)nchunks * F * sizeof(float);
+}
+
+extern "C" int cham_colsum(const float* X, int ld, int R, int F, const float* w, float* out, int accumulate,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !out || !workspace || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    if (workspace_bytes < cham_colsum_workspace_bytes(R, F)) return -CHAM_ERR_ARG;
+    int rpc = (R + 1023) / 1024; if (rpc < 64) rpc = 64;
+    const int nchunks = (R + rpc - 1) / rpc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (F % 4 == 0) && (F / 4 <= 256) && (256 % (F / 4) == 0) && (ld % 4 == 0);
+    if (vec) hipLaunchKernelGGL(k_colsum_vec, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
+    else hipLaunchKernelGGL(k_colsum_gen, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
+    hipLaunchKernelGGL(k_colsum_final, dim3((F + 255) / 256), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

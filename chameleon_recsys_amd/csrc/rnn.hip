@@ -1,0 +1,219 @@
+// Recurrent session encoder time-step kernels (UGRNN = the reference's cell; GRU selectable).
+//
+// Replaces nar_module/nar/nar_model.py:1308-1361: MultiRNNCell([DropoutWrapper(UGRNNCell(H))]) unrolled by
+// tf.nn.dynamic_rnn(sequence_length).  UGRNN step (tf.contrib.rnn.UGRNNCell, TF r1.12):
+//     [g_act, c_act] = [x_t, h] W + b ;  c = tanh(c_act) ; g = sigmoid(g_act + 1) ; h' = g*h + (1-g)*c
+// dynamic_rnn: for t >= len[b] the output row is zero and the state is carried unchanged.
+//
+// MI355X design: the input half x_t*W_x (+b) for ALL t is one big MFMA GEMM (gemm.hip).  The recurrence is
+// independent across sessions, so one workgroup owns 32 session rows for ALL time steps - no inter-workgroup
+// synchronisation, h lives in LDS, h*W_h runs on v_mfma_f32_32x32x2_f32 (W_h streamed from L2: 512 KB at
+// H=256), gates / tanh / sigmoid / length masking fused into the MFMA epilogue.  Hidden size is padded to a
+// multiple of 128 (H=255 -> 256); pad lanes stay exactly 0 (zero weights, tanh(0)=0).
+#include "common.h"
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// NT = 32-wide hidden tiles per wave (Hp = 128*NT)
+template <int NT>
+__global__ __launch_bounds__(256) void k_ugrnn_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
+                                                   const int* __restrict__ seq_len, int B, int T,
+                                                   float* __restrict__ out, float* __restrict__ hprev,
+                                                   float* __restrict__ G, float* __restrict__ Cc) {
+    constexpr int Hp = 128 * NT, LDH = Hp + 1, H2 = 2 * Hp;
+    extern __shared__ __attribute__((aligned(16))) float hL[];       // [32][LDH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 32;
+    const int fl = lane & 31, kl = lane >> 5;
+    for (int i = threadIdx.x; i < 32 * LDH; i += 256) hL[i] = 0.f;
+    __syncthreads();
+    const int hid0 = wave * (Hp / 4);
+    for (int t = 0; t < T; ++t) {
+        floatx16 ag[NT], ac[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ag[j][e] = 0.f; ac[j][e] = 0.f; }
+        const float* hrow = hL + fl * LDH + kl;
+        const float* wg = Wh + (size_t)kl * H2 + hid0 + fl;
+#pragma unroll 8
+        for (int k = 0; k < Hp; k += 2) {
+            const float a = hrow[k];
+            const float* w = wg + (size_t)k * H2;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                ag[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ag[j], 0, 0, 0);
+                ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], ac[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave finished reading h_{t-1}
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                if (b >= B) continue;
+                const size_t bt = (size_t)b * T + t;
+                const float zg = ag[j][e] + xproj[bt * H2 + hid];
+                const float zc = ac[j][e] + xproj[bt * H2 + Hp + hid];
+                const float g = sigmoidf_(zg + 1.0f);      // forget_bias = 1.0
+                const float c = tanhf(zc);
+                const float ho = hL[row * LDH + hid];
+                const float hn = g * ho + (1.f - g) * c;
+                const bool valid = t < seq_len[b];
+                out[bt * Hp + hid] = valid ? hn : 0.f;
+                hprev[bt * Hp + hid] = ho;
+                G[bt * Hp + hid] = g;
+                Cc[bt * Hp + hid] = c;
+                if (valid) hL[row * LDH + hid] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward through time.  dout = dL/d(out) [B,T,Hp];  writes dxproj [B,T,2Hp] (= dL/d[g_act, c_act]).
+// WhT = transpose(Wh) [2Hp, Hp].
+template <int NT>
+__global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
+                                                   const int* __restrict__ seq_len, int B, int T,
+                                                   const float* __restrict__ hprev, const float* __restrict__ G,
+                                                   const float* __restrict__ Cc, float* __restrict__ dxproj) {
+    constexpr int Hp = 128 * NT, H2 = 2 * Hp, LDZ = H2 + 1;
+    extern __shared__ __attribute__((aligned(16))) float dzL[];      // [32][LDZ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 32;
+    const int fl = lane & 31, kl = lane >> 5;
+    const int hid0 = wave * (Hp / 4);
+    floatx16 carry[NT];                                     // dL/dh_t flowing to step t (accumulator layout)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) carry[j][e] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        floatx16 direct[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                float dzg = 0.f, dzc = 0.f, dd = 0.f;
+                if (b < B && t < seq_len[b]) {
+                    const size_t o = ((size_t)b * T + t) * Hp + hid;
+                    const float dh = dout[o] + carry[j][e];
+                    const float g = G[o], c = Cc[o], hp = hprev[o];
+                    dzg = dh * (hp - c) * g * (1.f - g);
+                    dzc = dh * (1.f - g) * (1.f - c * c);
+                    dd = dh * g;
+                }
+                direct[j][e] = dd;
+                dzL[row * LDZ + hid] = dzg;
+                dzL[row * LDZ + Hp + hid] = dzc;
+                if (b < B) {
+                    const size_t o2 = ((size_t)b * T + t) * H2;
+                    dxproj[o2 + hid] = dzg;
+                    dxproj[o2 + Hp + hid] = dzc;
+                }
+            }
+        }
+        __syncthreads();
+        floatx16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        const float* zrow = dzL + fl * LDZ + kl;
+        const float* wt = WhT + (size_t)kl * Hp + hid0 + fl;
+#pragma unroll 8
+        for (int k = 0; k < H2; k += 2) {
+            const float a = zrow[k];
+            const float* w = wt + (size_t)k * Hp;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                const bool valid = (b < B) && (t < seq_len[b]);
+                carry[j][e] = valid ? (direct[j][e] + acc[j][e]) : carry[j][e];
+            }
+        __syncthreads();                                   // dzL is rewritten by the next step
+    }
+}
+
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ outp) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < rows && bx + tx < cols) tile[r][tx] = in[(size_t)(by + r) * cols + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < cols && by + tx < rows) outp[(size_t)(bx + r) * rows + by + tx] = tile[tx][r];
+}
+
+extern "C" int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, rows, cols, out);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+template <int NT>
+static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_len, int B, int T, float* out, float* hprev,
+                            float* G, float* Cc, hipStream_t st) {
+    const size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
+    auto kern = k_ugrnn_fwd<NT>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+template <int NT>
+static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_len, int B, int T, const float* hprev,
+                            const float* G, const float* Cc, float* dxproj, hipStream_t st) {
+    const size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
+    auto kern = k_ugrnn_bwd<NT>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// cell_kind: 0 = UGRNN
+extern "C" int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp,
+                            float* out, float* hprev, float* G, float* Cc, void* stream) {
+    if (!xproj || !Wh || !seq_len || !out || !hprev || !G || !Cc || B <= 0 || T <= 0) return -CHAM_ERR_ARG;
+    if (cell_kind != 0) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Hp) {
+        case 128: return launch_ugrnn_fwd<1>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
+        case 256: return launch_ugrnn_fwd<2>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
+        case 384: return launch_ugrnn_fwd<3>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
+        case 512: return launch_ugrnn_fwd<4>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
+        default: return -CHAM_ERR_ARG;
+    }
+}
+
+extern "C" int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
+                            const float* hprev, const float* G, const float* Cc, float* dxproj, void* stream) {
+    if (!dout || !WhT || !seq_len || !hprev || !G || !Cc || !dxproj || B <= 0 || T <= 0) return -CHAM_ERR_ARG;
+    if (cell_kind != 0) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Hp) {
+        case 128: return launch_ugrnn_bwd<1>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);
+        case 256: return launch_ugrnn_bwd<2>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);
+        case 384: return launch_ugrnn_bwd<3>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);
+        case 512: return launch_ugrnn_bwd<4>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);
+        default: return -CHAM_ERR_ARG;
+    }
+}

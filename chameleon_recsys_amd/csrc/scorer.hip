@@ -1,0 +1,253 @@
+// Candidate combine, scoring tail, sampled-softmax cross-entropy and their backward passes.
+//
+// Replaces (nar_module/nar/nar_model.py):
+//   * :356-405  the PreCAR layer over [B,T,N,F] negatives.  PreCAR(x) = leaky(W1^T(gamma*[u;i]+beta)+b1)
+//               = leaky(U[b,t] + V[item]) with U = X_ctx*W1_ctx + b1 (per click) and V = X_item*W1_item (per
+//               unique item row, features.hip) - exact up to fp32 re-association, valid for keep_prob==1.
+//   * :478-517  cand (.) pred  (fused into the scorer's first GEMM as a row-broadcast prologue),
+//               the last scorer layer (32 -> 1), softmax(logits / tau) over [positive, N negatives]
+//   * :639-667  masked negative log-likelihood and its gradient.
+//
+// Row layout of every "CAR row" matrix: rows [0,BT) = clicked inputs, rows [BT, BT + BT*(1+N)) =
+// candidates ordered (b,t,c) with c = 0 the positive, c = 1..N the negatives.
+// V row set: [0,BT) inputs, [BT,2BT) positives, [2BT, 2BT+pmax] pool slots (last = zero-padding item).
+#include "common.h"
+
+__device__ __forceinline__ int cand_vrow(int bt, int c, int BT, int N, int pmax, const int* __restrict__ neg_slot) {
+    if (c == 0) return BT + bt;
+    int s = neg_slot[(size_t)bt * N + (c - 1)];
+    if (s < 0) s = pmax;                      // masked click: any finite row (its gradient is exactly 0)
+    return 2 * BT + s;
+}
+
+// Z1[row,:] = leaky(U[u,:] + V[v,:])
+__global__ __launch_bounds__(256) void k_combine_fwd(const float* __restrict__ U, const float* __restrict__ V, int C,
+                                                     int BT, int N, int pmax, const int* __restrict__ neg_slot,
+                                                     float* __restrict__ Z1) {
+    const int row = blockIdx.x;
+    int u, v;
+    if (row < BT) { u = row; v = row; }
+    else {
+        const int i = row - BT, bt = i / (N + 1), c = i % (N + 1);
+        u = bt; v = cand_vrow(bt, c, BT, N, pmax, neg_slot);
+    }
+    const float4* pu = reinterpret_cast<const float4*>(U + (size_t)u * C);
+    const float4* pv = reinterpret_cast<const float4*>(V + (size_t)v * C);
+    float4* po = reinterpret_cast<float4*>(Z1 + (size_t)row * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 a = pu[k], b = pv[k];
+        float4 o;
+        o.x = act_fwd(a.x + b.x, ACT_LEAKY); o.y = act_fwd(a.y + b.y, ACT_LEAKY);
+        o.z = act_fwd(a.z + b.z, ACT_LEAKY); o.w = act_fwd(a.w + b.w, ACT_LEAKY);
+        po[k] = o;
+    }
+}
+
+// dU[bt] = dpre[input bt] + sum_c dpre[cand (bt,c)];  dV_in[bt] = dpre[input bt];  dV_pos[bt] = dpre[cand (bt,0)]
+__global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__ dpre, int C, int BT, int N,
+                                                       float* __restrict__ dU, float* __restrict__ dV) {
+    const int bt = blockIdx.x;
+    const float4* pin = reinterpret_cast<const float4*>(dpre + (size_t)bt * C);
+    const float4* pc = reinterpret_cast<const float4*>(dpre + ((size_t)BT + (size_t)bt * (N + 1)) * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 a = pin[k];
+        const float4 p0 = pc[k];
+        float4 s = make_float4(a.x + p0.x, a.y + p0.y, a.z + p0.z, a.w + p0.w);
+        for (int c = 1; c <= N; ++c) {
+            const float4 x = pc[(size_t)c * (C / 4) + k];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+        reinterpret_cast<float4*>(dU + (size_t)bt * C)[k] = s;
+        reinterpret_cast<float4*>(dV + (size_t)bt * C)[k] = a;
+        reinterpret_cast<float4*>(dV + ((size_t)BT + bt) * C)[k] = p0;
+    }
+}
+
+// dV[2BT + s] = sum over candidate rows that reference slot s, in row order (deterministic, no atomics):
+// every workgroup scans the (L2-resident) slot table and adds matching rows.
+__global__ __launch_bounds__(256) void k_combine_bwd_slots(const float* __restrict__ dpre, int C, int BT, int N, int pmax,
+                                                           const int* __restrict__ neg_slot, float* __restrict__ dV) {
+    __shared__ unsigned long long masks[4][4];
+    const int s = blockIdx.x;                              // 0..pmax
+    const size_t n = (size_t)BT * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = C / 4;                                  // float4 columns; thread owns k = tid, tid+256, ...
+    float4 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i0 = 0; i0 < n; i0 += 1024) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const size_t i = i0 + sub * 256 + threadIdx.x;
+            const bool m = (i < n) && (neg_slot[i] == s);
+            const unsigned long long bal = __ballot(m);
+            if (lane == 0) masks[sub][wave] = bal;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long mk = masks[sub][w];
+                while (mk) {
+                    const int bit = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    const size_t i = i0 + sub * 256 + w * 64 + bit;          // = bt*N + n
+                    const size_t bt = i / N, nn = i % N;
+                    const float4* src = reinterpret_cast<const float4*>(dpre + ((size_t)BT + bt * (N + 1) + 1 + nn) * C);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int k = threadIdx.x + a * 256;
+                        if (k < nk) { const float4 x = src[k]; acc[a].x += x.x; acc[a].y += x.y; acc[a].z += x.z; acc[a].w += x.w; }
+                    }
+                }
+            }
+        __syncthreads();
+    }
+    float4* dst = reinterpret_cast<float4*>(dV + ((size_t)2 * BT + s) * C);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int k = threadIdx.x + a * 256;
+        if (k < nk) dst[k] = acc[a];
+    }
+}
+
+// in place: dM[row] <- dM[row] * pred[bt] * (1 - Z2c[row]^2)   (gradient w.r.t. the CAR tanh pre-activation)
+// dpred_pre[bt]    = (sum_c dM[row] * Z2c[row]) * (1 - pred[bt]^2) (gradient w.r.t. the FC2 tanh pre-activation)
+__global__ __launch_bounds__(256) void k_mulpred_bwd(float* __restrict__ dM, const float* __restrict__ Z2c,
+                                                     const float* __restrict__ pred, int C, int N, float* __restrict__ dpred_pre) {
+    const int bt = blockIdx.x;
+    const float4* pp = reinterpret_cast<const float4*>(pred + (size_t)bt * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 p = pp[k];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c <= N; ++c) {
+            const size_t off = ((size_t)bt * (N + 1) + c) * (C / 4) + k;
+            const float4 g = reinterpret_cast<const float4*>(dM)[off];
+            const float4 z = reinterpret_cast<const float4*>(Z2c)[off];
+            acc.x += g.x * z.x; acc.y += g.y * z.y; acc.z += g.z * z.z; acc.w += g.w * z.w;
+            float4 o;
+            o.x = g.x * p.x * (1.f - z.x * z.x); o.y = g.y * p.y * (1.f - z.y * z.y);
+            o.z = g.z * p.z * (1.f - z.z * z.z); o.w = g.w * p.w * (1.f - z.w * z.w);
+            reinterpret_cast<float4*>(dM)[off] = o;
+        }
+        float4 o;
+        o.x = acc.x * (1.f - p.x * p.x); o.y = acc.y * (1.f - p.y * p.y);
+        o.z = acc.z * (1.f - p.z * p.z); o.w = acc.w * (1.f - p.w * p.w);
+        reinterpret_cast<float4*>(dpred_pre + (size_t)bt * C)[k] = o;
+    }
+}
+
+// last scorer layer (K3 -> 1) + softmax(logits/tau) + masked NLL.  One wave per click (b,t); lanes over the
+// 1+N candidates; max / sum by wavefront shuffles.
+template <int K3>
+__global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restrict__ S3, const float* __restrict__ w4,
+                                                           const float* __restrict__ b4, int BT, int N, float inv_tau,
+                                                           const unsigned char* __restrict__ mask,
+                                                           float* __restrict__ logits, float* __restrict__ probs,
+                                                           float* __restrict__ nll) {
+    const int lane = threadIdx.x & 63, bt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bt >= BT) return;
+    const int NC = N + 1;
+    float w[K3];
+#pragma unroll
+    for (int k = 0; k < K3; ++k) w[k] = w4[k];
+    const float bias = b4[0];
+    float mx = -INFINITY;
+    for (int c = lane; c < NC; c += 64) {
+        const float4* r = reinterpret_cast<const float4*>(S3 + ((size_t)bt * NC + c) * K3);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K3 / 4; ++k) { const float4 x = r[k]; s += x.x * w[4 * k] + x.y * w[4 * k + 1] + x.z * w[4 * k + 2] + x.w * w[4 * k + 3]; }
+        s += bias;
+        logits[(size_t)bt * NC + c] = s;
+        mx = fmaxf(mx, s * inv_tau);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < NC; c += 64) {
+        const float e = expf(logits[(size_t)bt * NC + c] * inv_tau - mx);   // same lane wrote it
+        probs[(size_t)bt * NC + c] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int c = lane; c < NC; c += 64) probs[(size_t)bt * NC + c] *= inv;
+    if (lane == 0) {
+        // -log softmax_0 (log-softmax form of nar_model.py:660; identical wherever the reference is finite)
+        const float z0 = logits[(size_t)bt * NC] * inv_tau;
+        nll[bt] = mask[bt] ? -((z0 - mx) - logf(sum)) : 0.f;
+    }
+}
+
+// ds[row] = (p - [c==0]) * mask / (tau * sum(mask));  dS3pre[row,k] = ds * w4[k] * leaky'(S3[row,k])
+template <int K3>
+__global__ __launch_bounds__(256) void k_score_softmax_bwd(const float* __restrict__ S3, const float* __restrict__ w4,
+                                                           const float* __restrict__ probs, const unsigned char* __restrict__ mask,
+                                                           int BT, int N, float scale /* 1/(tau*sum_mask) */,
+                                                           float* __restrict__ ds, float* __restrict__ dS3) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int NC = N + 1;
+    if (row >= (size_t)BT * NC) return;
+    const int bt = (int)(row / NC), c = (int)(row % NC);
+    const float g = mask[bt] ? (probs[row] - (c == 0 ? 1.f : 0.f)) * scale : 0.f;
+    ds[row] = g;
+    const float4* r = reinterpret_cast<const float4*>(S3 + row * K3);
+    float4* o = reinterpret_cast<float4*>(dS3 + row * K3);
+#pragma unroll
+    for (int k = 0; k < K3 / 4; ++k) {
+        const float4 x = r[k];
+        float4 y;
+        y.x = g * w4[4 * k] * act_bwd_from_out(x.x, ACT_LEAKY);
+        y.y = g * w4[4 * k + 1] * act_bwd_from_out(x.y, ACT_LEAKY);
+        y.z = g * w4[4 * k + 2] * act_bwd_from_out(x.z, ACT_LEAKY);
+        y.w = g * w4[4 * k + 3] * act_bwd_from_out(x.w, ACT_LEAKY);
+        o[k] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                                float* Z1, void* stream) {
+    if (!U || !V || !neg_slot || !Z1 || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    const long rows = (long)BT + (long)BT * (N + 1);
+    hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot, Z1);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                                float* dU, float* dV, void* stream) {
+    if (!dpre || !neg_slot || !dU || !dV || (C & 3) || C > 4096 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_combine_bwd_u, dim3(BT), dim3(256), 0, st, dpre, C, BT, N, dU, dV);
+    hipLaunchKernelGGL(k_combine_bwd_slots, dim3(pmax + 1), dim3(256), 0, st, dpre, C, BT, N, pmax, neg_slot, dV);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre,
+                                void* stream) {
+    if (!dM || !Z2c || !pred || !dpred_pre || (C & 3) || BT <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_mulpred_bwd, dim3(BT), dim3(256), 0, (hipStream_t)stream, dM, Z2c, pred, C, N, dpred_pre);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                                      const uint8_t* mask, float* logits, float* probs, float* nll, void* stream) {
+    if (!S3 || !w4 || !b4 || !mask || !logits || !probs || !nll || K3 != 32 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_score_softmax_fwd<32>, dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S3, w4, b4, BT, N,
+                       1.0f / tau, mask, logits, probs, nll);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                      int BT, int N, float tau, float sum_mask, float* ds, float* dS3, void* stream) {
+    if (!S3 || !w4 || !probs || !mask || !ds || !dS3 || K3 != 32 || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
+    const size_t rows = (size_t)BT * (N + 1);
+    hipLaunchKernelGGL(k_score_softmax_bwd<32>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
+                       probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

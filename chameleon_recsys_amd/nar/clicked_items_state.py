@@ -1,0 +1,100 @@
+"""Recent-clicks state (host side): recent-clicks ring buffer + recent popularity -> ``articles_recent_pop_norm``.
+
+Mirrors nar_module/nar/clicked_items_state.py:10-250 for the parts the NAR training step consumes
+(update_items_state :187-193, buffer :206-228, recent pop :231-246, global pop :248-250, snapshot around eval
+:49-79).  The co-occurrence matrix / cold-start bookkeeping (:252-255, benchmarks only) are out of scope.
+Vectorised numpy (np.bincount instead of collections.Counter); results are bit-identical to the reference class
+(tests/golden/state_trace.npz).
+"""
+import numpy as np
+
+MILISECS_BY_HOUR = 1000 * 60 * 60
+
+
+class ClickedItemsState:
+
+    def __init__(self, recent_clicks_buffer_hours, recent_clicks_buffer_max_size, recent_clicks_for_normalization, num_items):
+        self.recent_clicks_buffer_hours = recent_clicks_buffer_hours
+        self.recent_clicks_buffer_max_size = recent_clicks_buffer_max_size
+        self.recent_clicks_for_normalization = recent_clicks_for_normalization
+        self.num_items = num_items
+        self.reset_state()
+
+    def reset_state(self):
+        self.articles_pop = np.zeros(shape=[self.num_items], dtype=np.int64)
+        self.articles_recent_pop = np.zeros(shape=[self.num_items], dtype=np.int64)
+        self._update_recent_pop_norm(self.articles_recent_pop)
+        # two columns (article_id, click_timestamp), newest first
+        self.pop_recent_clicks_buffer = np.zeros(shape=[self.recent_clicks_buffer_max_size, 2], dtype=np.int64)
+        self.current_step = 0
+
+    def save_state_checkpoint(self):
+        self.articles_pop_chkp = np.copy(self.articles_pop)
+        self.pop_recent_clicks_buffer_chkp = np.copy(self.pop_recent_clicks_buffer)
+        self.articles_recent_pop_chkp = np.copy(self.articles_recent_pop)
+        self.current_step_chkp = self.current_step
+
+    def restore_state_checkpoint(self):
+        self.articles_pop = self.articles_pop_chkp
+        self.pop_recent_clicks_buffer = self.pop_recent_clicks_buffer_chkp
+        # NB the reference does not restore articles_recent_pop(_norm) (clicked_items_state.py:61-79): it is recomputed
+        # from the restored buffer at the next update.  We keep that behaviour.
+        self.current_step = self.current_step_chkp
+        del self.articles_pop_chkp, self.pop_recent_clicks_buffer_chkp, self.articles_recent_pop_chkp
+
+    def get_articles_pop(self):
+        return self.articles_pop
+
+    def get_articles_recent_pop(self):
+        return self.articles_recent_pop
+
+    def get_articles_recent_pop_norm(self):
+        return self.articles_recent_pop_norm
+
+    def get_recent_clicks_buffer(self):
+        return self.pop_recent_clicks_buffer[:, 0]
+
+    def increment_current_step(self):
+        self.current_step += 1
+
+    def get_current_step(self):
+        return self.current_step
+
+    def update_items_state(self, batch_clicked_items, batch_clicked_timestamps):
+        self._update_recently_clicked_items_buffer(batch_clicked_items, batch_clicked_timestamps)
+        self._update_recent_pop_items()
+        self._update_pop_items(batch_clicked_items)
+
+    def _update_recently_clicked_items_buffer(self, batch_clicked_items, batch_clicked_timestamps):
+        batch = np.hstack([batch_clicked_items.reshape(-1, 1), batch_clicked_timestamps.reshape(-1, 1)])[::-1]
+        self.truncate_last_hours_recent_clicks_buffer(np.min(batch_clicked_timestamps))
+        buf = np.vstack([batch, self.pop_recent_clicks_buffer])[:self.recent_clicks_buffer_max_size]
+        if buf.shape[0] < self.recent_clicks_buffer_max_size:
+            buf = np.vstack([buf, np.zeros(shape=[self.recent_clicks_buffer_max_size - buf.shape[0], 2], dtype=np.int64)])
+        self.pop_recent_clicks_buffer = buf
+
+    def truncate_last_hours_recent_clicks_buffer(self, reference_timestamp):
+        thr = reference_timestamp - int(self.recent_clicks_buffer_hours * MILISECS_BY_HOUR)
+        self.pop_recent_clicks_buffer = self.pop_recent_clicks_buffer[self.pop_recent_clicks_buffer[:, 1] >= thr]
+
+    def _update_recent_pop_items(self):
+        ids = self.pop_recent_clicks_buffer[:, 0]
+        self.articles_recent_pop = np.bincount(ids[ids != 0], minlength=self.num_items).astype(np.int64)
+        self._update_recent_pop_norm(self.articles_recent_pop)
+
+    def _update_recent_pop_norm(self, articles_recent_pop):
+        min_norm_pop = 1.0 / self.recent_clicks_for_normalization
+        self.articles_recent_pop_norm = np.maximum(articles_recent_pop / (articles_recent_pop.sum() + 1), [min_norm_pop])
+
+    def _update_pop_items(self, batch_items_nonzero):
+        self.articles_pop += np.bincount(batch_items_nonzero, minlength=self.num_items)
+
+
+def batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps):
+    """ItemsStateUpdaterHook.after_run, nar_model.py:1635-1646: flatten [clicks ; last label], drop padding; the last
+    label re-uses the max timestamp of its session."""
+    batch_clicked_items = np.concatenate([clicked_items, last_item_label], axis=1).reshape(-1)
+    nz = np.nonzero(batch_clicked_items)
+    last_ts = np.max(clicked_timestamps, axis=1).reshape(-1, 1)
+    ts = np.concatenate([clicked_timestamps, last_ts], axis=1).reshape(-1)
+    return batch_clicked_items[nz], ts[nz]

@@ -1,0 +1,294 @@
+"""Parameter layout of the NAR model in HBM: ONE flat fp32 buffer (regularised tensors first), padded shapes,
+feature-column descriptors, and conversion to / from the reference's logical variable shapes.
+
+Logical variable inventory: nar_module/nar/nar_model.py (scopes under ``main/``):
+  :736-742 ``{name}_cat_embedding``, :911-919 ``items_embedding``, :890-898 ``gamma_scale/beta_center``,
+  :375-388 PreCAR/CAR Dense, :1317 UGRNNCell kernel/bias, :411-426 FC1/FC2, :447-473 matching_dense_layer_1..4.
+Padding rules (MI355X): feature widths -> multiples of 4 floats (16-byte rows for float4 / global_load_dwordx4),
+rnn_units -> multiple of 128 (4 waves x 32-wide MFMA tiles); pad weights are 0 and provably stay 0.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+ARTICLE_REQ_FEATURES = ['article_id', 'created_at_ts']          # nar_model.py:22
+SESSION_REQ_SEQ_FEATURES = ['item_clicked', 'event_timestamp']  # nar_model.py:23
+
+COL_ZERO, COL_OHE, COL_EMB, COL_NUM, COL_ACE, COL_ITEMEMB, COL_RECENCY, COL_NOVELTY = range(8)
+
+DEFAULT_INTERNAL_FEATURES = {'recency': True, 'novelty': True, 'article_content_embeddings': True,
+                             'item_clicked_embeddings': True}
+
+
+def get_embedding_size(unique_val_count, const_mult=8):
+    """nar_model.py:25-26."""
+    return int(math.floor(const_mult * unique_val_count ** 0.25))
+
+
+def ceil_to(x, m):
+    return ((x + m - 1) // m) * m
+
+
+class Entry:
+    __slots__ = ("name", "shape", "offset", "size", "reg", "init", "fan")
+
+    def __init__(self, name, shape, reg, init, fan=None):
+        self.name, self.shape, self.reg, self.init, self.fan = name, tuple(shape), reg, init, fan
+        self.size = ceil_to(int(np.prod(shape)), 4)
+        self.offset = -1
+
+
+class ParamLayout:
+    def __init__(self, session_features_config, articles_features_config, n_items, ace_dim, CAR_embedding_size,
+                 rnn_units, rnn_num_layers=1, rnn_cell='ugrnn', internal_features_config=None,
+                 max_cardinality_for_ohe=10):
+        ifc = dict(DEFAULT_INTERNAL_FEATURES)
+        if internal_features_config:
+            ifc.update(internal_features_config)
+        self.ifc = ifc
+        self.C = C = CAR_embedding_size
+        if C % 4:
+            raise ValueError("CAR_embedding_size must be a multiple of 4")
+        self.H = H = rnn_units
+        self.Hp = Hp = ceil_to(H, 128)
+        if Hp > 512:
+            raise ValueError("rnn_units > 512 is not supported by the recurrent kernel")
+        self.L = rnn_num_layers
+        self.cell = rnn_cell
+        if rnn_cell != 'ugrnn':
+            raise NotImplementedError("rnn_cell=%r: only the reference's UGRNN cell is implemented in this build" % rnn_cell)
+        self.n_items = n_items
+        self.D = ace_dim
+        scfg = session_features_config['sequence_features']
+        acfg = articles_features_config
+        self.max_ohe = max_cardinality_for_ohe
+
+        emb, ctx_cols, item_cols = [], [], []
+        self.ctx_cat_names, self.ctx_num_names, self.meta_names = [], [], []
+        # ---- user-context columns, nar_model.py:746-767 (dict insertion order)
+        for name, cfg in scfg.items():
+            if name in SESSION_REQ_SEQ_FEATURES:
+                continue
+            if cfg['type'] == 'categorical':
+                fi = len(self.ctx_cat_names)
+                self.ctx_cat_names.append(name)
+                card = cfg['cardinality']
+                if card <= max_cardinality_for_ohe:
+                    ctx_cols += [(COL_OHE, fi, s, card, None) for s in range(card)]
+                else:
+                    dim = get_embedding_size(card)
+                    e = Entry('ctx_emb/' + name, (card, dim), True, 'xavier')
+                    emb.append(e)
+                    ctx_cols += [(COL_EMB, fi, s, dim, e) for s in range(dim)]
+            elif cfg['type'] == 'numerical':
+                fi = len(self.ctx_num_names)
+                self.ctx_num_names.append(name)
+                ctx_cols.append((COL_NUM, fi, 0, 1, None))
+            else:
+                raise Exception('Invalid feature type: {}'.format(name))     # nar_model.py:760
+        if not ctx_cols:
+            ctx_cols.append((COL_ZERO, 0, 0, 1, None))                        # nar_model.py:323-325
+        # ---- item columns, nar_model.py:926-990
+        for name, cfg in acfg.items():
+            if name in ARTICLE_REQ_FEATURES:
+                continue
+            fi = len(self.meta_names)
+            self.meta_names.append(name)
+            if cfg['type'] == 'categorical':
+                card = cfg['cardinality']
+                if card <= max_cardinality_for_ohe:
+                    item_cols += [(COL_OHE, fi, s, card, None) for s in range(card)]
+                else:
+                    dim = get_embedding_size(card)
+                    e = Entry('meta_emb/' + name, (card, dim), True, 'xavier')
+                    emb.append(e)
+                    item_cols += [(COL_EMB, fi, s, dim, e) for s in range(dim)]
+            elif cfg['type'] == 'numerical':
+                item_cols.append((COL_NUM, fi, 0, 1, None))
+            else:
+                raise Exception('Invalid feature type: {}'.format(name))
+        if ifc['article_content_embeddings']:
+            item_cols += [(COL_ACE, 0, s, self.D, None) for s in range(self.D)]
+        if ifc['item_clicked_embeddings']:
+            E = get_embedding_size(n_items)
+            e = Entry('items_embedding', (n_items, E), True, 'xavier')
+            emb.append(e)
+            item_cols += [(COL_ITEMEMB, 0, s, E, e) for s in range(E)]
+        if ifc['recency']:
+            item_cols.append((COL_RECENCY, 0, 0, 1, None))
+        if ifc['novelty']:
+            item_cols.append((COL_NOVELTY, 0, 0, 1, None))
+        self.f_ctx, self.f_item = len(ctx_cols), len(item_cols)
+        self.F = self.f_ctx + self.f_item
+        self.Fc, self.Fi = ceil_to(self.f_ctx, 4), ceil_to(self.f_item, 4)
+        ctx_cols += [(COL_ZERO, 0, 0, 1, None)] * (self.Fc - self.f_ctx)
+        item_cols += [(COL_ZERO, 0, 0, 1, None)] * (self.Fi - self.f_item)
+        self._ctx_cols, self._item_cols = ctx_cols, item_cols
+
+        Fc, Fi = self.Fc, self.Fi
+        ents = list(emb)
+        self.n_emb_entries = len(emb)
+        ents += [Entry('gamma_ctx', (Fc,), True, 'gamma'), Entry('beta_ctx', (Fc,), True, 'zeros'),
+                 Entry('gamma_item', (Fi,), True, 'gamma'), Entry('beta_item', (Fi,), True, 'zeros'),
+                 Entry('W1c', (Fc, C), True, 'pad'), Entry('W1i', (Fi, C), True, 'pad'),
+                 Entry('W2', (C, C), True, 'pad'), Entry('Wf1', (Hp, 512), True, 'pad'), Entry('Wf2', (512, C), True, 'pad'),
+                 Entry('Ws1', (C, 128), True, 'pad'), Entry('Ws2', (128, 64), True, 'pad'), Entry('Ws3', (64, 32), True, 'pad'),
+                 Entry('Ws4', (32,), True, 'pad')]
+        ents += [Entry('b1', (C,), False, 'zeros'), Entry('b2', (C,), False, 'zeros')]
+        for l in range(self.L):
+            Ip = C if l == 0 else Hp
+            ents += [Entry('rnn%d/Wx' % l, (Ip, 2 * Hp), False, 'pad'), Entry('rnn%d/Wh' % l, (Hp, 2 * Hp), False, 'pad'),
+                     Entry('rnn%d/b' % l, (2 * Hp,), False, 'zeros')]
+        ents += [Entry('bf1', (512,), False, 'zeros'), Entry('bf2', (C,), False, 'zeros'), Entry('bs1', (128,), False, 'zeros'),
+                 Entry('bs2', (64,), False, 'zeros'), Entry('bs3', (32,), False, 'zeros'), Entry('bs4', (1,), False, 'zeros')]
+        off = 0
+        self.entries = OrderedDict()
+        for e in ents:
+            e.offset = off
+            off += e.size
+            self.entries[e.name] = e
+        self.total = off
+        self.n_reg = sum(e.size for e in ents if e.reg)
+        self.emb_end = sum(e.size for e in emb)                 # embedding-gradient region [0, emb_end)
+        # regularised entries must be a prefix
+        seen_nonreg = False
+        for e in ents:
+            if not e.reg:
+                seen_nonreg = True
+            elif seen_nonreg:
+                raise AssertionError("regularised tensors must come first")
+
+    # ------------------------------------------------------------------ descriptors
+    def _desc(self, cols):
+        d = np.zeros((len(cols), 5), dtype=np.int64)
+        for i, (kind, feat, sub, dim, ent) in enumerate(cols):
+            d[i] = (kind, feat, sub, dim, ent.offset if ent is not None else 0)
+        return d
+
+    def ctx_descriptors(self):
+        return self._desc(self._ctx_cols)
+
+    def item_descriptors(self):
+        return self._desc(self._item_cols)
+
+    # ------------------------------------------------------------------ logical <-> flat
+    def logical_specs(self):
+        """(name -> (shape, init, reg)) in the oracle's / reference's logical variable space."""
+        C, H = self.C, self.H
+        specs = OrderedDict()
+        for name, e in self.entries.items():
+            if name.startswith(('ctx_emb/', 'meta_emb/')) or name == 'items_embedding':
+                specs[name] = (e.shape, 'xavier', True)
+        specs['gamma'] = ((self.F,), 'ones', True)
+        specs['beta'] = ((self.F,), 'zeros', True)
+        specs['PreCAR/kernel'] = ((self.F, C), 'variance_scaling', True)
+        specs['PreCAR/bias'] = ((C,), 'zeros', False)
+        specs['CAR/kernel'] = ((C, C), 'xavier', True)
+        specs['CAR/bias'] = ((C,), 'zeros', False)
+        for l in range(self.L):
+            I = C if l == 0 else H
+            specs['rnn/%d/kernel' % l] = ((I + H, 2 * H), 'xavier', False)
+            specs['rnn/%d/bias' % l] = ((2 * H,), 'zeros', False)
+        specs['FC1/kernel'] = ((H, 512), 'variance_scaling', True)
+        specs['FC1/bias'] = ((512,), 'zeros', False)
+        specs['FC2/kernel'] = ((512, C), 'xavier', True)
+        specs['FC2/bias'] = ((C,), 'zeros', False)
+        dims = [C, 128, 64, 32, 1]
+        inits = ['variance_scaling', 'variance_scaling', 'variance_scaling', 'lecun_uniform']
+        for i in range(4):
+            specs['match%d/kernel' % (i + 1)] = ((dims[i], dims[i + 1]), inits[i], True)
+            specs['match%d/bias' % (i + 1)] = ((dims[i + 1],), 'zeros', False)
+        return specs
+
+    def init_logical(self, seed=42):
+        """TF-1.12 initialiser distributions (xavier_initializer, variance_scaling_initializer(), lecun_uniform;
+        nar_model.py:210, 377, 413, 449-470).  TF's own random streams are not reproducible."""
+        rng = np.random.default_rng(seed)
+        out = OrderedDict()
+        for name, (shape, init, _) in self.logical_specs().items():
+            if init == 'zeros':
+                w = np.zeros(shape, np.float32)
+            elif init == 'ones':
+                w = np.ones(shape, np.float32)
+            else:
+                fan_in, fan_out = shape[0], shape[1]
+                if init == 'xavier':
+                    lim = math.sqrt(6.0 / (fan_in + fan_out))
+                    w = rng.uniform(-lim, lim, size=shape)
+                elif init == 'lecun_uniform':
+                    lim = math.sqrt(3.0 / fan_in)
+                    w = rng.uniform(-lim, lim, size=shape)
+                else:   # variance_scaling_initializer(): factor 2, FAN_IN, truncated normal (2 sigma)
+                    std = math.sqrt(1.3 * 2.0 / fan_in)
+                    w = rng.normal(0, std, size=shape)
+                    bad = np.abs(w) > 2 * std
+                    while bad.any():
+                        w[bad] = rng.normal(0, std, size=int(bad.sum()))
+                        bad = np.abs(w) > 2 * std
+                w = w.astype(np.float32)
+            out[name] = w
+        return out
+
+    def _view(self, flat, name):
+        e = self.entries[name]
+        return flat[e.offset:e.offset + int(np.prod(e.shape))].reshape(e.shape)
+
+    def pack(self, logical):
+        """logical dict -> flat padded numpy buffer."""
+        C, H, Hp, fc, fi = self.C, self.H, self.Hp, self.f_ctx, self.f_item
+        flat = np.zeros(self.total, np.float32)
+        v = lambda n: self._view(flat, n)
+        for name in self.entries:
+            if name.startswith(('ctx_emb/', 'meta_emb/')) or name == 'items_embedding':
+                v(name)[...] = logical[name]
+        g, b = np.asarray(logical['gamma']), np.asarray(logical['beta'])
+        v('gamma_ctx')[:fc] = g[:fc]; v('gamma_item')[:fi] = g[fc:]
+        v('beta_ctx')[:fc] = b[:fc]; v('beta_item')[:fi] = b[fc:]
+        W1 = np.asarray(logical['PreCAR/kernel'])
+        v('W1c')[:fc] = W1[:fc]; v('W1i')[:fi] = W1[fc:]
+        v('b1')[...] = logical['PreCAR/bias']
+        v('W2')[...] = logical['CAR/kernel']; v('b2')[...] = logical['CAR/bias']
+        for l in range(self.L):
+            I = C if l == 0 else H
+            K = np.asarray(logical['rnn/%d/kernel' % l]); bb = np.asarray(logical['rnn/%d/bias' % l])
+            Wx, Wh, rb = v('rnn%d/Wx' % l), v('rnn%d/Wh' % l), v('rnn%d/b' % l)
+            Wx[:I, :H] = K[:I, :H]; Wx[:I, Hp:Hp + H] = K[:I, H:]
+            Wh[:H, :H] = K[I:, :H]; Wh[:H, Hp:Hp + H] = K[I:, H:]
+            rb[:H] = bb[:H]; rb[Hp:Hp + H] = bb[H:]
+        v('Wf1')[:H] = logical['FC1/kernel']; v('bf1')[...] = logical['FC1/bias']
+        v('Wf2')[...] = logical['FC2/kernel']; v('bf2')[...] = logical['FC2/bias']
+        for i, (w, bn) in enumerate([('Ws1', 'bs1'), ('Ws2', 'bs2'), ('Ws3', 'bs3')]):
+            v(w)[...] = logical['match%d/kernel' % (i + 1)]; v(bn)[...] = logical['match%d/bias' % (i + 1)]
+        v('Ws4')[...] = np.asarray(logical['match4/kernel']).reshape(32)
+        v('bs4')[...] = np.asarray(logical['match4/bias']).reshape(1)
+        return flat
+
+    def unpack(self, flat):
+        """flat padded numpy buffer -> logical dict (works for params, grads, Adam slots alike)."""
+        C, H, Hp, fc, fi = self.C, self.H, self.Hp, self.f_ctx, self.f_item
+        flat = np.asarray(flat)
+        v = lambda n: self._view(flat, n)
+        out = OrderedDict()
+        for name in self.entries:
+            if name.startswith(('ctx_emb/', 'meta_emb/')) or name == 'items_embedding':
+                out[name] = v(name).copy()
+        out['gamma'] = np.concatenate([v('gamma_ctx')[:fc], v('gamma_item')[:fi]])
+        out['beta'] = np.concatenate([v('beta_ctx')[:fc], v('beta_item')[:fi]])
+        out['PreCAR/kernel'] = np.concatenate([v('W1c')[:fc], v('W1i')[:fi]], 0)
+        out['PreCAR/bias'] = v('b1').copy()
+        out['CAR/kernel'] = v('W2').copy(); out['CAR/bias'] = v('b2').copy()
+        for l in range(self.L):
+            I = C if l == 0 else H
+            Wx, Wh, rb = v('rnn%d/Wx' % l), v('rnn%d/Wh' % l), v('rnn%d/b' % l)
+            top = np.concatenate([Wx[:I, :H], Wx[:I, Hp:Hp + H]], 1)
+            bot = np.concatenate([Wh[:H, :H], Wh[:H, Hp:Hp + H]], 1)
+            out['rnn/%d/kernel' % l] = np.concatenate([top, bot], 0)
+            out['rnn/%d/bias' % l] = np.concatenate([rb[:H], rb[Hp:Hp + H]])
+        out['FC1/kernel'] = v('Wf1')[:H].copy(); out['FC1/bias'] = v('bf1').copy()
+        out['FC2/kernel'] = v('Wf2').copy(); out['FC2/bias'] = v('bf2').copy()
+        for i, (w, bn) in enumerate([('Ws1', 'bs1'), ('Ws2', 'bs2'), ('Ws3', 'bs3')]):
+            out['match%d/kernel' % (i + 1)] = v(w).copy(); out['match%d/bias' % (i + 1)] = v(bn).copy()
+        out['match4/kernel'] = v('Ws4').reshape(32, 1).copy(); out['match4/bias'] = v('bs4').reshape(1).copy()
+        # reorder to the logical spec order
+        return OrderedDict((k, out[k]) for k in self.logical_specs())

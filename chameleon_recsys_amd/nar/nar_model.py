@@ -1,0 +1,443 @@
+"""NAR module model on MI355X: host orchestration of the HIP kernels in libchameleon_nar.so.
+
+Mirrors nar_module/nar/nar_model.py of the reference:
+  * ``NARModuleModel(mode, inputs, labels, ...)`` keeps the reference constructor (nar_model.py:102-129) and the
+    attributes its SessionRunHook reads (:1435-1467);
+  * the TF graph (:210-722) becomes an eager sequence of stream-ordered kernel launches over device-resident
+    buffers: negative sampling -> de-duplicated feature assembly -> factorised PreCAR -> CAR -> UGRNN -> FCs ->
+    scorer -> sampled softmax loss -> full backward -> L2 + TF-Adam.
+PyTorch is only used for device memory, streams and (data-parallel) torch.distributed; all arithmetic of the step
+runs in the hand-written HIP kernels.  There is no CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr
+from .layout import ParamLayout
+
+ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+
+
+class ModeKeys:                       # tf.estimator.ModeKeys
+    TRAIN = 'train'
+    EVAL = 'eval'
+    PREDICT = 'infer'
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class NARRuntime:
+    """Everything that outlives a single train()/evaluate() call: weights + Adam slots in ONE flat HBM buffer,
+    resident article tables (ACE matrix, metadata - re-fed from numpy every step by the reference,
+    nar_model.py:1458-1467), global step, workspaces."""
+
+    def __init__(self, params, device='cuda:0', seed=42, weights=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.ChameleonLibError("no ROCm device visible: the NAR step has no CPU path")
+        self.device = torch.device(device)
+        self.params = params
+        acfg = params['articles_features_config']
+        ace = np.ascontiguousarray(params['content_article_embeddings_matrix'], dtype=np.float32)
+        self.n_items = acfg['article_id'].get('cardinality', ace.shape[0]) if 'article_id' in acfg else ace.shape[0]
+        if self.n_items != ace.shape[0]:
+            raise ValueError("article_id cardinality (%d) != ACE rows (%d)" % (self.n_items, ace.shape[0]))
+        self.layout = ParamLayout(params['session_features_config'], acfg, self.n_items, ace.shape[1],
+                                  params['CAR_embedding_size'], params['rnn_units'],
+                                  params.get('rnn_num_layers', 1), params.get('rnn_cell', 'ugrnn'),
+                                  params.get('internal_features_config'), params.get('max_cardinality_for_ohe', 10))
+        L = self.layout
+        logical = weights if weights is not None else L.init_logical(seed)
+        dev = self.device
+        self.flat = torch.from_numpy(L.pack(logical)).to(dev)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.grads = torch.zeros_like(self.flat)
+        self.global_step = 0
+        self.tf_random_seed = int(params.get('tf_random_seed', 42))
+        # resident article tables
+        meta = params['articles_metadata']
+        self.ace = torch.from_numpy(ace).to(dev)
+        self.created = torch.from_numpy(np.ascontiguousarray(meta['created_at_ts'], dtype=np.int64)).to(dev)
+        if L.meta_names:
+            mc = np.stack([np.asarray(meta[n], dtype=np.int64) for n in L.meta_names])
+        else:
+            mc = np.zeros((1, self.n_items), np.int64)
+        self.meta_cat = torch.from_numpy(np.ascontiguousarray(mc)).to(dev)
+        self.ctx_desc = torch.from_numpy(L.ctx_descriptors()).to(dev)
+        self.item_desc = torch.from_numpy(L.item_descriptors()).to(dev)
+        self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials
+        self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._plans = {}
+        # data-parallel context (set by parallel.DataParallelNAR)
+        self.dp_rank, self.dp_world, self.dp_allreduce = 0, 1, None
+
+    # ---- views into the flat buffers
+    def view(self, flat, name):
+        e = self.layout.entries[name]
+        return flat[e.offset:e.offset + int(np.prod(e.shape))].view(*e.shape)
+
+    def p(self, name):
+        return self.view(self.flat, name)
+
+    def g(self, name):
+        return self.view(self.grads, name)
+
+    def logical_weights(self):
+        return self.layout.unpack(self.flat.cpu().numpy())
+
+    def logical_grads(self):
+        return self.layout.unpack(self.grads.cpu().numpy())
+
+    def load_logical_weights(self, logical):
+        self.flat.copy_(torch.from_numpy(self.layout.pack(logical)))
+
+    def state_dict(self):
+        return {'flat': self.flat.cpu(), 'm': self.m.cpu(), 'v': self.v.cpu(), 'global_step': self.global_step}
+
+    def load_state_dict(self, sd):
+        self.flat.copy_(sd['flat']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
+        self.global_step = int(sd['global_step'])
+
+    def plan(self, B, T, N, n_buf, Bg=None):
+        key = (B, T, N, n_buf, Bg or B)
+        if key not in self._plans:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            self._plans[key] = StepPlan(self, B, T, N, n_buf, Bg or B)
+        return self._plans[key]
+
+    # ---- thin kernel wrappers -------------------------------------------------------------------------
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
+             dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1):
+        ws = self.gemm_ws if splits != 1 else None
+        check(self.lib.cham_gemm_f32(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
+                                     ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
+                                     self.gemm_ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
+
+    def colsum(self, X, ld, R, F, out, w=None, accumulate=0):
+        check(self.lib.cham_colsum(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(self.colsum_ws),
+                                   self.colsum_ws.numel() * 4, _stream()), "cham_colsum")
+
+
+class StepPlan:
+    """Device buffers for one (B, T, N) shape.  Row layouts: see csrc/scorer.hip."""
+
+    def __init__(self, rt, B, T, N, n_buf, Bg):
+        L, dev = rt.layout, rt.device
+        self.B, self.T, self.N, self.n_buf, self.Bg = B, T, N, n_buf, Bg
+        self.BT = BT = B * T
+        self.NC = NC = N + 1
+        self.Rc = Rc = BT * NC
+        self.Rall = Rall = BT + Rc
+        self.pmax = pmax = 20 * N
+        self.RV = RV = 2 * BT + pmax + 1
+        C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        i64 = lambda *s: torch.zeros(*s, dtype=torch.int64, device=dev)
+        # sampler
+        self.neg_ids = i64(B, T, N)
+        self.neg_slot = torch.zeros(B, T, N, dtype=torch.int32, device=dev)
+        self.pool = i64(pmax)
+        self.canon = torch.zeros(pmax, dtype=torch.int32, device=dev)
+        self.meta = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.ws_bytes = rt.lib.cham_neg_sample_workspace_bytes(Bg * (T + 1), int(rt.params['recent_clicks_buffer_max_size']), n_buf)
+        self.sampler_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        # features
+        self.ids_all = i64(RV)
+        self.ref_ts = i64(RV)
+        self.rec_raw, self.nov_raw = f32(RV), f32(RV)
+        self.stats = f32(3, 8)
+        self.stat_scratch = f32(2 * max(1, int(rt.params['recent_clicks_for_normalization'])))
+        self.w_rows = f32(RV)
+        self.Xc_raw, self.Xc_s, self.dXc = f32(BT, Fc), f32(BT, Fc), f32(BT, Fc)
+        self.Xi_raw, self.Xi_s, self.dXi = f32(RV, Fi), f32(RV, Fi), f32(RV, Fi)
+        # CAR
+        self.U, self.dU = f32(BT, C), f32(BT, C)
+        self.V, self.dV = f32(RV, C), f32(RV, C)
+        self.Z1 = f32(Rall, C)
+        self.Z2 = f32(Rall, C)
+        self.dZ2 = f32(Rall, C)
+        self.dZ1 = f32(Rall, C)
+        # RNN
+        self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.xproj = [f32(BT, 2 * Hp) for _ in range(L.L)]
+        self.dxproj = f32(BT, 2 * Hp)
+        self.rnn_out = [f32(BT, Hp) for _ in range(L.L)]
+        self.hprev = [f32(BT, Hp) for _ in range(L.L)]
+        self.G = [f32(BT, Hp) for _ in range(L.L)]
+        self.Cc = [f32(BT, Hp) for _ in range(L.L)]
+        self.drnn = f32(BT, Hp)
+        self.WhT = f32(2 * Hp, Hp)
+        # FCs / scorer
+        self.FC1, self.dFC1 = f32(BT, 512), f32(BT, 512)
+        self.pred, self.dpred = f32(BT, C), f32(BT, C)
+        self.S1, self.dS1 = f32(Rc, 128), f32(Rc, 128)
+        self.S2, self.dS2 = f32(Rc, 64), f32(Rc, 64)
+        self.S3, self.dS3 = f32(Rc, 32), f32(Rc, 32)
+        self.ds = f32(Rc)
+        self.logits, self.probs = f32(BT, NC), f32(BT, NC)
+        self.nll = f32(BT)
+        self.mask = torch.zeros(BT, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
+
+
+class NARModuleModel:
+    """Reference constructor signature: nar_module/nar/nar_model.py:102-129 (+ ``runtime``, the device-resident
+    state that TF keeps in its checkpoint / session)."""
+
+    def __init__(self, mode, inputs, labels, session_features_config, articles_features_config, batch_size, lr, keep_prob,
+                 negative_samples, negative_sample_from_buffer, content_article_embeddings_matrix, rnn_num_layers=1,
+                 softmax_temperature=1.0, reg_weight_decay=0.0, recent_clicks_buffer_hours=1.0,
+                 recent_clicks_buffer_max_size=1000, recent_clicks_for_normalization=1000, articles_metadata=None,
+                 plot_histograms=False, metrics_top_n=5, elapsed_days_smooth_log_base=1.3, popularity_smooth_log_base=2.0,
+                 CAR_embedding_size=256, rnn_units=256, max_cardinality_for_ohe=10, novelty_reg_factor=0.0,
+                 diversity_reg_factor=0.0,
+                 internal_features_config={'recency': True, 'novelty': True, 'article_content_embeddings': True,
+                                           'item_clicked_embeddings': True},
+                 eval_cold_start=False, runtime=None):
+        if elapsed_days_smooth_log_base != 1.3 or popularity_smooth_log_base != 2.0:
+            raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
+        if novelty_reg_factor != 0.0:
+            raise NotImplementedError("novelty_reg_factor > 0 (nar_model.py:673-683) is not built yet")
+        self.is_training = (mode == ModeKeys.TRAIN)
+        if self.is_training and keep_prob != 1.0:
+            raise NotImplementedError("dropout_keep_prob < 1.0: the de-duplicated / factorised CAR path requires the "
+                                      "reference's shipped keep_prob = 1.0 (SURVEY section 7)")
+        self.mode = mode
+        self.inputs, self.labels = inputs, labels
+        self.lr, self.keep_prob = lr, keep_prob
+        self.negative_samples = negative_samples
+        self.negative_sample_from_buffer = negative_sample_from_buffer
+        self.softmax_temperature = softmax_temperature
+        self.reg_weight_decay = reg_weight_decay
+        self.metrics_top_n = metrics_top_n
+        self.recent_clicks_for_normalization = recent_clicks_for_normalization
+        self.recent_clicks_buffer_max_size = recent_clicks_buffer_max_size
+        self.eval_cold_start = eval_cold_start
+        if runtime is None:
+            runtime = NARRuntime(dict(session_features_config=session_features_config,
+                                      articles_features_config=articles_features_config,
+                                      content_article_embeddings_matrix=content_article_embeddings_matrix,
+                                      articles_metadata=articles_metadata, CAR_embedding_size=CAR_embedding_size,
+                                      rnn_units=rnn_units, rnn_num_layers=rnn_num_layers,
+                                      internal_features_config=internal_features_config,
+                                      max_cardinality_for_ohe=max_cardinality_for_ohe,
+                                      recent_clicks_buffer_max_size=recent_clicks_buffer_max_size,
+                                      recent_clicks_for_normalization=recent_clicks_for_normalization))
+        self.rt = runtime
+        # state "placeholders" (nar_model.py:195-202): fed by ItemsStateUpdaterHook.before_run
+        self.articles_recent_pop_norm = None
+        self.pop_recent_items_buffer = None
+        self._dev_state = None
+        self.total_loss = None
+        self.train = self.train_step           # the reference's ``model.train`` op
+
+    # ------------------------------------------------------------------ host -> device
+    def feed_state(self, pop_norm, buffer_ids):
+        """The hook's feed_dict (nar_model.py:1458-1463)."""
+        self.articles_recent_pop_norm = pop_norm
+        self.pop_recent_items_buffer = buffer_ids
+        dev = self.rt.device
+        buf = np.ascontiguousarray(buffer_ids, dtype=np.int64)
+        nz = buf[buf != 0][: self.recent_clicks_for_normalization]           # nar_model.py:1041-1044
+        self._dev_state = dict(
+            buffer=torch.from_numpy(buf).to(dev, non_blocking=True),
+            pop_norm=torch.from_numpy(np.ascontiguousarray(pop_norm, dtype=np.float32)).to(dev, non_blocking=True),
+            last=torch.from_numpy(np.ascontiguousarray(nz)).to(dev, non_blocking=True), n_last=int(nz.shape[0]))
+
+    def upload_batch(self, features, labels, global_features=None, global_labels=None, row_begin=0):
+        """numpy batch (input_fn output) -> device tensors + the few host scalars the launch parameters need."""
+        L, dev = self.rt.layout, self.rt.device
+        item_clicked = np.ascontiguousarray(features['item_clicked'], dtype=np.int64)
+        B, T = item_clicked.shape
+        gf = features if global_features is None else global_features
+        gl = labels if global_labels is None else global_labels
+        aci = np.concatenate([np.asarray(gf['item_clicked'], np.int64), np.asarray(gl['label_last_item'], np.int64).reshape(-1, 1)], 1)
+        ssz = np.asarray(features['session_size'], dtype=np.int64).reshape(-1)
+        seq_len = (ssz - 1).astype(np.int32)                                   # nar_model.py:227
+        mask = (np.arange(T)[None, :] < seq_len[:, None])                      # :231
+        g_ssz = np.asarray(gf['session_size'], dtype=np.int64).reshape(-1)
+        g_T = np.asarray(gf['item_clicked']).shape[1]
+        sum_mask = float(np.minimum(np.maximum(g_ssz - 1, 0), g_T).sum())      # global denominator (:664)
+        ets = np.ascontiguousarray(features['event_timestamp'], dtype=np.int64)
+        max_ts = int(np.asarray(gf['event_timestamp']).max())                  # :235
+        cat = np.stack([np.asarray(features[n], np.int64).reshape(-1) for n in L.ctx_cat_names]) if L.ctx_cat_names \
+            else np.zeros((1, B * T), np.int64)
+        num = np.stack([np.asarray(features[n], np.float32).reshape(-1) for n in L.ctx_num_names]) if L.ctx_num_names \
+            else np.zeros((1, B * T), np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        return dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts,
+                    aci=t(aci), item_clicked=t(item_clicked), label_next=t(np.asarray(labels['label_next_item'], np.int64)),
+                    event_ts=t(ets), seq_len=t(seq_len), mask=t(mask.astype(np.uint8).reshape(-1)), cat=t(cat), num=t(num))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, d, step=None):
+        rt, lib, L = self.rt, self.rt.lib, self.rt.layout
+        st = self._dev_state
+        if st is None:
+            raise RuntimeError("feed_state() must be called before every step (ItemsStateUpdaterHook.before_run)")
+        B, T, N = d['B'], d['T'], self.negative_samples
+        pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
+        self._plan, self._d = pl, d
+        s = _stream()
+        BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
+        C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        step = rt.global_step if step is None else step
+        p = rt.p
+        # K0 negative sampling (nar_model.py:265-276)
+        check(lib.cham_neg_sample(ptr(d['aci']), d['Bg'], T + 1, ptr(st['buffer']), st['buffer'].numel(),
+                                  rt.tf_random_seed, step, d['row_begin'], B, N, self.negative_sample_from_buffer,
+                                  ptr(pl.neg_ids), ptr(pl.neg_slot), ptr(pl.pool), ptr(pl.canon), ptr(pl.meta),
+                                  ptr(pl.sampler_ws), pl.ws_bytes, s), "cham_neg_sample")
+        # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
+        pl.ids_all[:BT].copy_(d['item_clicked'].view(-1))
+        pl.ids_all[BT:2 * BT].copy_(d['label_next'].view(-1))
+        pl.ids_all[2 * BT:2 * BT + pmax].copy_(pl.pool)
+        pl.ref_ts[:BT].copy_(d['event_ts'].view(-1))
+        pl.ref_ts[BT:].fill_(d['max_ts'])
+        check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
+                                        ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
+        if st['n_last'] > 0:
+            check(lib.cham_norm_stats_from_recent(ptr(st['last']), st['n_last'], d['max_ts'], ptr(rt.created),
+                                                  ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
+                  "cham_norm_stats_from_recent")
+        else:   # very first batch: population = the call's own non-pad ids (nar_model.py:1078-1084)
+            check(lib.cham_row_weights(ptr(pl.ids_all), 2 * BT, ptr(pl.neg_slot), BT * N, pmax, ptr(pl.pool),
+                                       ptr(pl.w_rows), pl.w_rows[2 * BT:].data_ptr(), s), "cham_row_weights")
+            for g, (a, b) in enumerate([(0, BT), (BT, 2 * BT), (2 * BT, RV)]):
+                check(lib.cham_norm_stats_from_rows(pl.rec_raw[a:].data_ptr(), pl.nov_raw[a:].data_ptr(),
+                                                    pl.w_rows[a:].data_ptr(), b - a, pl.stats[g].data_ptr(), s),
+                      "cham_norm_stats_from_rows")
+        check(lib.cham_ctx_assemble(ptr(d['cat']), ptr(d['num']), BT, ptr(rt.ctx_desc), Fc, ptr(rt.flat), ptr(p('gamma_ctx')),
+                                    ptr(p('beta_ctx')), ptr(pl.Xc_raw), ptr(pl.Xc_s), s), "cham_ctx_assemble")
+        check(lib.cham_item_assemble(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
+                                     ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
+                                     ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
+              "cham_item_assemble")
+        # factorised PreCAR: U (per click) + V (per unique item row), then CAR
+        rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
+        rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
+        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), s), "cham_combine_fwd")
+        rt.gemm(pl.Z1, p('W2'), pl.Z2, Rall, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+        # recurrent session encoder
+        pl.seq_len.copy_(d['seq_len']); pl.mask.copy_(d['mask'])
+        x, ldx, K = pl.Z2, C, C
+        for l in range(L.L):
+            rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, 2 * Hp, K, ldx, 2 * Hp, 2 * Hp, bias=p('rnn%d/b' % l))
+            check(lib.cham_rnn_fwd(0, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp, ptr(pl.rnn_out[l]),
+                                   ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), s), "cham_rnn_fwd")
+            x, ldx, K = pl.rnn_out[l], Hp, Hp
+        rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
+        rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
+        # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
+        Z2c = pl.Z2[BT:]
+        rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
+        rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
+        rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
+        check(lib.cham_score_softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
+                                         ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), s), "cham_score_softmax_fwd")
+        check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
+        check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
+              "cham_loss_finalize")
+        self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
+        self.batch_negative_items = pl.neg_ids
+        return pl
+
+    # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
+    def backward(self):
+        rt, lib, L = self.rt, self.rt.lib, self.rt.layout
+        pl, d = self._plan, self._d
+        s = _stream()
+        B, T, N = pl.B, pl.T, pl.N
+        BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
+        C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        p, g = rt.p, rt.g
+        rt.grads[:L.emb_end].zero_()
+        check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
+                                         float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3), s),
+              "cham_score_softmax_bwd")
+        rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
+        rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
+        # scorer layers 3, 2, 1
+        rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
+        rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
+        rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
+        rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
+        rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
+        rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+        Z2c, dZ2c = pl.Z2[BT:], pl.dZ2[BT:]
+        rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
+        rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
+        rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
+        check(lib.cham_mulpred_bwd(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s), "cham_mulpred_bwd")
+        # session FCs
+        last = L.L - 1
+        rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
+        rt.colsum(pl.dpred, C, BT, C, g('bf2'))
+        rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
+        rt.gemm(pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
+        rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
+        rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
+        # recurrent layers, last to first
+        for l in range(last, -1, -1):
+            check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), s), "cham_transpose_f32")
+            check(lib.cham_rnn_bwd(0, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
+                                   ptr(pl.Cc[l]), ptr(pl.dxproj), s), "cham_rnn_bwd")
+            x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
+            rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, 2 * Hp, BT, ldx, 2 * Hp, 2 * Hp, transA=1, splits=0)
+            rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, 2 * Hp, 2 * Hp, transA=1, splits=0)
+            rt.colsum(pl.dxproj, 2 * Hp, BT, 2 * Hp, g('rnn%d/b' % l))
+            if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows
+                rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, 2 * Hp, 2 * Hp, 2 * Hp, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
+            else:
+                rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1)
+        # CAR layer 2 then the factorised PreCAR
+        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
+        rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+        rt.gemm(pl.dZ2, p('W2'), pl.dZ1, Rall, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), s), "cham_combine_bwd")
+        rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+        rt.colsum(pl.dU, C, BT, C, g('b1'))
+        rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
+        rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+        rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
+        # scale/center + embedding tables
+        check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(rt.ctx_desc), ptr(p('gamma_ctx')), 0, ptr(d['cat']),
+                                   None, None, 0, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), ptr(rt.grads), s), "cham_feature_bwd")
+        check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(rt.item_desc), ptr(p('gamma_item')), 1, None,
+                                   ptr(pl.ids_all), ptr(rt.meta_cat), rt.n_items, ptr(g('gamma_item')), ptr(g('beta_item')),
+                                   ptr(rt.grads), s), "cham_feature_bwd")
+
+    def apply_gradients(self):
+        """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
+        rt, L = self.rt, self.rt.layout
+        if rt.dp_allreduce is not None:
+            rt.dp_allreduce(rt.grads)
+        rt.global_step += 1
+        t = rt.global_step
+        lr_t = self.lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        check(rt.lib.cham_adam_tf(ptr(rt.flat), ptr(rt.grads), ptr(rt.m), ptr(rt.v), L.total, L.n_reg,
+                                  float(self.reg_weight_decay), float(lr_t), 0.9, 0.999, 1e-8, _stream()), "cham_adam_tf")
+
+    def train_step(self, device_batch=None):
+        """One optimizer step on the current batch (the reference's ``session.run(model.train)``)."""
+        d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)
+        self.forward(d)
+        self.backward()
+        self.apply_gradients()
+        return self.total_loss
+
+    # convenience for tests / hooks -------------------------------------------------------------------
+    def outputs_numpy(self):
+        pl = self._plan
+        torch.cuda.synchronize()
+        return dict(loss=pl.loss.cpu().numpy(), logits=pl.logits.view(pl.B, pl.T, pl.NC).cpu().numpy(),
+                    probs=pl.probs.view(pl.B, pl.T, pl.NC).cpu().numpy(), neg_items=pl.neg_ids.cpu().numpy(),
+                    neg_slot=pl.neg_slot.cpu().numpy(), pool=pl.pool.cpu().numpy(), meta=pl.meta.cpu().numpy())

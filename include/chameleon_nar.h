@@ -1,0 +1,106 @@
+/*
+ * chameleon_nar.h - C ABI of libchameleon_nar.so: the MI355X (gfx950) NAR training-step kernels.
+ *
+ * The reference (gabrielspmoreira/chameleon_recsys) has NO FFI: its hot path is a TensorFlow-1.12 graph built
+ * by nar_module/nar/nar_model.py.  Each entry point below replaces one cluster of TF ops of that graph; the
+ * cluster is cited as file:line (relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless marked host; row-major; `void* stream` is a
+ * hipStream_t; kernels are stream-ordered and re-entrant per stream; the caller owns every buffer; return value
+ * 0 = ok, -22 (-EINVAL) = bad argument, -5 (-EIO) = launch failure.  No exceptions cross the boundary.
+ * Feature / hidden dimensions are padded by the host to multiples of 4 floats (16-byte rows).
+ */
+#ifndef CHAMELEON_NAR_H
+#define CHAMELEON_NAR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHAM_ACT_NONE 0
+#define CHAM_ACT_LEAKY 1 /* tf.nn.leaky_relu, alpha = 0.2 */
+#define CHAM_ACT_TANH 2
+
+/* --- K0 negative sampling: nar_model.py:1220-1304 (+ :265-276) -------------------------------------------
+ * aci = all_clicked_items of the GLOBAL batch [Bg, T1] (T1 = T+1, nar_model.py:241); output rows
+ * [row_begin, row_begin+row_count).  neg_ids [row_count, T, N]; neg_slot = pool position of each negative
+ * (20*N = zero-padding item, -1 = padded click); pool [20*N]; canon [20*N]; meta[4] = {_, n_buffer_sample, _, P}.
+ * RNG: Philox4x32-10 keyed (seed, step); see oracle/philox.py for the contract. */
+size_t cham_neg_sample_workspace_bytes(int n_aci, int buf_size, int n_from_buffer);
+int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size, uint32_t seed, uint32_t step,
+                    int row_begin, int row_count, int N, int n_from_buffer, int64_t* neg_ids, int32_t* neg_slot,
+                    int64_t* pool, int32_t* canon, int32_t* meta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- K1 feature gather / assemble ------------------------------------------------------------------------
+ * Column descriptors: 5 x int64 per output column {kind, feat, sub, dim, param_offset};
+ * kind: 0 zero-pad, 1 one-hot, 2 embedding, 3 numeric, 4 ACE column, 5 item embedding, 6 recency, 7 novelty. */
+/* user context features, nar_model.py:730-773 + :887-907.  cat [n_cat][R] int64, num [n_num][R] float */
+int cham_ctx_assemble(const int64_t* cat, const float* num, int R, const int64_t* desc, int F, const float* params,
+                      const float* gamma, const float* beta, float* xraw, float* xs, void* stream);
+/* raw recency log_1.3(1+relu((f32(ts)-f32(created))/86.4e6)) and novelty -log2(pop_norm): nar_model.py:1055-1060,
+ * 1074, 1147-1148 */
+int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, int R, const int64_t* created, const float* pop_norm,
+                          float* rec_raw, float* nov_raw, void* stream);
+/* normalisation population = last `recent_clicks_for_normalization` buffer clicks: nar_model.py:1062-1089, 1150-1186;
+ * stats [3][8] = per call group {mean, sd, zmin, zmax} x {recency, novelty} */
+int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, int64_t max_ts, const int64_t* created,
+                                const float* pop_norm, float* scratch, float* stats, void* stream);
+/* empty-buffer fallback (first batch): population = the call's own non-pad ids, nar_model.py:1078-1084, 1168-1181 */
+int cham_norm_stats_from_rows(const float* rec_raw, const float* nov_raw, const float* weights, int n, float* stats_group,
+                              void* stream);
+int cham_row_weights(const int64_t* ids, int n_ids, const int32_t* neg_slot, size_t n_neg, int pmax, const int64_t* pool,
+                     float* w_ids, float* w_slots, void* stream);
+/* item rows, nar_model.py:921-994 (+ normalize_values :996-1039, scale/center :887-907).
+ * rows [0,g1_begin) = clicked inputs, [g1_begin,g2_begin) = positives, rest = candidate-pool slots */
+int cham_item_assemble(const int64_t* ids, int R, int g1_begin, int g2_begin, const int64_t* meta_cat, int n_items,
+                       const float* ace, int ld_ace, const float* rec_raw, const float* nov_raw, const float* stats,
+                       const int64_t* desc, int F, const float* params, const float* gamma, const float* beta, float* xraw,
+                       float* xs, void* stream);
+/* backward of the two above: dgamma/dbeta + embedding scatter-add (TF IndexedSlices of embedding_lookup, :741, :918) */
+int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, const int64_t* desc, const float* gamma, int src_kind,
+                     const int64_t* cat, const int64_t* ids, const int64_t* meta_cat, int n_items, float* dgamma, float* dbeta,
+                     float* grads, void* stream);
+
+/* --- K2/K4 fp32 MFMA GEMM with fused prologue/epilogue: tf.layers.Dense at nar_model.py:374-405, 410-426, 447-473,
+ * the RNN input projection (:1308-1361) and their gradients.
+ * C[M,N] (+)= epi(op(A)[M,K] * op(B)[K,N]); transA: A stored [K,M]; transB: B stored [N,K];
+ * epi: +bias, act; or *act'(dref) (dgrad); rowscale: A_stored[r,c] *= rowscale[(r / rs_div), c] */
+int cham_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
+                  int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
+                  int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+
+/* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward */
+int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* Z1,
+                     void* stream);
+int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
+                     void* stream);
+
+/* --- K3 recurrent cell time steps: nar_model.py:1308-1361 (cell_kind 0 = UGRNN) */
+int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp, float* out,
+                 float* hprev, float* G, float* Cc, void* stream);
+int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
+                 const float* hprev, const float* G, const float* Cc, float* dxproj, void* stream);
+int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);
+
+/* --- K5 scoring tail + sampled softmax + masked NLL: nar_model.py:478-517, 639-667 */
+int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream);
+int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                           const uint8_t* mask, float* logits, float* probs, float* nll, void* stream);
+int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N,
+                           float tau, float sum_mask, float* ds, float* dS3, void* stream);
+
+/* --- K7 regularisation loss, loss finalisation, TF Adam, bias-gradient column sums: nar_model.py:655, 660-667, 708-722 */
+int cham_sumsq_partial(const float* params, size_t n_reg, float* partial, void* stream);
+int cham_loss_finalize(const float* nll, int BT, float sum_mask, const float* sumsq_partial, float lambda, float* loss,
+                       void* stream);
+int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda, float lr_t,
+                 float beta1, float beta2, float eps, void* stream);
+size_t cham_colsum_workspace_bytes(int R, int F);
+int cham_colsum(const float* X, int ld, int R, int F, const float* w, float* out, int accumulate, float* workspace,
+                size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""Shared helpers for parity tests: build (HIP model, oracle) pairs with identical weights / state."""
+import numpy as np
+
+from chameleon_recsys_amd.nar import synthetic
+from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
+
+
+def tiny_params(**over):
+    kw = dict(n_items=1000, ace_dim=64, seq_len=8, batch_size=64, neg=10, neg_from_buffer=100, buffer_size=2000,
+              for_norm=200, C=128, H=255)
+    kw.update(over)
+    n_items, ace_dim = kw.pop('n_items'), kw.pop('ace_dim')
+    return synthetic.default_params(n_items, ace_dim, **kw)
+
+
+def warm_state(p, batches):
+    st = ClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'],
+                           p['recent_clicks_for_normalization'], p['content_article_embeddings_matrix'].shape[0])
+    for f, l in batches:
+        ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
+        st.update_items_state(ids, ts)
+    return st
+
+
+def update_state(st, f, l):
+    ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
+    st.update_items_state(ids, ts)
+
+
+def make_pair(p, seed=3):
+    """(hip NARModuleModel(train), NAROracle) sharing weights."""
+    from chameleon_recsys_amd.nar.nar_model import NARModuleModel, NARRuntime, ModeKeys
+    from oracle.nar_oracle import NAROracle
+    rt = NARRuntime(p, seed=seed)
+    w = rt.logical_weights()
+    # make biases / gamma / beta non-trivial so their gradients and uses are exercised
+    rng = np.random.default_rng(seed)
+    for k in w:
+        if k.endswith('bias') or k == 'beta':
+            w[k] = (0.05 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        if k == 'gamma':
+            w[k] = (1.0 + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    rt.load_logical_weights(w)
+    model = NARModuleModel(ModeKeys.TRAIN, None, None, p['session_features_config'], p['articles_features_config'],
+                           p['batch_size'], p['lr'], 1.0, p['train_total_negative_samples'],
+                           p['train_negative_samples_from_buffer'], p['content_article_embeddings_matrix'],
+                           softmax_temperature=p['softmax_temperature'], reg_weight_decay=p['reg_weight_decay'],
+                           recent_clicks_buffer_max_size=p['recent_clicks_buffer_max_size'],
+                           recent_clicks_for_normalization=p['recent_clicks_for_normalization'],
+                           articles_metadata=p['articles_metadata'], CAR_embedding_size=p['CAR_embedding_size'],
+                           rnn_units=p['rnn_units'], runtime=rt)
+    orc = NAROracle(p, weights=w)
+    return model, orc
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))

@@ -1,0 +1,94 @@
+"""fp32 MFMA GEMM (csrc/gemm.hip) against a float64 reference, every transpose mode / epilogue / tile config."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, accumulate=0, splits=1, seed=0):
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn((K, M) if transA else (M, K), generator=g)
+    B = torch.randn((N, K) if transB else (K, N), generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    bias_t = torch.randn(N, generator=g) if bias else None
+    ref_t = torch.randn(M, N, generator=g) if dref else None
+    rs_div = rowscale if rowscale else 1
+    rs_rows = (A.shape[0] + rs_div - 1) // rs_div
+    rs_t = torch.randn(rs_rows, A.shape[1], generator=g) if rowscale else None
+    # fp64 reference
+    Ae = A.double()
+    if rowscale:
+        Ae = Ae * rs_t.double()[torch.arange(A.shape[0]) // rs_div]
+    opA = Ae.t() if transA else Ae
+    opB = B.double().t() if transB else B.double()
+    R = opA @ opB
+    if bias:
+        R = R + bias_t.double()
+    if act == 1:
+        R = torch.where(R > 0, R, 0.2 * R)
+    elif act == 2:
+        R = torch.tanh(R)
+    if dref:
+        y = ref_t.double()
+        R = R * (torch.where(y > 0, 1.0, 0.2) if dact == 1 else (1 - y * y) if dact == 2 else 1.0)
+    if accumulate:
+        R = R + C0.double()
+    dA, dB, dC = A.to(gpu), B.to(gpu), C0.clone().to(gpu)
+    dbias = bias_t.to(gpu) if bias else None
+    dref_t = ref_t.to(gpu) if dref else None
+    drs = rs_t.to(gpu) if rowscale else None
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=gpu) if splits != 1 else None
+    rc = lib.cham_gemm_f32(ptr(dA), A.shape[1], transA, ptr(dB), B.shape[1], transB, ptr(dC), N, M, N, K, ptr(dbias), act,
+                           ptr(dref_t), N, dact, ptr(drs), A.shape[1], rs_div, accumulate, ptr(ws),
+                           (32 << 20) * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream)
+    check(rc, "gemm")
+    torch.cuda.synchronize()
+    out = dC.cpu().double()
+    scale = max(1.0, float(R.abs().max()))
+    err = float((out - R).abs().max()) / scale
+    return err
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 96), (77, 1024, 408), (1000, 64, 128), (513, 32, 64), (64, 72, 1024)])
+def test_nn(gpu, M, N, K):
+    assert _run(gpu, M, N, K) < 2e-5
+    assert _run(gpu, M, N, K, bias=True, act=1) < 2e-5
+    assert _run(gpu, M, N, K, bias=True, act=2) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (259, 72, 1024), (1000, 408, 128), (123, 1024, 512), (400, 64, 32)])
+def test_nt_dgrad(gpu, M, N, K):
+    assert _run(gpu, M, N, K, transB=1) < 2e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=1) < 2e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=2, accumulate=1) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 5000), (72, 1024, 777), (408, 128, 3001), (64, 32, 20000), (1024, 128, 4099)])
+def test_tn_wgrad_splitk(gpu, M, N, K):
+    assert _run(gpu, M, N, K, transA=1) < 5e-5
+    assert _run(gpu, M, N, K, transA=1, splits=0) < 5e-5
+    assert _run(gpu, M, N, K, transA=1, splits=7) < 5e-5
+
+
+def test_rowscale(gpu):
+    assert _run(gpu, 51 * 40, 128, 256, rowscale=51, bias=True, act=1) < 2e-5          # scorer layer 1
+    assert _run(gpu, 256, 128, 51 * 40, transA=1, rowscale=51, splits=0) < 5e-5         # its wgrad
+
+
+def test_asymmetric_layout(gpu):
+    """A = I against an asymmetric B catches row/col swaps of the MFMA C/D map."""
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    n = 160
+    A = torch.eye(n).to(gpu)
+    B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97 - 31.0).to(gpu)
+    C = torch.zeros(n, n, device=gpu)
+    check(lib.cham_gemm_f32(ptr(A), n, 0, ptr(B), n, 0, ptr(C), n, n, n, n, None, 0, None, 0, 0, None, 0, 1, 0, None, 0, 1,
+                            torch.cuda.current_stream().cuda_stream), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(C, B)

@@ -1,0 +1,88 @@
+"""NAR training step: HIP path vs the CPU oracle on identical inputs / weights / state.
+
+Tolerances (BASELINE.json north_star): negative-sample indices bit-exact; logits / loss within 1e-3 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from chameleon_recsys_amd.nar import synthetic
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+def _compare_step(model, orc, f, l, st, check_grads=True):
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    model.feed_state(pop, buf)
+    d = model.upload_batch(f, l)
+    model.forward(d)
+    out = model.outputs_numpy()
+    for v in orc.w.values():
+        v.grad = None
+    ref = orc.forward(f, l, buf, pop, 'train')
+    assert np.array_equal(out['neg_items'], ref['neg_items'].numpy()), "negative samples must be bit exact"
+    mask = ref['mask'].numpy()
+    assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < LOGIT_TOL
+    assert np.abs(out['probs'] - ref['probs'].detach().numpy())[mask].max() < LOGIT_TOL
+    assert abs(out['loss'][1] - float(ref['xe_loss'])) < LOGIT_TOL
+    assert abs(out['loss'][2] - float(ref['reg_loss'])) < 1e-5
+    assert abs(out['loss'][0] - float(ref['total_loss'])) < LOGIT_TOL
+    if check_grads:
+        ref['xe_loss'].backward()
+        model.backward()
+        torch.cuda.synchronize()
+        g = model.rt.logical_grads()
+        for k, v in orc.w.items():
+            rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
+            scale = max(1e-6, float(np.abs(rg).max()))
+            err = float(np.abs(g[k] - rg).max())
+            assert err < 2e-3 * scale + 1e-7, "grad %s: err %g scale %g" % (k, err, scale)
+
+
+def test_step_parity_tiny_warm_state(gpu):
+    p = H.tiny_params()
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    _compare_step(model, orc, *batches[3], st)
+
+
+def test_step_parity_first_batch_empty_buffer(gpu):
+    """nar_model.py:1080-1084: with an empty recent-clicks buffer the normalisation stats come from the batch."""
+    p = H.tiny_params()
+    batches = synthetic.make_batches(1, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, [])
+    model, orc = H.make_pair(p)
+    _compare_step(model, orc, *batches[0], st)
+
+
+def test_step_parity_full_length_sessions(gpu):
+    p = H.tiny_params(C=256, H=128, neg=12, batch_size=40)
+    batches = synthetic.make_batches(3, 40, 8, 1000, p['session_features_config'], length_dist='full')
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=11)
+    _compare_step(model, orc, *batches[2], st)
+
+
+def test_training_curve_matches_oracle(gpu):
+    """Several optimizer steps with the state evolving: loss curve within 1e-3, Adam slots agree."""
+    p = H.tiny_params()
+    batches = synthetic.make_batches(8, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, [])
+    model, orc = H.make_pair(p)
+    for i, (f, l) in enumerate(batches):
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        model.feed_state(pop, buf)
+        loss = model.train_step(model.upload_batch(f, l)).cpu().numpy()
+        ref = orc.train_step(f, l, buf, pop)
+        assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy())
+        assert abs(loss[0] - float(ref['total_loss'])) < LOGIT_TOL, (i, loss, float(ref['total_loss']))
+        H.update_state(st, f, l)
+    m_hip = model.rt.layout.unpack(model.rt.m.cpu().numpy())
+    for k, v in orc.m.items():
+        scale = max(1e-8, float(v.abs().max()))
+        assert float(np.abs(m_hip[k] - v.numpy()).max()) < 5e-3 * scale + 1e-8, k
+    w_hip = model.rt.logical_weights()
+    for k, v in orc.w.items():
+        assert float(np.abs(w_hip[k] - v.detach().numpy()).max()) < 2.5 * p['lr'] * len(batches), k
