@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py - NAR training sessions/sec on MI355X (BASELINE.json metric), G1-shape synthetic workload.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one optimizer step of the NAR hot path (negative sampling -> features -> CAR -> UGRNN -> scorer ->
+sampled-softmax loss -> backward -> L2 + TF-Adam -> recent-clicks state update) on one batch of 256 sessions PER
+GPU (weak scaling) whose tensors are already resident in HBM.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G1 = dict(n_items=46000, ace_dim=250, seq_len=20, batch=256, neg=50, neg_from_buffer=3000, buffer=20000, for_norm=2000,
+          C=1024, H=255)
+TINY = dict(n_items=1000, ace_dim=64, seq_len=8, batch=64, neg=10, neg_from_buffer=100, buffer=2000, for_norm=200,
+            C=1024, H=255)
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+
+
+def dense_step_flops(B, T, N, F, C, H, L=1):
+    """Reference-dense forward FLOPs per step (SURVEY.md 8d / BASELINE.md section 4); training ~ 3x."""
+    rows_neg, rows_io = B * T * N, B * T
+    fwd = 2 * (rows_neg + 2 * rows_io) * (F * C + C * C)
+    I = C
+    for _ in range(L):
+        fwd += 2 * B * T * (I + H) * 2 * H
+        I = H
+    fwd += 2 * rows_io * (H * 512 + 512 * C)
+    fwd += 2 * (rows_neg + rows_io) * (C * 128 + 128 * 64 + 64 * 32 + 32)
+    return fwd
+
+
+def cpu_baseline(params, cfg, length_dist, seed):
+    """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of the same workload."""
+    import torch
+    from chameleon_recsys_amd.nar import synthetic
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
+    from oracle.nar_oracle import NAROracle
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    Bs = 64                                    # sample: 64-session batches of the same shape
+    p = dict(params); p['batch_size'] = Bs
+    batches = synthetic.make_batches(3, Bs, cfg['seq_len'], cfg['n_items'], p['session_features_config'], seed=seed,
+                                     length_dist=length_dist, sessions_per_hour=Bs * 4)
+    orc = NAROracle(p, seed=seed)
+    st = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
+    times = []
+    for i, (f, l) in enumerate(batches):
+        t0 = time.perf_counter()
+        orc.train_step(f, l, st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm())
+        ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
+        st.update_items_state(ids, ts)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:])                        # first step = warm-up
+    return dict(value=round(Bs * (len(times) - 1) / dt, 3), unit="sessions/s", cores=cores, kind="port",
+                sample="2 timed optimizer steps of 64-session batches (same shape, 1 warm-up step), "
+                       "restated CPU oracle (PyTorch-CPU fp32, TF 1.12 unavailable), %d threads" % cores)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="g1", choices=["g1", "tiny"])
+    ap.add_argument("--length-dist", default="full", choices=["full", "g1"],
+                    help="full: every session has seq_len clicks (no padded rows); g1: G1-like ragged lengths")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from chameleon_recsys_amd.nar import synthetic
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
+    from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel, NARRuntime
+    from chameleon_recsys_amd.nar.parallel import DataParallelNAR
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = G1 if args.config == "g1" else TINY
+    Bl = cfg['batch']                 # per-GPU batch (weak scaling)
+    Bg = Bl * world
+    params = synthetic.default_params(cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'], batch_size=Bg, neg=cfg['neg'],
+                                      neg_from_buffer=cfg['neg_from_buffer'], buffer_size=cfg['buffer'],
+                                      for_norm=cfg['for_norm'], C=cfg['C'], H=cfg['H'], seed=args.seed)
+    n_distinct = 8
+    batches = synthetic.make_batches(n_distinct, Bg, cfg['seq_len'], cfg['n_items'], params['session_features_config'],
+                                     seed=args.seed, length_dist=args.length_dist, sessions_per_hour=Bg * 2)
+    rt = NARRuntime(params, device="cuda:%d" % local_rank, seed=args.seed)
+    model = NARModuleModel(ModeKeys.TRAIN, None, None, params['session_features_config'], params['articles_features_config'],
+                           Bg, params['lr'], 1.0, cfg['neg'], cfg['neg_from_buffer'], params['content_article_embeddings_matrix'],
+                           softmax_temperature=params['softmax_temperature'], reg_weight_decay=params['reg_weight_decay'],
+                           recent_clicks_buffer_max_size=cfg['buffer'], recent_clicks_for_normalization=cfg['for_norm'],
+                           articles_metadata=params['articles_metadata'], CAR_embedding_size=cfg['C'], rnn_units=cfg['H'],
+                           runtime=rt)
+    dp = DataParallelNAR(model)
+    state = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
+    dev_batches = [dp.upload(f, l) for f, l in batches]          # inputs resident in HBM before the timed region
+    host_clicks = [batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']) for f, l in batches]
+
+    def one_step(i):
+        k = i % n_distinct
+        model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())   # hook.before_run
+        model.train_step(dev_batches[k])
+        state.update_items_state(*host_clicks[k])                                                   # hook.after_run
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = dp.global_loss().cpu().numpy()
+
+    # ---- roofline leg: HIP-event timing of every GEMM launch over a few extra steps -------------------------
+    rt.profile = []
+    nprof = 3
+    for i in range(nprof):
+        one_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    prof, rt.profile = rt.profile, None
+    # dominant kernel = the NN (forward) / NT (dgrad) / TN (wgrad) 128x128 MFMA tile instances; report the NN one,
+    # aggregated over all of its launches in a step exactly like `rocprofv3 --stats` aggregates per kernel symbol
+    def agg(sel):
+        rows = [r for r in prof if sel(r)]
+        ms = sum(r['ev'][0].elapsed_time(r['ev'][1]) for r in rows)
+        fl = sum(2.0 * r['M'] * r['N'] * r['K'] for r in rows)
+        return len(rows), ms, fl
+    big = lambda r: r['N'] > 64
+    n_nn, ms_nn, fl_nn = agg(lambda r: big(r) and not r['transA'] and not r['transB'])
+    n_all, ms_all, fl_all = agg(lambda r: True)
+    achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
+
+    if rank == 0:
+        L = rt.layout
+        T = cfg['seq_len'] - 1
+        dense_fwd = dense_step_flops(Bl, T, cfg['neg'], L.F, cfg['C'], cfg['H'])
+        ms_step = dt / args.steps * 1e3
+        out = {
+            "metric": "NAR training sessions/sec", "value": round(Bg * args.steps / dt, 2), "unit": "sessions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "G1-shape synthetic (BASELINE.json configs[1])" if args.config == "g1" else "G1-tiny synthetic",
+                       "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
+                       "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
+                       "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": "ugrnn",
+                       "session_lengths": args.length_dist, "parallelism": "dp%d" % world,
+                       "final_loss": [round(float(x), 5) for x in loss]},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2,16,true,false> (NN, all launches of a step)",
+                         "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_nn // nprof, "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),
+                         "algorithmic_gflop_per_launch": round(fl_nn / max(1, n_nn) / 1e9, 3),
+                         "all_gemm_ms_per_step": round(ms_all / nprof, 3),
+                         "all_gemm_tflops": round(fl_all / (ms_all * 1e-3) / 1e12, 2) if ms_all > 0 else 0.0,
+                         "step_reference_dense_tflops": round(3 * dense_fwd / (ms_step * 1e-3) / 1e12, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

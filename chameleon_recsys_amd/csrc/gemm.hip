@@ -37,22 +37,23 @@ struct GemmParams {
     int nbm, nbn;
 };
 
-template <int BF, int BK, bool XK>
+template <int BF, int BK, bool XK, int NTH>
 struct TileLoader {
     static constexpr int NF4 = BF * BK / 4;               // float4 in the tile
-    static constexpr int NV = (NF4 + 255) / 256;          // float4 per thread
+    static constexpr int NV = (NF4 + NTH - 1) / NTH;      // float4 per thread
     static constexpr int LD = XK ? (BF + (BK == 16 ? 2 : 1)) : (BF + 4);
     float4 r[NV];
+    float4 sc[NV];                                        // row-broadcast scale (multiplied at store time)
 
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int f0, int F, int k0, int kend,
                                          const float* __restrict__ rs, int ldrs, int rs_div) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             int srow, scol;   // stored row / col of this float4
             bool ok;
-            if (NF4 % 256 != 0 && idx >= NF4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (NF4 % NTH != 0 && idx >= NF4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
                 srow = f0 + fr; scol = k0 + kq * 4;
@@ -65,20 +66,21 @@ struct TileLoader {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
                 v = *reinterpret_cast<const float4*>(base + (size_t)srow * ld + scol);
-                if (rs) {
-                    const float4 s = *reinterpret_cast<const float4*>(rs + (size_t)(srow / rs_div) * ldrs + scol);
-                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                }
+                if (rs) sc[i] = *reinterpret_cast<const float4*>(rs + (size_t)(srow / rs_div) * ldrs + scol);
             }
             r[i] = v;
         }
+    }
+    __device__ __forceinline__ void apply_scale() {      // after the loads have landed, just before the LDS store
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { r[i].x *= sc[i].x; r[i].y *= sc[i].y; r[i].z *= sc[i].z; r[i].w *= sc[i].w; }
     }
     __device__ __forceinline__ void store(float* __restrict__ S) const {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * 256;
-            if (NF4 % 256 != 0 && idx >= NF4) continue;
+            const int idx = tid + i * NTH;
+            if (NF4 % NTH != 0 && idx >= NF4) continue;
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
                 float* d = S + (kq * 4) * LD + fr;
@@ -92,10 +94,10 @@ struct TileLoader {
 };
 
 template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    using LA = TileLoader<BM, BK, AK>;
-    using LB = TileLoader<BN, BK, BKC>;
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
+    using LA = TileLoader<BM, BK, AK, NTH>;
+    using LB = TileLoader<BN, BK, BKC, NTH>;
     constexpr int LDA = LA::LD, LDB = LB::LD;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if (nk > 0) {
         la.load(p.A, p.lda, m0, p.M, kbeg, kend, p.rs, p.ldrs, p.rs_div);
         lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, nullptr, 0, 1);
+        if (p.rs) la.apply_scale();
         la.store(As); lb.store(Bs);
     }
     __syncthreads();
@@ -142,20 +145,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
         const float* Ac = As + cur * ASZ + wm0 + fl;
         const float* Bc = Bs + cur * BSZ + wn0 + fl;
+        // fragment registers are double-buffered: the ds_reads of k-step kk+2 are issued before the MFMAs of kk
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = Ac[kl * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bc[kl * LDB + j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            const int c = (kk >> 1) & 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ac[(kk + kl) * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) a[c ^ 1][i] = Ac[(kk + 2 + kl) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bc[(kk + kl) * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) b[c ^ 1][j] = Bc[(kk + 2 + kl) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
+            if (p.rs) la.apply_scale();
             la.store(As + (cur ^ 1) * ASZ);
             lb.store(Bs + (cur ^ 1) * BSZ);
         }
@@ -204,8 +216,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
 
 template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
-    using LA = TileLoader<BM, BK, AK>;
-    using LB = TileLoader<BN, BK, BKC>;
+    using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
+    using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
     const size_t smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
@@ -217,7 +229,7 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     if (p.splits > 1) {
         const size_t n = (size_t)p.M * p.N;
@@ -229,9 +241,24 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     return CHAM_OK;
 }
 
+static int g_variant = -1;     // -1 = automatic
+extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
+
 template <bool AK, bool BKC>
 static int launch_by_shape(GemmParams& p, hipStream_t st) {
-    if (p.N > 64) return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
+    if (p.N > 64) {
+        // default: 256x128 tile / 8 waves for large outputs (best on MI355X: 113-117 TFLOP/s on the CAR shapes),
+        // 128x128 / 4 waves when the grid would otherwise be too small to fill 256 CUs
+        const int v = g_variant >= 0 ? g_variant : (((long)p.M * p.N >= (1L << 20)) ? 2 : 0);
+        switch (v) {
+            case 1: return launch_cfg<128, 128, 2, 2, 32, AK, BKC>(p, st);
+            case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
+            case 3: return launch_cfg<128, 256, 2, 2, 16, AK, BKC>(p, st);
+            case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
+            case 5: return launch_cfg<256, 128, 2, 2, 16, AK, BKC>(p, st);
+            default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
+        }
+    }
     if (p.N > 32) return launch_cfg<256, 64, 4, 1, 16, AK, BKC>(p, st);
     return launch_cfg<256, 32, 4, 1, 16, AK, BKC>(p, st);
 }
@@ -259,9 +286,9 @@ extern "C" int cham_gemm_f32(const float* A, int lda, int transA, const float* B
     int splits = 1;
     if (splits_hint != 1 && workspace) {
         // long-reduction / small-output shapes (wgrad): fill >= ~1024 workgroups
-        const int bm = (N > 64) ? 128 : 256, bn = (N > 64) ? 128 : (N > 32 ? 64 : 32);
+        const int bm = (N > 64) ? (((long)M * N >= (1L << 20)) ? 256 : 128) : 256, bn = (N > 64) ? 128 : (N > 32 ? 64 : 32);
         const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        long want = splits_hint > 1 ? splits_hint : (tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles);
+        long want = splits_hint > 1 ? splits_hint : (tiles >= 384 ? 1 : (512 + tiles - 1) / tiles);
         const long maxk = (K + 255) / 256;               // at least 256 reduction steps per split
         if (want > maxk) want = maxk;
         const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));

@@ -93,13 +93,23 @@ __global__ __launch_bounds__(256) void k_colsum_gen(const float* __restrict__ X,
         partial[(size_t)blockIdx.x * F + c] = acc;
     }
 }
+// 32 columns x 8 chunk-lanes per workgroup; lane l sums chunks l, l+8, ... then the 8 lanes are added in order
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nchunks, int F, float* __restrict__ out,
                                                       int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
+    __shared__ float sm[8][33];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * F + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < F)
+        for (int k = kl; k < nchunks; k += 8) s += partial[(size_t)k * F + c];
+    sm[kl][cl] = s;
+    __syncthreads();
+    if (kl == 0 && c < F) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 extern "C" int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
@@ -147,7 +157,7 @@ extern "C" int cham_colsum(const float* X, int ld, int R, int F, const float* w,
     const bool vec = (F % 4 == 0) && (F / 4 <= 256) && (256 % (F / 4) == 0) && (ld % 4 == 0);
     if (vec) hipLaunchKernelGGL(k_colsum_vec, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
     else hipLaunchKernelGGL(k_colsum_gen, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((F + 255) / 256), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
+    hipLaunchKernelGGL(k_colsum_final, dim3((F + 31) / 32), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

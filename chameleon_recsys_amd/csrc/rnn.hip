@@ -166,13 +166,20 @@ extern "C" int cham_transpose_f32(const float* in, int rows, int cols, float* ou
     return CHAM_OK;
 }
 
+// When the recurrent kernels run on a side stream next to the big CAR GEMM they must not share a CU with GEMM
+// workgroups (the MFMA pipes would be time-sliced and the latency-bound recurrence would stretch 5x): requesting
+// most of the 160 KB LDS makes every CU that hosts a recurrent workgroup exclusive to it.
+static size_t g_rnn_lds_hog = 0;
+extern "C" void cham_rnn_set_exclusive_lds(size_t bytes) { g_rnn_lds_hog = bytes > 160 * 1024 ? 160 * 1024 : bytes; }
+
 template <int NT>
 static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_len, int B, int T, float* out, float* hprev,
                             float* G, float* Cc, hipStream_t st) {
-    const size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
+    size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
+    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_ugrnn_fwd<NT>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -180,10 +187,11 @@ static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_
 template <int NT>
 static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_len, int B, int T, const float* hprev,
                             const float* G, const float* Cc, float* dxproj, hipStream_t st) {
-    const size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
+    size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
+    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_ugrnn_bwd<NT>;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

@@ -34,24 +34,29 @@ __global__ __launch_bounds__(256) void k_keys_pool(const int64_t* __restrict__ a
     keys[i] = v != 0 ? philox_sort_key((uint32_t)i, 0u, 0u, 1u, seed, step) : CHAM_INF_KEY;
 }
 
-// out[rank(i)] = vals[i] for rank < limit; *count = min(limit, #valid)   (out / count pre-zeroed)
-__global__ __launch_bounds__(256) void k_rank_select(const uint64_t* __restrict__ keys, const int64_t* __restrict__ vals,
-                                                     int n, int limit, int64_t* __restrict__ out, int* __restrict__ count) {
+// rank[i] = #{j : key[j] < key[i]}: 2-D grid (256 elements) x (slice of 2048 keys staged in LDS); integer atomics
+__global__ __launch_bounds__(256) void k_rank_count(const uint64_t* __restrict__ keys, int n, int* __restrict__ rank) {
     __shared__ uint64_t tile[2048];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const uint64_t mine = i < n ? keys[i] : CHAM_INF_KEY;
-    int rank = 0;
-    for (int t0 = 0; t0 < n; t0 += 2048) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < 2048; t += 256) tile[t] = (t0 + t) < n ? keys[t0 + t] : CHAM_INF_KEY;
-        __syncthreads();
-        const int m = min(2048, n - t0);
-        for (int t = 0; t < m; ++t) rank += (tile[t] < mine) ? 1 : 0;
-    }
-    if (i < n && mine != CHAM_INF_KEY && rank < limit) {
-        out[rank] = vals[i];
-        atomicAdd(count, 1);
-    }
+    const int t0 = blockIdx.y * 2048;
+    for (int t = threadIdx.x; t < 2048; t += 256) tile[t] = (t0 + t) < n ? keys[t0 + t] : CHAM_INF_KEY;
+    __syncthreads();
+    if (i >= n || mine == CHAM_INF_KEY) return;
+    const int m = min(2048, n - t0);
+    int r = 0;
+#pragma unroll 8
+    for (int t = 0; t < m; ++t) r += (tile[t] < mine) ? 1 : 0;
+    if (r) atomicAdd(rank + i, r);
+}
+// out[rank(i)] = vals[i] for rank < limit; *count = min(limit, #valid)   (out / count / rank pre-zeroed)
+__global__ __launch_bounds__(256) void k_rank_place(const uint64_t* __restrict__ keys, const int64_t* __restrict__ vals,
+                                                    const int* __restrict__ rank, int n, int limit, int64_t* __restrict__ out,
+                                                    int* __restrict__ count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || keys[i] == CHAM_INF_KEY) return;
+    const int r = rank[i];
+    if (r < limit) { out[r] = vals[i]; atomicAdd(count, 1); }
 }
 
 __global__ __launch_bounds__(256) void k_canon(const int64_t* __restrict__ pool, const int* __restrict__ pcount, int pmax,
@@ -128,7 +133,8 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t cham_neg_sample_workspace_bytes(int n_aci, int buf_size, int n_from_buffer) {
     const size_t ncat = (size_t)n_aci + n_from_buffer;
-    return align256((size_t)buf_size * 8) + align256((size_t)n_from_buffer * 8) + align256(ncat * 8) * 2 + 256;
+    const size_t nmax = ncat > (size_t)buf_size ? ncat : (size_t)buf_size;
+    return align256((size_t)buf_size * 8) + align256((size_t)n_from_buffer * 8) + align256(ncat * 8) * 2 + align256(nmax * 4) + 256;
 }
 
 extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size,
@@ -148,19 +154,24 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
     int64_t* buf_sample = reinterpret_cast<int64_t*>(w); w += align256((size_t)n_from_buffer * 8);
     const int ncat = n_aci + n_from_buffer;
     int64_t* cat_vals = reinterpret_cast<int64_t*>(w); w += align256((size_t)ncat * 8);
-    uint64_t* keys1 = reinterpret_cast<uint64_t*>(w);
+    uint64_t* keys1 = reinterpret_cast<uint64_t*>(w); w += align256((size_t)ncat * 8);
+    int* rank = reinterpret_cast<int*>(w);
 
     if (hipMemsetAsync(meta, 0, 4 * sizeof(int), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (n_from_buffer > 0 && hipMemsetAsync(buf_sample, 0, (size_t)n_from_buffer * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (hipMemsetAsync(pool, 0, (size_t)pmax * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (buf_size > 0 && n_from_buffer > 0) {
         hipLaunchKernelGGL(k_keys_buffer, dim3((buf_size + 255) / 256), dim3(256), 0, st, buffer, buf_size, keys0, seed, step);
-        hipLaunchKernelGGL(k_rank_select, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buffer, buf_size,
+        if (hipMemsetAsync(rank, 0, (size_t)buf_size * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_rank_count, dim3((buf_size + 255) / 256, (buf_size + 2047) / 2048), dim3(256), 0, st, keys0, buf_size, rank);
+        hipLaunchKernelGGL(k_rank_place, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buffer, rank, buf_size,
                            n_from_buffer, buf_sample, meta + 1);
     }
     hipLaunchKernelGGL(k_keys_pool, dim3((ncat + 255) / 256), dim3(256), 0, st, aci, n_aci, buf_sample, n_from_buffer,
                        cat_vals, keys1, seed, step);
-    hipLaunchKernelGGL(k_rank_select, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, ncat, pmax, pool, meta + 3);
+    if (hipMemsetAsync(rank, 0, (size_t)ncat * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_rank_count, dim3((ncat + 255) / 256, (ncat + 2047) / 2048), dim3(256), 0, st, keys1, ncat, rank);
+    hipLaunchKernelGGL(k_rank_place, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, rank, ncat, pmax, pool, meta + 3);
     hipLaunchKernelGGL(k_canon, dim3((pmax + 255) / 256), dim3(256), 0, st, pool, meta + 3, pmax, canon);
     if (row_count > 0) {
         const size_t smem = (size_t)pp * 8 + (size_t)T1 * 8;

@@ -63,51 +63,96 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__
     }
 }
 
-// dV[2BT + s] = sum over candidate rows that reference slot s, in row order (deterministic, no atomics):
-// every workgroup scans the (L2-resident) slot table and adds matching rows.
-__global__ __launch_bounds__(256) void k_combine_bwd_slots(const float* __restrict__ dpre, int C, int BT, int N, int pmax,
-                                                           const int* __restrict__ neg_slot, float* __restrict__ dV) {
-    __shared__ unsigned long long masks[4][4];
-    const int s = blockIdx.x;                              // 0..pmax
+// dV[2BT + s] = sum over candidate rows that reference slot s (deterministic, no float atomics).
+// Negatives are popularity-sampled, so a few slots are referenced by almost every click: the reduction is
+// therefore split over (slot, row-chunk) workgroups.  Each workgroup scans its chunk of the (L2-resident) slot
+// table, compacts the matching rows IN ORDER into an LDS list (ballot + popcount prefix), then sums those rows
+// with 8 independent row loads in flight; a second kernel adds the per-chunk partials in chunk order.
+#define SLOT_CHUNK 16384
+#define SLOT_LIST 2048          // a click holds a slot at most once -> <= SLOT_CHUNK / N + 2 matches per chunk (N >= 8)
+__global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* __restrict__ dpre, int C, int BT, int N,
+                                                                   const int* __restrict__ neg_slot,
+                                                                   float* __restrict__ partial /*[nchunk][pmax+1][C]*/, int nslots,
+                                                                   int chunk_len /* multiple of 1024, <= SLOT_CHUNK */) {
+    __shared__ int list[SLOT_LIST];
+    __shared__ int wave_tot[4];
+    const int s = blockIdx.x, chunk = blockIdx.y;
     const size_t n = (size_t)BT * N;
+    const size_t i0 = (size_t)chunk * chunk_len;
+    const size_t i1 = i0 + chunk_len < n ? i0 + chunk_len : n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nk = C / 4;                                  // float4 columns; thread owns k = tid, tid+256, ...
-    float4 acc[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i0 = 0; i0 < n; i0 += 1024) {
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            const size_t i = i0 + sub * 256 + threadIdx.x;
-            const bool m = (i < n) && (neg_slot[i] == s);
-            const unsigned long long bal = __ballot(m);
-            if (lane == 0) masks[sub][wave] = bal;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-            for (int w = 0; w < 4; ++w) {
-                unsigned long long mk = masks[sub][w];
-                while (mk) {
-                    const int bit = __ffsll((long long)mk) - 1;
-                    mk &= mk - 1;
-                    const size_t i = i0 + sub * 256 + w * 64 + bit;          // = bt*N + n
-                    const size_t bt = i / N, nn = i % N;
-                    const float4* src = reinterpret_cast<const float4*>(dpre + ((size_t)BT + bt * (N + 1) + 1 + nn) * C);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int k = threadIdx.x + a * 256;
-                        if (k < nk) { const float4 x = src[k]; acc[a].x += x.x; acc[a].y += x.y; acc[a].z += x.z; acc[a].w += x.w; }
-                    }
-                }
+    // each thread owns a contiguous segment of chunk_len/256 (<= 64) entries: count, block prefix, then fill in order
+    const int SEG = chunk_len / 256;
+    const size_t sb = i0 + (size_t)threadIdx.x * SEG;
+    unsigned long long mbits = 0ull;
+    if (sb < i1) {
+        const int4* pv = reinterpret_cast<const int4*>(neg_slot + sb);       // sb is a multiple of 64 entries
+        for (int q = 0; q < SEG / 4; ++q) {
+            if (sb + 4 * q + 3 < i1) {
+                const int4 v = pv[q];
+                mbits |= (unsigned long long)(v.x == s) << (4 * q) | (unsigned long long)(v.y == s) << (4 * q + 1) |
+                         (unsigned long long)(v.z == s) << (4 * q + 2) | (unsigned long long)(v.w == s) << (4 * q + 3);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (sb + 4 * q + e < i1 && neg_slot[sb + 4 * q + e] == s) mbits |= 1ull << (4 * q + e);
             }
-        __syncthreads();
+        }
     }
-    float4* dst = reinterpret_cast<float4*>(dV + ((size_t)2 * BT + s) * C);
+    const int mycnt = __popcll(mbits);
+    // wave-level inclusive scan of counts
+    int incl = mycnt;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int k = threadIdx.x + a * 256;
-        if (k < nk) dst[k] = acc[a];
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = incl - mycnt;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    const int total_s = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    while (mbits) {
+        const int bit = __ffsll((long long)mbits) - 1;
+        mbits &= mbits - 1;
+        if (off < SLOT_LIST) list[off] = threadIdx.x * SEG + bit;
+        ++off;
+    }
+    __syncthreads();
+    const int cnt = total_s < SLOT_LIST ? total_s : SLOT_LIST;
+    const int nk = C / 4;
+    for (int k = threadIdx.x; k < nk; k += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t i = i0 + list[t + u];
+                const size_t row = (size_t)BT + (i / N) * (N + 1) + 1 + (i % N);
+                x[u] = reinterpret_cast<const float4*>(dpre + row * C)[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+        for (; t < cnt; ++t) {
+            const size_t i = i0 + list[t];
+            const size_t row = (size_t)BT + (i / N) * (N + 1) + 1 + (i % N);
+            const float4 x = reinterpret_cast<const float4*>(dpre + row * C)[k];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<float4*>(partial + ((size_t)chunk * nslots + s) * C)[k] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_combine_bwd_slots_final(const float* __restrict__ partial, int C, int nslots, int nchunk,
+                                                                 int BT, float* __restrict__ dV) {
+    const int s = blockIdx.x;
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < nchunk; ++c) {
+            const float4 x = reinterpret_cast<const float4*>(partial + ((size_t)c * nslots + s) * C)[k];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<float4*>(dV + ((size_t)2 * BT + s) * C)[k] = acc;
     }
 }
 
@@ -215,12 +260,31 @@ extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, i
     return CHAM_OK;
 }
 
+static int slot_chunk_len(int N) {
+    long c = ((long)(SLOT_LIST - 2) * N / 1024) * 1024;      // matches per chunk <= chunk/N + 2 <= SLOT_LIST
+    if (c > SLOT_CHUNK) c = SLOT_CHUNK;
+    if (c < 1024) c = 1024;
+    return (int)c;
+}
+extern "C" size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax) {
+    const size_t n = (size_t)BT * N;
+    const size_t cl = (size_t)slot_chunk_len(N);
+    const size_t nchunk = (n + cl - 1) / cl;
+    return nchunk * (size_t)(pmax + 1) * C * sizeof(float);
+}
+
 extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot,
-                                float* dU, float* dV, void* stream) {
-    if (!dpre || !neg_slot || !dU || !dV || (C & 3) || C > 4096 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+                                float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dpre || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    if (workspace_bytes < cham_combine_bwd_workspace_bytes(C, BT, N, pmax)) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)BT * N;
+    const int cl = slot_chunk_len(N);
+    const int nchunk = (int)((n + cl - 1) / cl);
     hipLaunchKernelGGL(k_combine_bwd_u, dim3(BT), dim3(256), 0, st, dpre, C, BT, N, dU, dV);
-    hipLaunchKernelGGL(k_combine_bwd_slots, dim3(pmax + 1), dim3(256), 0, st, dpre, C, BT, N, pmax, neg_slot, dV);
+    hipLaunchKernelGGL(k_combine_bwd_slots_partial, dim3(pmax + 1, nchunk), dim3(256), 0, st, dpre, C, BT, N, neg_slot, workspace,
+                       pmax + 1, cl);
+    hipLaunchKernelGGL(k_combine_bwd_slots_final, dim3(pmax + 1), dim3(256), 0, st, workspace, C, pmax + 1, nchunk, BT, dV);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

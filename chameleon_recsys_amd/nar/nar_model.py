@@ -71,10 +71,18 @@ class NARRuntime:
         self.meta_cat = torch.from_numpy(np.ascontiguousarray(mc)).to(dev)
         self.ctx_desc = torch.from_numpy(L.ctx_descriptors()).to(dev)
         self.item_desc = torch.from_numpy(L.item_descriptors()).to(dev)
-        self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials
+        self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
+        # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
+        self.side_stream = torch.cuda.Stream(device=dev)
+        self.gemm_ws_side = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+        self.colsum_ws_side = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+        # Measured on MI355X (profiles/r01_notes.md): with a second stream the 8 recurrent workgroups are starved by the
+        # 15k-workgroup GEMM grid (no CU reservation), so the overlap is OFF by default; kept as an experiment switch.
+        self.overlap = False
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._plans = {}
+        self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
         # data-parallel context (set by parallel.DataParallelNAR)
         self.dp_rank, self.dp_world, self.dp_allreduce = 0, 1, None
 
@@ -116,14 +124,37 @@ class NARRuntime:
     # ---- thin kernel wrappers -------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
              dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1):
-        ws = self.gemm_ws if splits != 1 else None
+        ws = None
+        if splits != 1:
+            ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()       # torch's current stream == the stream the kernel is launched on (_stream())
         check(self.lib.cham_gemm_f32(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
                                      ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
-                                     self.gemm_ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
+                                     ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
+        if prof is not None:
+            e1.record()
+            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=splits, ev=(e0, e1)))
 
     def colsum(self, X, ld, R, F, out, w=None, accumulate=0):
-        check(self.lib.cham_colsum(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(self.colsum_ws),
-                                   self.colsum_ws.numel() * 4, _stream()), "cham_colsum")
+        ws = self.colsum_ws_side if torch.cuda.current_stream() == self.side_stream else self.colsum_ws
+        check(self.lib.cham_colsum(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws), ws.numel() * 4, _stream()),
+              "cham_colsum")
+
+    def side(self):
+        """Context manager: run the enclosed launches on the side stream (or inline when overlap is disabled)."""
+        import contextlib
+        return torch.cuda.stream(self.side_stream) if self.overlap else contextlib.nullcontext()
+
+    def fork(self):
+        if self.overlap:
+            self.side_stream.wait_stream(torch.cuda.current_stream())
+
+    def join(self):
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
 
 class StepPlan:
@@ -147,6 +178,9 @@ class StepPlan:
         self.pool = i64(pmax)
         self.canon = torch.zeros(pmax, dtype=torch.int32, device=dev)
         self.meta = torch.zeros(4, dtype=torch.int32, device=dev)
+        need = rt.lib.cham_combine_bwd_workspace_bytes(L.C, B * T, N, 20 * N)
+        if need > rt.gemm_ws.numel() * 4:
+            rt.gemm_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         self.ws_bytes = rt.lib.cham_neg_sample_workspace_bytes(Bg * (T + 1), int(rt.params['recent_clicks_buffer_max_size']), n_buf)
         self.sampler_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         # features
@@ -325,17 +359,22 @@ class NARModuleModel:
         rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
         rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
         check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), s), "cham_combine_fwd")
-        rt.gemm(pl.Z1, p('W2'), pl.Z2, Rall, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
-        # recurrent session encoder
         pl.seq_len.copy_(d['seq_len']); pl.mask.copy_(d['mask'])
-        x, ldx, K = pl.Z2, C, C
-        for l in range(L.L):
-            rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, 2 * Hp, K, ldx, 2 * Hp, 2 * Hp, bias=p('rnn%d/b' % l))
-            check(lib.cham_rnn_fwd(0, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp, ptr(pl.rnn_out[l]),
-                                   ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), s), "cham_rnn_fwd")
-            x, ldx, K = pl.rnn_out[l], Hp, Hp
-        rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
-        rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
+        # CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
+        rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+        rt.fork()
+        with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
+            x, ldx, K = pl.Z2, C, C
+            for l in range(L.L):
+                rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, 2 * Hp, K, ldx, 2 * Hp, 2 * Hp, bias=p('rnn%d/b' % l))
+                check(lib.cham_rnn_fwd(0, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
+                                       ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), _stream()), "cham_rnn_fwd")
+                x, ldx, K = pl.rnn_out[l], Hp, Hp
+            rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
+            rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
+        # ... the dominant GEMM: CAR layer 2 on the B*T*(1+N) candidate rows
+        rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+        rt.join()
         # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
         Z2c = pl.Z2[BT:]
         rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
@@ -377,32 +416,37 @@ class NARModuleModel:
         rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
         rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         check(lib.cham_mulpred_bwd(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s), "cham_mulpred_bwd")
-        # session FCs
+        # session FCs + recurrent layers on the side stream ...
         last = L.L - 1
-        rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
-        rt.colsum(pl.dpred, C, BT, C, g('bf2'))
-        rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
-        rt.gemm(pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
-        rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
-        rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
-        # recurrent layers, last to first
-        for l in range(last, -1, -1):
-            check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), s), "cham_transpose_f32")
-            check(lib.cham_rnn_bwd(0, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
-                                   ptr(pl.Cc[l]), ptr(pl.dxproj), s), "cham_rnn_bwd")
-            x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
-            rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, 2 * Hp, BT, ldx, 2 * Hp, 2 * Hp, transA=1, splits=0)
-            rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, 2 * Hp, 2 * Hp, transA=1, splits=0)
-            rt.colsum(pl.dxproj, 2 * Hp, BT, 2 * Hp, g('rnn%d/b' % l))
-            if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows
-                rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, 2 * Hp, 2 * Hp, 2 * Hp, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
-            else:
-                rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1)
-        # CAR layer 2 then the factorised PreCAR
+        rt.fork()
+        with rt.side():
+            ss = _stream()
+            rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
+            rt.colsum(pl.dpred, C, BT, C, g('bf2'))
+            rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
+            rt.gemm(pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
+            rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
+            rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
+            for l in range(last, -1, -1):
+                check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), ss), "cham_transpose_f32")
+                check(lib.cham_rnn_bwd(0, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
+                                       ptr(pl.Cc[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
+                x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
+                rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, 2 * Hp, BT, ldx, 2 * Hp, 2 * Hp, transA=1, splits=0)
+                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, 2 * Hp, 2 * Hp, transA=1, splits=0)
+                rt.colsum(pl.dxproj, 2 * Hp, BT, 2 * Hp, g('rnn%d/b' % l))
+                if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows
+                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, 2 * Hp, 2 * Hp, 2 * Hp, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
+                else:
+                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1)
+        # ... overlapped with the candidate-row dgrad of CAR layer 2 (needs dZ2c only)
+        rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+        rt.join()
+        rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
         rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
-        rt.gemm(pl.dZ2, p('W2'), pl.dZ1, Rall, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
-        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), s), "cham_combine_bwd")
+        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
+                                   rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
         rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
         rt.colsum(pl.dU, C, BT, C, g('b1'))
         rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)

@@ -70,17 +70,23 @@ int cham_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, 
                   int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
                   int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 
+/* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
+void cham_gemm_set_variant(int variant);
+
 /* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward */
 int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* Z1,
                      void* stream);
+size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax);
 int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
-                     void* stream);
+                     float* workspace, size_t workspace_bytes, void* stream);
 
 /* --- K3 recurrent cell time steps: nar_model.py:1308-1361 (cell_kind 0 = UGRNN) */
 int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp, float* out,
                  float* hprev, float* G, float* Cc, void* stream);
 int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
                  const float* hprev, const float* G, const float* Cc, float* dxproj, void* stream);
+/* scheduling hook: recurrent workgroups request this much LDS so that no other workgroup shares their CU */
+void cham_rnn_set_exclusive_lds(size_t bytes);
 int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);
 
 /* --- K5 scoring tail + sampled softmax + masked NLL: nar_model.py:478-517, 639-667 */

@@ -248,6 +248,7 @@ class NAROracle:
     def _car(self, x):
         w = self.w
         pre = _leaky(x @ w['PreCAR/kernel'] + w['PreCAR/bias'])        # nar_model.py:375-382
+        self._tap('Z1', pre)
         return torch.tanh(pre @ w['CAR/kernel'] + w['CAR/bias'])       # :384-403
 
     # -- nar_model.py:1308-1361 (UGRNNCell / GRUCell semantics: SURVEY A.6)
@@ -282,10 +283,17 @@ class NAROracle:
 
     def _scorer(self, m):
         w = self.w
-        s = _leaky(m @ w['match1/kernel'] + w['match1/bias'])
-        s = _leaky(s @ w['match2/kernel'] + w['match2/bias'])
-        s = _leaky(s @ w['match3/kernel'] + w['match3/bias'])
-        return s @ w['match4/kernel'] + w['match4/bias']
+        s1 = _leaky(m @ w['match1/kernel'] + w['match1/bias'])
+        s2 = _leaky(s1 @ w['match2/kernel'] + w['match2/bias'])
+        s3 = _leaky(s2 @ w['match3/kernel'] + w['match3/bias'])
+        self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
+        return s3 @ w['match4/kernel'] + w['match4/bias']
+
+    def _tap(self, name, t):
+        """Optional capture of leaky-ReLU outputs (tests use them to detect kink sign flips)."""
+        taps = getattr(self, 'debug_taps', None)
+        if taps is not None:
+            taps.setdefault(name, []).append(t.detach())
 
     def reg_loss(self):
         lam = self.p['reg_weight_decay']
@@ -333,6 +341,7 @@ class NAROracle:
         car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos), self._car(x_neg)                             # :374-405
         rnn_out = self._rnn(car_in, seq_len)                                                                      # :408
         fc1 = _leaky(rnn_out @ self.w['FC1/kernel'] + self.w['FC1/bias'])                                        # :411
+        self._tap('FC1', fc1)
         pred = torch.tanh(fc1 @ self.w['FC2/kernel'] + self.w['FC2/bias'])                                       # :423
         s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
         s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500

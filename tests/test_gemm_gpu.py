@@ -55,27 +55,27 @@ def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 96), (77, 1024, 408), (1000, 64, 128), (513, 32, 64), (64, 72, 1024)])
 def test_nn(gpu, M, N, K):
-    assert _run(gpu, M, N, K) < 2e-5
-    assert _run(gpu, M, N, K, bias=True, act=1) < 2e-5
-    assert _run(gpu, M, N, K, bias=True, act=2) < 2e-5
+    assert _run(gpu, M, N, K) < 5e-5
+    assert _run(gpu, M, N, K, bias=True, act=1) < 5e-5
+    assert _run(gpu, M, N, K, bias=True, act=2) < 5e-5
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 64), (259, 72, 1024), (1000, 408, 128), (123, 1024, 512), (400, 64, 32)])
 def test_nt_dgrad(gpu, M, N, K):
-    assert _run(gpu, M, N, K, transB=1) < 2e-5
-    assert _run(gpu, M, N, K, transB=1, dref=True, dact=1) < 2e-5
-    assert _run(gpu, M, N, K, transB=1, dref=True, dact=2, accumulate=1) < 2e-5
+    assert _run(gpu, M, N, K, transB=1) < 5e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=1) < 5e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=2, accumulate=1) < 5e-5
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 5000), (72, 1024, 777), (408, 128, 3001), (64, 32, 20000), (1024, 128, 4099)])
 def test_tn_wgrad_splitk(gpu, M, N, K):
-    assert _run(gpu, M, N, K, transA=1) < 5e-5
-    assert _run(gpu, M, N, K, transA=1, splits=0) < 5e-5
-    assert _run(gpu, M, N, K, transA=1, splits=7) < 5e-5
+    assert _run(gpu, M, N, K, transA=1) < 1e-4
+    assert _run(gpu, M, N, K, transA=1, splits=0) < 1e-4
+    assert _run(gpu, M, N, K, transA=1, splits=7) < 1e-4
 
 
 def test_rowscale(gpu):
-    assert _run(gpu, 51 * 40, 128, 256, rowscale=51, bias=True, act=1) < 2e-5          # scorer layer 1
+    assert _run(gpu, 51 * 40, 128, 256, rowscale=51, bias=True, act=1) < 5e-5          # scorer layer 1
     assert _run(gpu, 256, 128, 51 * 40, transA=1, rowscale=51, splits=0) < 5e-5         # its wgrad
 
 

@@ -20,6 +20,7 @@ def _compare_step(model, orc, f, l, st, check_grads=True):
     out = model.outputs_numpy()
     for v in orc.w.values():
         v.grad = None
+    orc.debug_taps = {}
     ref = orc.forward(f, l, buf, pop, 'train')
     assert np.array_equal(out['neg_items'], ref['neg_items'].numpy()), "negative samples must be bit exact"
     mask = ref['mask'].numpy()
@@ -28,24 +29,50 @@ def _compare_step(model, orc, f, l, st, check_grads=True):
     assert abs(out['loss'][1] - float(ref['xe_loss'])) < LOGIT_TOL
     assert abs(out['loss'][2] - float(ref['reg_loss'])) < 1e-5
     assert abs(out['loss'][0] - float(ref['total_loss'])) < LOGIT_TOL
+    flips = _kink_flips(model, orc, mask)
     if check_grads:
         ref['xe_loss'].backward()
         model.backward()
         torch.cuda.synchronize()
         g = model.rt.logical_grads()
+        # leaky_relu'(x) jumps 0.2 -> 1 at 0: a pre-activation within ~1e-7 of zero may take either branch in two
+        # correct fp32 evaluations.  Tight tolerance when no such flip happened on this batch, loose otherwise.
+        tol = 3e-4 if flips == 0 else 0.25
         for k, v in orc.w.items():
             rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
             scale = max(1e-6, float(np.abs(rg).max()))
             err = float(np.abs(g[k] - rg).max())
-            assert err < 2e-3 * scale + 1e-7, "grad %s: err %g scale %g" % (k, err, scale)
+            assert err < tol * scale + 2e-5, "grad %s: err %g scale %g (kink flips %d)" % (k, err, scale, flips)
+    return flips
+
+
+def _kink_flips(model, orc, mask):
+    """Number of leaky-ReLU outputs whose SIGN differs between the HIP path and the oracle (gradient-carrying rows)."""
+    pl, taps = model._plan, orc.debug_taps
+    B, T, NC, BT = pl.B, pl.T, pl.NC, pl.BT
+    n = 0
+    for name, hip in (('S1', pl.S1), ('S2', pl.S2), ('S3', pl.S3)):
+        pos, neg = taps[name]
+        ref = torch.cat([pos.unsqueeze(2), neg], 2).numpy()
+        h = hip.cpu().numpy().reshape(ref.shape)
+        n += int(((h > 0) != (ref > 0))[mask].sum())
+    zin, zpos, zneg = taps['Z1']
+    Z1 = pl.Z1.cpu().numpy()
+    C = zin.shape[-1]
+    n += int(((Z1[:BT].reshape(B, T, C) > 0) != (zin.numpy() > 0))[mask].sum())
+    zc = torch.cat([zpos.unsqueeze(2), zneg], 2).numpy()
+    n += int(((Z1[BT:].reshape(B, T, NC, C) > 0) != (zc > 0))[mask].sum())
+    n += int(((pl.FC1.cpu().numpy().reshape(B, T, -1) > 0) != (taps['FC1'][0].numpy() > 0))[mask].sum())
+    return n
 
 
 def test_step_parity_tiny_warm_state(gpu):
     p = H.tiny_params()
-    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    batches = synthetic.make_batches(7, 64, 8, 1000, p['session_features_config'], length_dist='g1')
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p)
-    _compare_step(model, orc, *batches[3], st)
+    flips = [_compare_step(model, orc, *batches[i], st) for i in (3, 4, 5, 6)]
+    assert sum(1 for x in flips if x == 0) >= 2, "tight gradient parity needs kink-free batches: %r" % flips
 
 
 def test_step_parity_first_batch_empty_buffer(gpu):
@@ -82,7 +109,7 @@ def test_training_curve_matches_oracle(gpu):
     m_hip = model.rt.layout.unpack(model.rt.m.cpu().numpy())
     for k, v in orc.m.items():
         scale = max(1e-8, float(v.abs().max()))
-        assert float(np.abs(m_hip[k] - v.numpy()).max()) < 5e-3 * scale + 1e-8, k
+        assert float(np.abs(m_hip[k] - v.numpy()).max()) < 5e-3 * scale + 2e-6, k   # match4/bias: true gradient is 0
     w_hip = model.rt.logical_weights()
     for k, v in orc.w.items():
         assert float(np.abs(w_hip[k] - v.detach().numpy()).max()) < 2.5 * p['lr'] * len(batches), k
