@@ -14,13 +14,35 @@ SOURCES = ["gemm.hip", "sampler.hip", "features.hip", "scorer.hip", "rnn.hip", "
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stamp():
+HOST_LIB = os.path.join(HERE, "libchameleon_tfrecord.so")
+HOST_SOURCES = [os.path.join(CSRC, "host", "tfrecord.cpp")]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
+
+
+def _stamp(files=None, flags=FLAGS):
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)):
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    if files is None:
+        files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode()); h.update(fh.read())
+    h.update(" ".join(flags).encode())
     return h.hexdigest()
+
+
+def build_host(force=False, verbose=True):
+    """libchameleon_tfrecord.so: the host-side session TFRecord codec (plain C++17 + zlib, g++)."""
+    stamp_file = HOST_LIB + ".stamp"
+    stamp = _stamp(HOST_SOURCES, HOST_FLAGS)
+    if not force and os.path.exists(HOST_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return HOST_LIB
+    cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + HOST_SOURCES + ["-o", HOST_LIB, "-lz"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return HOST_LIB
 
 
 def build(force=False, verbose=True):
@@ -57,3 +79,4 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_host(force="--force" in sys.argv)

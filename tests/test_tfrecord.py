@@ -1,0 +1,224 @@
+"""Session-file codec (libchameleon_tfrecord.so) and the input_fn mirror (nar/datasets.py).
+
+Independent pins (TensorFlow is not installable here): CRC-32C known answers (RFC 3720), python's gzip/struct for
+the TFRecord framing, and the official protobuf runtime with a dynamically built tf.train.SequenceExample
+descriptor (feature.proto / example.proto field numbers) for the payload - both directions."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from chameleon_recsys_amd import _tfrecord
+from chameleon_recsys_amd.nar import config, datasets, synthetic, tf_records_management as tfm
+
+
+def _crc(data):
+    lib = _tfrecord.load()
+    return lib.cham_crc32c_masked(data, len(data))
+
+
+def _unmask(m):
+    rot = (m - 0xa282ead8) & 0xFFFFFFFF
+    return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
+
+
+def test_crc32c_known_answers():
+    assert _unmask(_crc(b"123456789")) == 0xE3069283
+    assert _unmask(_crc(bytes(32))) == 0x8A9136AA
+    assert _unmask(_crc(bytes([0xFF] * 32))) == 0x62A8AB43
+    assert _unmask(_crc(bytes(range(32)))) == 0x46DD794E
+
+
+def _seqex_classes():
+    """tf.train.SequenceExample built from its published .proto definition with the protobuf runtime."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="cham_example.proto", package="chamtf", syntax="proto3")
+
+    def msg(name):
+        m = fd.message_type.add(); m.name = name
+        return m
+
+    def field(m, name, num, ftype, label=1, type_name=None, packed=None):
+        f = m.field.add(); f.name, f.number, f.type, f.label = name, num, ftype, label
+        if type_name:
+            f.type_name = type_name
+        if packed is not None:
+            f.options.packed = packed
+        return f
+    T = descriptor_pb2.FieldDescriptorProto
+    field(msg("BytesList"), "value", 1, T.TYPE_BYTES, 3)
+    field(msg("FloatList"), "value", 1, T.TYPE_FLOAT, 3, packed=True)
+    field(msg("Int64List"), "value", 1, T.TYPE_INT64, 3, packed=True)
+    m = msg("Feature")
+    m.oneof_decl.add().name = "kind"
+    for n, num, tn in (("bytes_list", 1, ".chamtf.BytesList"), ("float_list", 2, ".chamtf.FloatList"), ("int64_list", 3, ".chamtf.Int64List")):
+        field(m, n, num, T.TYPE_MESSAGE, 1, tn).oneof_index = 0
+    m = msg("Features")
+    e = m.nested_type.add(); e.name = "FeatureEntry"; e.options.map_entry = True
+    field(e, "key", 1, T.TYPE_STRING); field(e, "value", 2, T.TYPE_MESSAGE, 1, ".chamtf.Feature")
+    field(m, "feature", 1, T.TYPE_MESSAGE, 3, ".chamtf.Features.FeatureEntry")
+    field(msg("FeatureList"), "feature", 1, T.TYPE_MESSAGE, 3, ".chamtf.Feature")
+    m = msg("FeatureLists")
+    e = m.nested_type.add(); e.name = "FeatureListEntry"; e.options.map_entry = True
+    field(e, "key", 1, T.TYPE_STRING); field(e, "value", 2, T.TYPE_MESSAGE, 1, ".chamtf.FeatureList")
+    field(m, "feature_list", 1, T.TYPE_MESSAGE, 3, ".chamtf.FeatureLists.FeatureListEntry")
+    m = msg("SequenceExample")
+    field(m, "context", 1, T.TYPE_MESSAGE, 1, ".chamtf.Features")
+    field(m, "feature_lists", 2, T.TYPE_MESSAGE, 1, ".chamtf.FeatureLists")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("chamtf.SequenceExample"))
+
+
+def _read_records_python(path):
+    """Independent TFRecord framing reader: python gzip + struct."""
+    raw = gzip.open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        (n,) = struct.unpack_from("<Q", raw, off)
+        out.append(raw[off + 12: off + 12 + n])
+        off += 12 + n + 4
+    assert off == len(raw)
+    return out
+
+
+@pytest.fixture(scope="module")
+def g1_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sessions")
+    cfg = config.get_session_features_config_gcom(1000)
+    files, sessions = [], []
+    sid = 0
+    for hour in range(3):
+        ss = synthetic.make_sessions(37 + 5 * hour, 25, 1000, cfg, seed=3, hour_index=hour, length_dist='g1', first_session_id=sid)
+        if hour == 1:     # a few long sessions so that truncation bites
+            ss += synthetic.make_sessions(4, 25, 1000, cfg, seed=4, hour_index=hour, length_dist='full', first_session_id=sid + 1000)
+        sid += len(ss)
+        path = str(d / ("sessions_hour_%03d.tfrecord.gz" % hour))
+        tfm.save_rows_to_tf_record_file(ss, cfg, path)
+        files.append(path); sessions += ss
+    return cfg, files, sessions
+
+
+def test_writer_payload_parses_with_protobuf_runtime(g1_files):
+    cfg, files, sessions = g1_files
+    SeqEx = _seqex_classes()
+    recs = _read_records_python(files[0])
+    n0 = sum(1 for _ in recs)
+    assert n0 == 37
+    for rec, s in zip(recs, sessions[:n0]):
+        ex = SeqEx.FromString(rec)
+        assert ex.context.feature["session_id"].int64_list.value[0] == s["session_id"]
+        assert ex.context.feature["session_size"].int64_list.value[0] == s["session_size"]
+        fl = ex.feature_lists.feature_list
+        assert [f.int64_list.value[0] for f in fl["item_clicked"].feature] == list(s["item_clicked"])
+        assert [f.int64_list.value[0] for f in fl["event_timestamp"].feature] == list(s["event_timestamp"])
+        got = np.array([f.float_list.value[0] for f in fl["local_hour_sin"].feature], np.float32)
+        assert np.array_equal(got, s["local_hour_sin"])
+        assert all(len(f.int64_list.value) == 1 for f in fl["os"].feature)     # one value per step (FixedLenSequenceFeature([]))
+
+
+def test_reader_parses_protobuf_runtime_output(tmp_path):
+    """Records serialised by the protobuf runtime (what tf.train.SequenceExample.SerializeToString emits) -> our reader,
+    including features the config does not name (ignored) and unpacked encodings."""
+    SeqEx = _seqex_classes()
+    cfg = config.get_session_features_config_gcom(1000)
+    ss = synthetic.make_sessions(9, 12, 1000, cfg, seed=8, length_dist='g1')
+    path = str(tmp_path / "pb.tfrecord.gz")
+    lib = _tfrecord.load()
+    h = lib.cham_tfw_open(path.encode(), 6)
+    for s in ss:
+        ex = SeqEx()
+        for n in cfg['single_features']:
+            ex.context.feature[n].int64_list.value.append(int(s[n]))
+        ex.context.feature["extra_ctx"].bytes_list.value.append(b"ignored")
+        for n, c in cfg['sequence_features'].items():
+            for v in s[n]:
+                f = ex.feature_lists.feature_list[n].feature.add()
+                if c['dtype'] == 'int':
+                    f.int64_list.value.append(int(v))
+                else:
+                    f.float_list.value.append(float(v))
+        ex.feature_lists.feature_list["url"].feature.add().bytes_list.value.append(b"http://x")
+        data = ex.SerializeToString()
+        assert lib.cham_tfw_write_record(h, data, len(data)) == 0
+    assert lib.cham_tfw_close(h) == 0
+    f, l = next(iter(datasets.SessionDataset(path, cfg, batch_size=16, truncate_sequence_length=20)))
+    rf, rl = synthetic.batch_from_sessions(ss, cfg, 20)
+    for k in rf:
+        assert np.array_equal(f[k], rf[k]), k
+    for k in rl:
+        assert np.array_equal(l[k], rl[k]), k
+
+
+def test_input_fn_matches_reference_transform(g1_files):
+    """prepare_dataset_iterator == the truncate / shift / pad transform of datasets.py:35-143 on the same sessions;
+    files in order, short last batch, T varies per batch."""
+    cfg, files, sessions = g1_files
+    features, labels = datasets.prepare_dataset_iterator(files, cfg, batch_size=32, truncate_session_length=20)
+    ds = features.dataset
+    i, n_batches = 0, 0
+    while ds.advance():
+        chunk = sessions[i:i + 32]
+        rf, rl = synthetic.batch_from_sessions(chunk, cfg, 20)
+        assert set(features.keys()) == set(rf.keys())
+        for k in rf:
+            assert features[k].dtype == rf[k].dtype and np.array_equal(features[k], rf[k]), k
+        assert np.array_equal(labels['label_next_item'], rl['label_next_item'])
+        assert np.array_equal(labels['label_last_item'], rl['label_last_item']) and labels['label_last_item'].shape == (len(chunk), 1)
+        assert features['session_size'].max() <= 20 and features['item_clicked'].shape[1] <= 19
+        i += len(chunk); n_batches += 1
+    assert i == len(sessions) and n_batches == (len(sessions) + 31) // 32
+    assert not ds.advance()
+    with pytest.raises(datasets.OutOfRangeError):
+        ds.get_next()
+
+
+def test_corrupt_and_missing_inputs(g1_files, tmp_path):
+    cfg, files, _ = g1_files
+    raw = bytearray(gzip.open(files[0], "rb").read())
+    raw[40] ^= 0x5A                                   # flip a payload byte -> data CRC mismatch
+    bad = str(tmp_path / "bad.tfrecord.gz")
+    gzip.open(bad, "wb").write(bytes(raw))
+    ds = datasets.SessionDataset(bad, cfg, batch_size=8)
+    with pytest.raises(_tfrecord.TFRecordError, match="CRC"):
+        while ds.advance():
+            pass
+    with pytest.raises(_tfrecord.TFRecordError, match="I/O"):
+        datasets.SessionDataset(str(tmp_path / "nope.tfrecord.gz"), cfg, batch_size=8).advance()
+    cfg2 = config.get_session_features_config_gcom(1000)
+    cfg2['sequence_features']['not_in_file'] = {'type': 'numerical', 'dtype': 'float'}
+    with pytest.raises(_tfrecord.TFRecordError, match="missing"):
+        datasets.SessionDataset(files[0], cfg2, batch_size=8).advance()
+    empty = str(tmp_path / "empty.tfrecord.gz")
+    gzip.open(empty, "wb").close()
+    assert not datasets.SessionDataset(empty, cfg, batch_size=8).advance()
+
+
+def test_adressa_schema_with_bytes_user_id(tmp_path):
+    cfg = config.get_session_features_config_adressa(500)
+    cfg['single_features']['user_id'] = {'type': 'categorical', 'dtype': 'bytes'}     # nar_trainer_adressa.py:149
+    ss = synthetic.make_sessions(11, 30, 500, cfg, seed=2, length_dist='g1')
+    for i, s in enumerate(ss):
+        s['user_id'] = ("cx:%d:abc" % i).encode()
+    path = str(tmp_path / "adressa_sessions_0000.tfrecord.gz")
+    tfm.save_rows_to_tf_record_file(ss, cfg, path)
+    f, l = next(iter(datasets.SessionDataset(path, cfg, batch_size=64, truncate_sequence_length=30)))
+    assert list(f['user_id']) == [s['user_id'] for s in ss]
+    rf, rl = synthetic.batch_from_sessions(ss, {**cfg, 'single_features': {k: v for k, v in cfg['single_features'].items() if k != 'user_id'}}, 30)
+    for k in rf:
+        assert np.array_equal(f[k], rf[k]), k
+    assert np.array_equal(l['label_next_item'], rl['label_next_item'])
+
+
+def test_export_and_resolve_files(tmp_path):
+    from chameleon_recsys_amd.nar.utils import chunks, resolve_files
+    cfg = config.get_session_features_config_gcom(300)
+    ss = synthetic.make_sessions(25, 10, 300, cfg, seed=1)
+    out = tfm.export_sessions_to_tf_records(ss, cfg, str(tmp_path / "sessions_hour_*.tfrecord.gz"), examples_by_file=10)
+    assert [os.path.basename(p) for p in out] == ["sessions_hour_%04d.tfrecord.gz" % i for i in range(3)]
+    assert resolve_files(str(tmp_path / "sessions_hour_*.tfrecord.gz")) == sorted(out)
+    assert list(chunks(list(range(5)), 2)) == [[0, 1], [2, 3], [4]]
+    n = sum(len(f['session_id']) for f, _ in datasets.SessionDataset(out, cfg, batch_size=7))
+    assert n == 25
