@@ -33,6 +33,7 @@ _SIGNATURES = {
     "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, P]),
     "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, P]),
+    "cham_rank_items": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
     "cham_sumsq_partial": (c_int, [P, c_size_t, P, P]),
     "cham_loss_finalize": (c_int, [P, c_int, c_float, P, c_float, P, P]),
     "cham_adam_tf": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),

@@ -250,6 +250,34 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const float* __restri
     }
 }
 
+
+// rank_items_by_predicted_prob (nar_model.py:777-794): tf.nn.top_k over the 1+N candidates = descending stable sort
+// (lowest index wins ties).  One wave per click; rank by counting; also emits the rank of the positive (c = 0).
+__global__ __launch_bounds__(256) void k_rank_items(const float* __restrict__ probs, const int64_t* __restrict__ label_next,
+                                                    const int64_t* __restrict__ neg_ids, const unsigned char* __restrict__ mask,
+                                                    int BT, int N, int64_t* __restrict__ pred_ids, float* __restrict__ pred_probs,
+                                                    int32_t* __restrict__ label_rank) {
+    extern __shared__ float sp[];                  // [4][NC]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, bt = blockIdx.x * 4 + w;
+    const int NC = N + 1;
+    float* p = sp + (size_t)w * NC;
+    if (bt < BT)
+        for (int c = lane; c < NC; c += 64) p[c] = probs[(size_t)bt * NC + c];
+    __syncthreads();
+    if (bt >= BT) return;
+    for (int c = lane; c < NC; c += 64) {
+        const float pc = p[c];
+        int r = 0;
+        for (int j = 0; j < NC; ++j) {
+            const float pj = p[j];
+            r += (pj > pc) || (pj == pc && j < c);
+        }
+        pred_ids[(size_t)bt * NC + r] = c == 0 ? label_next[bt] : neg_ids[(size_t)bt * N + (c - 1)];
+        pred_probs[(size_t)bt * NC + r] = pc;
+        if (c == 0) label_rank[bt] = mask[bt] ? r : -1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot,
                                 float* Z1, void* stream) {
@@ -312,6 +340,17 @@ extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, 
     const size_t rows = (size_t)BT * (N + 1);
     hipLaunchKernelGGL(k_score_softmax_bwd<32>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
                        probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t* neg_ids, const uint8_t* mask, int BT,
+                               int N, int64_t* pred_ids, float* pred_probs, int32_t* label_rank, void* stream) {
+    if (!probs || !label_next || !neg_ids || !mask || !pred_ids || !pred_probs || !label_rank || BT <= 0 || N <= 0 || N > 8191)
+        return -CHAM_ERR_ARG;
+    const size_t smem = (size_t)4 * (N + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_rank_items, dim3((BT + 3) / 4), dim3(256), smem, (hipStream_t)stream, probs, label_next, neg_ids, mask, BT,
+                       N, pred_ids, pred_probs, label_rank);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -1,0 +1,226 @@
+"""Minimal Estimator runtime behind the reference's ``model_fn`` / ``input_fn`` contract.
+
+The reference drives training through tf.estimator.Estimator (nar_trainer_gcom.py:335-386, 511-525): every
+``train(input_fn)`` / ``evaluate(input_fn)`` call builds the graph by calling ``input_fn()`` then
+``model_fn(features, labels, mode, params)``, restores the variables from ``model_dir``, runs one ``session.run`` per
+batch with the spec's SessionRunHooks around it until the input is exhausted (tf.errors.OutOfRangeError), and saves a
+checkpoint.  This module keeps exactly that control flow without a graph: ``features`` / ``labels`` are the re-bound
+batch handles of datasets.prepare_dataset_iterator, the "variables" are the device-resident NARRuntime kept in the
+Estimator's variable store between calls (and checkpointed to model_dir), and a step is ``spec.train_op()``.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import nar_model
+from .nar_model import ModeKeys
+
+
+class RunConfig:
+    """tf.estimator.RunConfig fields the reference sets (nar_trainer_gcom.py:343-348)."""
+
+    def __init__(self, tf_random_seed=None, keep_checkpoint_max=1, save_checkpoints_secs=1200, save_summary_steps=100,
+                 log_step_count_steps=100, model_dir=None):
+        self.tf_random_seed = tf_random_seed
+        self.keep_checkpoint_max = keep_checkpoint_max
+        self.save_checkpoints_secs = save_checkpoints_secs
+        self.save_summary_steps = save_summary_steps
+        self.log_step_count_steps = log_step_count_steps
+        self.model_dir = model_dir
+
+
+class EstimatorSpec:
+    def __init__(self, mode, loss=None, train_op=None, eval_metric_ops=None, training_chief_hooks=None, training_hooks=None,
+                 evaluation_hooks=None, predictions=None):
+        self.mode, self.loss, self.train_op = mode, loss, train_op
+        self.eval_metric_ops = eval_metric_ops or {}
+        self.training_chief_hooks = list(training_chief_hooks or [])
+        self.training_hooks = list(training_hooks or [])
+        self.evaluation_hooks = list(evaluation_hooks or [])
+        self.predictions = predictions
+        if mode == ModeKeys.TRAIN and (loss is None or train_op is None):
+            raise ValueError("Missing loss / train_op for ModeKeys.TRAIN")
+        if mode == ModeKeys.EVAL and loss is None:
+            raise ValueError("Missing loss for ModeKeys.EVAL")
+
+
+class SessionRunArgs:
+    def __init__(self, fetches=None, feed_dict=None):
+        self.fetches, self.feed_dict = fetches or {}, feed_dict or {}
+
+
+class SessionRunValues:
+    def __init__(self, results):
+        self.results = results
+
+
+class SessionRunContext:
+    def __init__(self, model):
+        self.model = model
+        self.stop_requested = False
+
+    def request_stop(self):
+        self.stop_requested = True
+
+
+class SessionRunHook:
+    def begin(self):
+        pass
+
+    def after_create_session(self, session=None, coord=None):
+        pass
+
+    def before_run(self, run_context):
+        return None
+
+    def after_run(self, run_context, run_values):
+        pass
+
+    def end(self, session=None):
+        pass
+
+
+class StreamingMean:
+    """(value, update_op) pair of tf.metrics.* as one object: ``update(batch_sum, batch_count)`` / ``result()``."""
+
+    def __init__(self):
+        self.total, self.count = 0.0, 0.0
+
+    def update(self, s, n):
+        self.total += float(s); self.count += float(n)
+
+    def result(self):
+        return self.total / self.count if self.count > 0 else 0.0
+
+
+class Estimator:
+    def __init__(self, model_fn, model_dir=None, config=None, params=None, warm_start_from=None):
+        self._model_fn = model_fn
+        self.config = config or RunConfig()
+        self.model_dir = model_dir or self.config.model_dir
+        self.params = dict(params or {})
+        seed = self.config.tf_random_seed
+        self._store = dict(runtime=None, tf_random_seed=42 if seed is None else int(seed))
+        self._last_ckpt_time = time.time()
+        self.steps_per_sec = None
+        if self.model_dir:
+            os.makedirs(self.model_dir, exist_ok=True)
+
+    # ---- checkpoints (nar_trainer_gcom.py:343-353: keep_checkpoint_max=1, implicit restore)
+    def _ckpt_path(self):
+        return os.path.join(self.model_dir, "model.ckpt.pt") if self.model_dir else None
+
+    def latest_checkpoint(self):
+        p = self._ckpt_path()
+        return p if p and os.path.exists(p) else None
+
+    def _maybe_restore(self, created_now):
+        """A freshly created runtime (first call in this process) is restored from model_dir when a checkpoint exists."""
+        if created_now and self.latest_checkpoint():
+            sd = torch.load(self.latest_checkpoint(), map_location="cpu", weights_only=False)
+            self._store['runtime'].load_state_dict(sd)
+
+    def save_checkpoint(self):
+        p = self._ckpt_path()
+        rt = self._store.get('runtime')
+        if p and rt is not None:
+            tmp = p + ".tmp"
+            torch.save(rt.state_dict(), tmp)
+            os.replace(tmp, p)
+            self._last_ckpt_time = time.time()
+
+    def get_variable_value(self, name):
+        return self._store['runtime'].logical_weights()[name]
+
+    def get_variable_names(self):
+        return list(self._store['runtime'].layout.logical_specs().keys())
+
+    @property
+    def global_step(self):
+        rt = self._store.get('runtime')
+        return rt.global_step if rt is not None else 0
+
+    # ---- the session.run loop
+    def _call_model_fn(self, input_fn, mode):
+        features, labels = input_fn()
+        had_rt = self._store.get('runtime') is not None
+        with nar_model.variable_store(self._store):
+            spec = self._model_fn(features, labels, mode, self.params)
+        self._maybe_restore(not had_rt and self._store.get('runtime') is not None)
+        return features, labels, spec
+
+    @staticmethod
+    def _run_hooks_step(hooks, ctx, step_fn):
+        fetches = []
+        feed = {}
+        for h in hooks:
+            args = h.before_run(ctx)
+            fetches.append(args.fetches if args is not None else None)
+            if args is not None:
+                feed.update(args.feed_dict)
+        if feed:
+            ctx.model.feed(feed)
+        out = step_fn()
+        for h, f in zip(hooks, fetches):
+            res = {k: (v.eval() if hasattr(v, 'eval') else v) for k, v in f.items()} if f is not None else None
+            h.after_run(ctx, SessionRunValues(res))
+        return out
+
+    def train(self, input_fn, hooks=None, steps=None, max_steps=None):
+        features, labels, spec = self._call_model_fn(input_fn, ModeKeys.TRAIN)
+        ds = features.dataset
+        all_hooks = list(spec.training_chief_hooks) + list(spec.training_hooks) + list(hooks or [])
+        model = getattr(spec.train_op, '__self__', None)
+        ctx = SessionRunContext(model)
+        for h in all_hooks:
+            h.begin()
+        n, t0 = 0, time.time()
+        last_log, log_every = 0, self.config.log_step_count_steps
+        while (steps is None or n < steps) and (max_steps is None or self.global_step < max_steps) and not ctx.stop_requested:
+            if not ds.advance():
+                break
+            self._run_hooks_step(all_hooks, ctx, spec.train_op)
+            n += 1
+            if log_every and n - last_log >= log_every:
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                self.steps_per_sec = n / dt
+                print("INFO:global_step/sec: %.4g (step %d)" % (n / dt, self.global_step), flush=True)
+                last_log = n
+            if self.config.save_checkpoints_secs and time.time() - self._last_ckpt_time > self.config.save_checkpoints_secs:
+                self.save_checkpoint()
+        torch.cuda.synchronize()
+        if n:
+            self.steps_per_sec = n / max(1e-9, time.time() - t0)
+        for h in all_hooks:
+            h.end(None)
+        ds.close()
+        self.save_checkpoint()
+        return self
+
+    def evaluate(self, input_fn, steps=None, hooks=None, name=None):
+        features, labels, spec = self._call_model_fn(input_fn, ModeKeys.EVAL)
+        ds = features.dataset
+        all_hooks = list(spec.evaluation_hooks) + list(hooks or [])
+        model = None
+        for h in all_hooks:
+            model = getattr(h, 'model', model)
+        ctx = SessionRunContext(model)
+        for h in all_hooks:
+            h.begin()
+        n, loss_sum = 0, 0.0
+        while steps is None or n < steps:
+            if not ds.advance():
+                break
+            self._run_hooks_step(all_hooks, ctx, model.run_step)
+            loss_sum += float(np.asarray(spec.loss.eval() if hasattr(spec.loss, 'eval') else spec.loss).reshape(-1)[0])
+            n += 1
+        for h in all_hooks:
+            h.end(None)
+        ds.close()
+        out = {k: (v.result() if hasattr(v, 'result') else v) for k, v in spec.eval_metric_ops.items()}
+        out['loss'] = loss_sum / max(1, n)
+        out['global_step'] = self.global_step
+        return out

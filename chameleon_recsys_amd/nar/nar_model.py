@@ -31,6 +31,52 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Tensor:
+    """Lazy fetch handle: what a symbolic tf.Tensor attribute of the reference model is to its SessionRunHook
+    (nar_model.py:1435-1456).  ``eval()`` returns the numpy value of the LAST executed step."""
+
+    def __init__(self, name, fn):
+        self.name, self._fn = name, fn
+
+    def eval(self):
+        v = self._fn()
+        if torch.is_tensor(v):
+            v = v.cpu().numpy()
+        return v
+
+
+class Placeholder:
+    """tf.placeholder stand-in (nar_model.py:170-202): fed through ``NARModuleModel.feed(feed_dict)``."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __hash__(self):
+        return hash(self.name)
+
+    def __eq__(self, o):
+        return isinstance(o, Placeholder) and o.name == self.name
+
+
+# The Estimator's "variable store": TF re-creates the graph at every train()/evaluate() call and restores the
+# variables from the checkpoint in model_dir; here the device-resident NARRuntime simply survives between calls.
+_VARIABLE_STORE = None
+
+
+class variable_store:
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        global _VARIABLE_STORE
+        self._prev, _VARIABLE_STORE = _VARIABLE_STORE, self.store
+        return self.store
+
+    def __exit__(self, *a):
+        global _VARIABLE_STORE
+        _VARIABLE_STORE = self._prev
+
+
 class NARRuntime:
     """Everything that outlives a single train()/evaluate() call: weights + Adam slots in ONE flat HBM buffer,
     resident article tables (ACE matrix, metadata - re-fed from numpy every step by the reference,
@@ -255,8 +301,11 @@ class NARModuleModel:
         self.recent_clicks_for_normalization = recent_clicks_for_normalization
         self.recent_clicks_buffer_max_size = recent_clicks_buffer_max_size
         self.eval_cold_start = eval_cold_start
+        if runtime is None and _VARIABLE_STORE is not None and _VARIABLE_STORE.get('runtime') is not None:
+            runtime = _VARIABLE_STORE['runtime']
         if runtime is None:
-            runtime = NARRuntime(dict(session_features_config=session_features_config,
+            seed = _VARIABLE_STORE.get('tf_random_seed', 42) if _VARIABLE_STORE is not None else 42
+            runtime = NARRuntime(dict(tf_random_seed=seed,session_features_config=session_features_config,
                                       articles_features_config=articles_features_config,
                                       content_article_embeddings_matrix=content_article_embeddings_matrix,
                                       articles_metadata=articles_metadata, CAR_embedding_size=CAR_embedding_size,
@@ -264,7 +313,9 @@ class NARModuleModel:
                                       internal_features_config=internal_features_config,
                                       max_cardinality_for_ohe=max_cardinality_for_ohe,
                                       recent_clicks_buffer_max_size=recent_clicks_buffer_max_size,
-                                      recent_clicks_for_normalization=recent_clicks_for_normalization))
+                                      recent_clicks_for_normalization=recent_clicks_for_normalization), seed=seed)
+            if _VARIABLE_STORE is not None:
+                _VARIABLE_STORE['runtime'] = runtime
         self.rt = runtime
         # state "placeholders" (nar_model.py:195-202): fed by ItemsStateUpdaterHook.before_run
         self.articles_recent_pop_norm = None
@@ -272,6 +323,38 @@ class NARModuleModel:
         self._dev_state = None
         self.total_loss = None
         self.train = self.train_step           # the reference's ``model.train`` op
+        self._eval_iter = 0
+        self._eval = None
+        # attributes ItemsStateUpdaterHook fetches / feeds (nar_model.py:1435-1467)
+        inp = lambda k: Tensor(k, lambda: np.asarray(self.inputs[k]))
+        self.item_clicked = inp('item_clicked')
+        self.event_timestamp = Tensor('event_timestamp', lambda: np.asarray(self.inputs['event_timestamp'])[..., None])   # :233
+        self.session_id, self.user_id = inp('session_id'), inp('user_id')
+        self.next_item_label = Tensor('next_item_label', lambda: np.asarray(self.labels['label_next_item']))
+        self.label_last_item = Tensor('label_last_item', lambda: np.asarray(self.labels['label_last_item']))
+        self.batch_negative_items = Tensor('batch_negative_items', lambda: self._plan.neg_ids)
+        self.predicted_item_ids = Tensor('predicted_item_ids', lambda: self._eval['pred_ids'])
+        self.predicted_item_probs = Tensor('predicted_item_probs', lambda: self._eval['pred_probs'])
+        self.label_rank = Tensor('label_rank', lambda: self._eval['label_rank'])
+        self.batch_items_count = Tensor('batch_items_count', lambda: self._batch_counts()[0])          # :258
+        self.batch_unique_items_count = Tensor('batch_unique_items_count', lambda: self._batch_counts()[1])   # :261
+        self.loss_t = Tensor('total_loss', lambda: self.total_loss)
+        self.ph_articles_recent_pop_norm = Placeholder('articles_recent_pop_norm')      # :195
+        self.ph_pop_recent_items_buffer = Placeholder('pop_recent_items_buffer')        # :200
+        self.ph_content_article_embeddings_matrix = Placeholder('content_article_embeddings_matrix')   # :170
+        self.ph_articles_metadata = {n: Placeholder('articles_metadata/' + n) for n in (articles_metadata or {})}
+
+    def _batch_counts(self):
+        ic = np.asarray(self.inputs['item_clicked'])
+        nz = ic[ic != 0]
+        return int(nz.shape[0]), int(np.unique(nz).shape[0])
+
+    def feed(self, feed_dict):
+        """session.run(feed_dict=...) of the hook (nar_model.py:1458-1467).  The ACE matrix / metadata placeholders are
+        accepted and ignored when they are the arrays already resident in HBM (the reference re-feeds them every step
+        only to keep them out of the checkpoint)."""
+        by_name = {(k.name if isinstance(k, Placeholder) else k): v for k, v in feed_dict.items()}
+        self.feed_state(by_name['articles_recent_pop_norm'], by_name['pop_recent_items_buffer'])
 
     # ------------------------------------------------------------------ host -> device
     def feed_state(self, pop_norm, buffer_ids):
@@ -323,7 +406,8 @@ class NARModuleModel:
         s = _stream()
         BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
-        step = rt.global_step if step is None else step
+        if step is None:
+            step = rt.global_step if self.is_training else self.eval_step_key(rt.global_step, self._eval_iter)
         p = rt.p
         # K0 negative sampling (nar_model.py:265-276)
         check(lib.cham_neg_sample(ptr(d['aci']), d['Bg'], T + 1, ptr(st['buffer']), st['buffer'].numel(),
@@ -386,7 +470,6 @@ class NARModuleModel:
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
         self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
-        self.batch_negative_items = pl.neg_ids
         return pl
 
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
@@ -478,6 +561,32 @@ class NARModuleModel:
         self.apply_gradients()
         return self.total_loss
 
+    @staticmethod
+    def eval_step_key(global_step, eval_iter):
+        """Sampler key of the eval_iter-th batch of an evaluate() call (distinct from every training step's key)."""
+        return (global_step + 1000003 * (eval_iter + 1)) & 0xFFFFFFFF
+
+    def evaluate_step(self, device_batch=None):
+        """EVAL-mode ``session.run``: forward with the eval negative-sample counts (nar_trainer_gcom.py:240-242) +
+        rank_items_by_predicted_prob (nar_model.py:777-794)."""
+        d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)
+        pl = self.forward(d)
+        rt, dev = self.rt, self.rt.device
+        ev = self._eval
+        if ev is None or ev['pred_ids'].shape != (pl.B, pl.T, pl.NC):
+            ev = self._eval = dict(pred_ids=torch.zeros(pl.B, pl.T, pl.NC, dtype=torch.int64, device=dev),
+                                   pred_probs=torch.zeros(pl.B, pl.T, pl.NC, dtype=torch.float32, device=dev),
+                                   label_rank=torch.zeros(pl.B, pl.T, dtype=torch.int32, device=dev))
+        check(rt.lib.cham_rank_items(ptr(pl.probs), ptr(d['label_next']), ptr(pl.neg_ids), ptr(pl.mask), pl.BT, pl.N,
+                                     ptr(ev['pred_ids']), ptr(ev['pred_probs']), ptr(ev['label_rank']), _stream()),
+              "cham_rank_items")
+        self._eval_iter += 1
+        return self.total_loss
+
+    def run_step(self):
+        """What ``session.run(train_op | eval fetches)`` does for the current value of the input handles."""
+        return self.train_step() if self.is_training else self.evaluate_step()
+
     # convenience for tests / hooks -------------------------------------------------------------------
     def outputs_numpy(self):
         pl = self._plan
@@ -485,3 +594,114 @@ class NARModuleModel:
         return dict(loss=pl.loss.cpu().numpy(), logits=pl.logits.view(pl.B, pl.T, pl.NC).cpu().numpy(),
                     probs=pl.probs.view(pl.B, pl.T, pl.NC).cpu().numpy(), neg_items=pl.neg_ids.cpu().numpy(),
                     neg_slot=pl.neg_slot.cpu().numpy(), pool=pl.pool.cpu().numpy(), meta=pl.meta.cpu().numpy())
+
+
+class ItemsStateUpdaterHook:
+    """SessionRunHook around every step (nar_model.py:1369-1700), NAR-path subset:
+      * before_run (:1434-1470): feeds ``articles_recent_pop_norm`` / ``pop_recent_items_buffer`` (+ the ACE matrix and
+        metadata placeholders, which are already resident in HBM here) and names the fetches;
+      * after_run (:1504-1650): in EVAL, HitRate@n / MRR@n of the ranked candidates (the reference's numpy streaming
+        metrics, metrics.py, plus the TF streaming twins nar_model.py:826-835, 859-885); always: the recent-clicks state
+        update from the batch (:1635-1649);
+      * begin / end (:1410-1431, :1669-1695): state snapshot around evaluation, metrics appended to
+        ``eval_sessions_metrics_log``.
+    Out of scope: the baseline recommenders (``eval_benchmark_classifiers`` must be empty), the
+    co-occurrence matrix (:1650), cold-start analysis, novelty / diversity / coverage metrics."""
+
+    def __init__(self, mode, model, eval_metrics_top_n, clicked_items_state, eval_sessions_metrics_log,
+                 sessions_negative_items_log=None, sessions_chameleon_recommendations_log=None,
+                 content_article_embeddings_matrix=None, articles_metadata=None, eval_negative_sample_relevance=None,
+                 eval_benchmark_classifiers=[], eval_metrics_by_session_position=False, eval_cold_start=False,
+                 eval_metric_ops=None):
+        if eval_benchmark_classifiers:
+            raise NotImplementedError("baseline recommenders (nar/benchmarks) are out of scope: pass --disable_eval_benchmarks")
+        if eval_cold_start or eval_metrics_by_session_position:
+            raise NotImplementedError("eval_cold_start / eval_metrics_by_session_position are not built")
+        self.mode, self.model = mode, model
+        self.eval_metrics_top_n = eval_metrics_top_n
+        self.clicked_items_state = clicked_items_state
+        self.eval_sessions_metrics_log = eval_sessions_metrics_log
+        self.sessions_negative_items_log = sessions_negative_items_log
+        self.sessions_chameleon_recommendations_log = sessions_chameleon_recommendations_log
+        self.content_article_embeddings_matrix = content_article_embeddings_matrix
+        self.articles_metadata = articles_metadata or {}
+        self.eval_metric_ops = eval_metric_ops or {}
+
+    def begin(self):
+        if self.mode == ModeKeys.EVAL:
+            from .metrics import HitRate, MRR
+            self.clicked_items_state.save_state_checkpoint()                    # nar_model.py:1415
+            self.eval_streaming_metrics_last = {}
+            self.streaming_metrics = [HitRate(self.eval_metrics_top_n), MRR(self.eval_metrics_top_n)]
+            self.stats_logs = []
+
+    def after_create_session(self, session=None, coord=None):
+        pass
+
+    def before_run(self, run_context):
+        from .estimator import SessionRunArgs
+        m = self.model
+        fetches = {'clicked_items': m.item_clicked, 'clicked_timestamps': m.event_timestamp,
+                   'next_item_labels': m.next_item_label, 'last_item_label': m.label_last_item,
+                   'session_id': m.session_id, 'user_id': m.user_id}
+        if self.mode == ModeKeys.EVAL:
+            fetches.update(predicted_item_ids=m.predicted_item_ids, eval_batch_negative_items=m.batch_negative_items,
+                           batch_items_count=m.batch_items_count, batch_unique_items_count=m.batch_unique_items_count,
+                           predicted_item_probs=m.predicted_item_probs, label_rank=m.label_rank)
+        feed_dict = {m.ph_articles_recent_pop_norm: self.clicked_items_state.get_articles_recent_pop_norm(),
+                     m.ph_pop_recent_items_buffer: self.clicked_items_state.get_recent_clicks_buffer(),
+                     m.ph_content_article_embeddings_matrix: self.content_article_embeddings_matrix}
+        for name in self.articles_metadata:
+            if name in m.ph_articles_metadata:
+                feed_dict[m.ph_articles_metadata[name]] = self.articles_metadata[name]
+        return SessionRunArgs(fetches=fetches, feed_dict=feed_dict)
+
+    def after_run(self, run_context, run_values):
+        r = run_values.results
+        clicked_items = r['clicked_items']
+        clicked_timestamps = np.squeeze(r['clicked_timestamps'], axis=-1)
+        next_item_labels, last_item_label = r['next_item_labels'], r['last_item_label']
+        sessions_ids = r['session_id']
+        if self.mode == ModeKeys.EVAL:
+            predicted_item_ids = r['predicted_item_ids']
+            # TF streaming twins (sparse_recall_at_top_k, define_mrr_metric) from the device-side rank of the positive
+            rank = r['label_rank']
+            valid = rank >= 0
+            hit = valid & (rank < self.eval_metrics_top_n)
+            if 'hitrate_at_n' in self.eval_metric_ops:
+                self.eval_metric_ops['hitrate_at_n'].update(hit.sum(), valid.sum())
+            if 'mrr_at_n' in self.eval_metric_ops:
+                self.eval_metric_ops['mrr_at_n'].update((1.0 / (1.0 + rank[hit])).sum(), valid.sum())
+            self.eval_streaming_metrics_last = {k: v.result() for k, v in self.eval_metric_ops.items()}
+            if self.sessions_negative_items_log is not None:                   # :1530-1541
+                for session_id, labels, neg_items in zip(sessions_ids, next_item_labels, r['eval_batch_negative_items']):
+                    self.sessions_negative_items_log.append(
+                        {'session_id': str(session_id),
+                         'negative_items': [n for l, n in zip(labels.tolist(), neg_items.tolist()) if l != 0]})
+            if self.sessions_chameleon_recommendations_log is not None:        # :1544-1580
+                probs = r['predicted_item_probs'].round(decimals=7)
+                pop = self.clicked_items_state.get_articles_recent_pop_norm()
+                for session_id, labels, ids, pp in zip(sessions_ids, next_item_labels, predicted_item_ids, probs):
+                    keep = labels != 0
+                    self.sessions_chameleon_recommendations_log.append(
+                        {'session_id': str(session_id), 'next_click_labels': labels[keep].tolist(),
+                         'predicted_item_ids': ids[keep].tolist(), 'predicted_item_probs': pp[keep].tolist(),
+                         'predicted_item_norm_pop': pop[ids[keep]].round(decimals=7).tolist()})
+            self.stats_logs.append({'batch_items_count': r['batch_items_count'],
+                                    'batch_unique_items_count': r['batch_unique_items_count'],
+                                    'batch_sessions_count': len(sessions_ids)})
+            for metric in self.streaming_metrics:                              # evaluation.py:12-26 update_metrics
+                metric.add(predicted_item_ids, next_item_labels)
+            for metric in self.streaming_metrics:                              # evaluation.py:28-45
+                self.eval_streaming_metrics_last['{}_{}'.format(metric.name, 'chameleon')] = metric.result()
+        # state update, nar_model.py:1635-1649
+        from .clicked_items_state import batch_clicks_for_state
+        ids, ts = batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps)
+        self.clicked_items_state.update_items_state(ids, ts)
+
+    def end(self, session=None):
+        if self.mode == ModeKeys.EVAL:                                         # :1669-1695
+            self.eval_streaming_metrics_last['clicks_count'] = int(np.sum([x['batch_items_count'] for x in self.stats_logs]))
+            self.eval_streaming_metrics_last['sessions_count'] = int(np.sum([x['batch_sessions_count'] for x in self.stats_logs]))
+            self.eval_sessions_metrics_log.append(self.eval_streaming_metrics_last)
+            self.clicked_items_state.restore_state_checkpoint()

@@ -146,3 +146,35 @@ def default_params(n_items, ace_dim, seq_len=20, batch_size=256, neg=50, neg_fro
              content_article_embeddings_matrix=ace, truncate_session_length=seq_len)
     p.update(over)
     return p
+
+
+def write_dataset(out_dir, n_hours, sessions_per_hour, n_items, ace_dim, seq_len=20, seed=42, length_dist='g1',
+                  dataset='gcom'):
+    """Writes a synthetic G1-shaped dataset the trainer can consume unchanged: ``sessions_hour_NNN.tfrecord.gz`` (one GZIP
+    TFRecord file per hour) + the ACR-module resources ``articles_metadata.csv`` and
+    ``articles_embeddings.pickle`` (un-normalised ACE matrix; the trainer L2-normalises and scales it).
+    Returns (files, metadata_csv, embeddings_pickle)."""
+    import os
+    import pickle
+    from . import config, tf_records_management as tfm
+    os.makedirs(out_dir, exist_ok=True)
+    scfg = config.get_session_features_config_gcom(n_items) if dataset == 'gcom' else config.get_session_features_config_adressa(n_items)
+    cards = {'category_id': 461} if dataset == 'gcom' else {'category0': 41, 'category1': 128, 'author': 112}
+    ace, meta = make_catalog(n_items, ace_dim, seed, 1.0, cards)
+    rng = np.random.default_rng(seed + 1)
+    ace = ace * rng.uniform(0.5, 2.0, size=(n_items, 1)).astype(np.float32)         # rows are NOT unit length on disk
+    with open(os.path.join(out_dir, 'articles_embeddings.pickle'), 'wb') as fh:
+        pickle.dump(ace, fh)
+    cols = list(meta.keys())
+    with open(os.path.join(out_dir, 'articles_metadata.csv'), 'w') as fh:
+        fh.write(','.join(cols) + '\n')
+        for i in range(n_items):
+            fh.write(','.join(str(int(meta[c][i])) for c in cols) + '\n')
+    files, sid = [], 0
+    for hour in range(n_hours):
+        ss = make_sessions(sessions_per_hour, seq_len, n_items, scfg, seed, hour, length_dist, sid)
+        sid += len(ss)
+        path = os.path.join(out_dir, 'sessions_hour_%03d.tfrecord.gz' % hour)
+        tfm.save_rows_to_tf_record_file(ss, scfg, path)
+        files.append(path)
+    return files, os.path.join(out_dir, 'articles_metadata.csv'), os.path.join(out_dir, 'articles_embeddings.pickle')

@@ -96,6 +96,12 @@ int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float
 int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N,
                            float tau, float sum_mask, float* ds, float* dS3, void* stream);
 
+/* evaluation: rank_items_by_predicted_prob, nar_model.py:777-794 (tf.nn.top_k over 1+N: descending, lowest index wins
+ * ties).  pred_ids/pred_probs [BT, 1+N]; label_rank[bt] = 0-based rank of the positive, -1 for padded clicks - the input of
+ * HitRate@n / MRR@n (metrics.py:40-66, 109-134; TF twins nar_model.py:826-835, 859-885) */
+int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t* neg_ids, const uint8_t* mask, int BT, int N,
+                    int64_t* pred_ids, float* pred_probs, int32_t* label_rank, void* stream);
+
 /* --- K7 regularisation loss, loss finalisation, TF Adam, bias-gradient column sums: nar_model.py:655, 660-667, 708-722 */
 int cham_sumsq_partial(const float* params, size_t n_reg, float* partial, void* stream);
 int cham_loss_finalize(const float* nll, int BT, float sum_mask, const float* sumsq_partial, float lambda, float* loss,

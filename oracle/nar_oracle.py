@@ -208,14 +208,15 @@ class NAROracle:
         return torch.relu((ref_ts.to(torch.float32) - created.to(torch.float32)) / torch.tensor(MS_PER_DAY, dtype=torch.float32))
 
     # -- nar_model.py:1092-1131 + 1062-1089
-    def _recency(self, ids, ref_ts, buffer_ids):
+    def _recency(self, ids, ref_ts, buffer_ids, stats_ref_ts=None):
         created = self.meta['created_at_ts'][ids].unsqueeze(-1)
         x = self._log1p_base(self._elapsed_days(created, ref_ts), 1.3)
         last = self._last_buffer_items(buffer_ids)
         if last.numel() == 0:
             stats = x[(ids != 0)].reshape(-1)
         else:
-            stats = self._log1p_base(self._elapsed_days(self.meta['created_at_ts'][last], ref_ts.max()), 1.3)
+            stats = self._log1p_base(self._elapsed_days(self.meta['created_at_ts'][last],
+                                                        ref_ts.max() if stats_ref_ts is None else stats_ref_ts), 1.3)
         return self._normalize_values(x, stats)
 
     # -- nar_model.py:1134-1193
@@ -229,7 +230,7 @@ class NAROracle:
         return self._normalize_values(nov, stats)
 
     # -- nar_model.py:921-994
-    def _item_features(self, ids, ref_ts, buffer_ids, pop_norm):
+    def _item_features(self, ids, ref_ts, buffer_ids, pop_norm, stats_ref_ts=None):
         acfg = self.p['articles_features_config']
         feats = []
         meta_vals = {n: self.meta[n][ids] for n in acfg if n not in ARTICLE_REQ_FEATURES}
@@ -240,7 +241,7 @@ class NAROracle:
         if self.ifc['item_clicked_embeddings']:
             feats.append(self.w['items_embedding'][ids])
         if self.ifc['recency']:
-            feats.append(self._recency(ids, ref_ts, buffer_ids))
+            feats.append(self._recency(ids, ref_ts, buffer_ids, stats_ref_ts))
         if self.ifc['novelty']:
             feats.append(self._novelty(ids, buffer_ids, pop_norm))
         return torch.cat(feats, dim=-1)
@@ -304,7 +305,7 @@ class NAROracle:
         return tot
 
     # ------------------------------------------------------------------ forward (nar_model.py:210-704)
-    def forward(self, features, labels, buffer_ids, pop_norm, mode='train', neg_items=None, step=None):
+    def forward(self, features, labels, buffer_ids, pop_norm, mode='train', neg_items=None, step=None, global_max_ts=None):
         p = self.p
         train = (mode == 'train')
         N = p['train_total_negative_samples'] if train else p['eval_total_negative_samples']
@@ -316,6 +317,8 @@ class NAROracle:
         mask = torch.arange(T).unsqueeze(0) < seq_len.unsqueeze(1)                       # :231
         event_ts = torch.as_tensor(features['event_timestamp']).long().unsqueeze(-1)     # :233
         max_ts = event_ts.max()                                                           # :235
+        if global_max_ts is not None:      # data-parallel row shard: the scalar of the GLOBAL batch
+            max_ts = torch.as_tensor(int(global_max_ts))
         label_last = torch.as_tensor(labels['label_last_item']).long()
         label_next = torch.as_tensor(labels['label_next_item']).long()
         all_clicked = torch.cat([item_clicked, label_last], 1)                            # :241
@@ -334,7 +337,7 @@ class NAROracle:
         gamma, beta = self.w['gamma'], self.w['beta']
         # keep_prob == 1.0 (every shipped script) -> dropout is the identity (:338, 352, 368)
         assert p.get('dropout_keep_prob', 1.0) == 1.0 or not train, "oracle restates keep_prob=1.0 only"
-        x_in = torch.cat([ctx, self._item_features(item_clicked, event_ts, buffer_t, pop_t)], 2) * gamma + beta   # :328-333
+        x_in = torch.cat([ctx, self._item_features(item_clicked, event_ts, buffer_t, pop_t, max_ts if global_max_ts is not None else None)], 2) * gamma + beta   # :328-333
         x_pos = torch.cat([ctx, self._item_features(label_next, max_ts, buffer_t, pop_t)], 2) * gamma + beta     # :343-347
         ctx_tiled = ctx.unsqueeze(2).expand(B, T, neg.shape[2], ctx.shape[-1])                                     # :360
         x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364

@@ -1,0 +1,97 @@
+"""Data-parallel semantics on CPU with the gloo backend, world_size 2: row sharding, sampler keyed by the
+GLOBAL row, local losses divided by the GLOBAL sum(mask), gradients combined by ONE all-reduce(SUM) through
+chameleon_recsys_amd.nar.parallel - checked against the single-process oracle on the full batch.  (The compute of each
+shard is the CPU oracle here: the HIP step itself has no CPU path; its sharded launch parameters - row_begin, global
+denominators - are covered by tests/test_step_gpu.py::test_row_shards_sum_to_full_batch on the GPU.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chameleon_recsys_amd.nar import parallel, synthetic
+from tests import helpers as H
+
+
+def test_shard_rows_partition():
+    for n in (1, 7, 64, 255, 256):
+        for w in (1, 2, 3, 8):
+            spans = [parallel.shard_rows(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import sampler as S
+    from oracle.nar_oracle import NAROracle
+    p = H.tiny_params(C=32, H=24, neg=5, batch_size=16, buffer_size=300, for_norm=50, neg_from_buffer=30, n_items=200, ace_dim=8)
+    batches = synthetic.make_batches(3, 16, 8, 200, p['session_features_config'], seed=2, length_dist='g1')
+    st = H.warm_state(p, batches[:2])
+    f, l = batches[2]
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    orc = NAROracle(p, seed=5)
+    # ---- this rank's rows; negatives keyed by the global row index from the replicated global id tensor
+    b, e = parallel.shard_rows(16, rank, world)
+    fl, ll = parallel.slice_batch(f, l, b, e)
+    aci = np.concatenate([f['item_clicked'], l['label_last_item']], 1)
+    neg = S.batch_negative_samples(aci, buf, 5, 30, 42, 0, rows=range(b, e))
+    out = orc.forward(fl, ll, buf, pop, 'train', neg_items=neg, global_max_ts=int(np.asarray(f['event_timestamp']).max()))
+    # the oracle's forward normalises by the LOCAL sum(mask) and max timestamp: re-scale to the global denominator and check
+    # the global scalars are what every rank would compute from the replicated ints
+    g_mask = float(np.minimum(np.maximum(f['session_size'] - 1, 0), f['item_clicked'].shape[1]).sum())
+    l_mask = float(out['mask'].sum())
+    assert int(np.asarray(fl['event_timestamp']).max()) <= int(np.asarray(f['event_timestamp']).max())
+    xe_share = out['xe_loss'] * (l_mask / g_mask)
+    for v in orc.w.values():
+        v.grad = None
+    xe_share.backward()
+    names = list(orc.w.keys())
+    flat = torch.cat([(orc.w[k].grad if orc.w[k].grad is not None else torch.zeros_like(orc.w[k])).reshape(-1) for k in names])
+
+    class _RT:          # the two attributes DataParallelNAR touches
+        flat = torch.zeros(4)
+        dp_rank = dp_world = dp_allreduce = None
+
+    class _Model:
+        rt = _RT()
+        total_loss = torch.tensor([float(xe_share.detach()) + float(out['reg_loss'].detach()), float(xe_share.detach()), float(out['reg_loss'].detach())])
+    dp = parallel.DataParallelNAR(_Model())
+    assert (dp.rank, dp.world) == (rank, world) and _Model.rt.dp_allreduce is not None
+    _Model.rt.dp_allreduce(flat)                       # ONE all-reduce(SUM) of the flat gradient buffer
+    loss = dp.global_loss()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "dp.npz"), flat=flat.numpy(), loss=loss.numpy(), neg=neg)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(str(tmp_path / "dp.npz"))
+    torch.set_num_threads(1)
+    from oracle.nar_oracle import NAROracle
+    p = H.tiny_params(C=32, H=24, neg=5, batch_size=16, buffer_size=300, for_norm=50, neg_from_buffer=30, n_items=200, ace_dim=8)
+    batches = synthetic.make_batches(3, 16, 8, 200, p['session_features_config'], seed=2, length_dist='g1')
+    st = H.warm_state(p, batches[:2])
+    f, l = batches[2]
+    orc = NAROracle(p, seed=5)
+    out = orc.forward(f, l, st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm(), 'train')
+    assert np.array_equal(out['neg_items'].numpy()[:8], got['neg'])           # rank 0's rows of the global sample
+    out['xe_loss'].backward()
+    flat = torch.cat([(v.grad if v.grad is not None else torch.zeros_like(v)).reshape(-1) for v in orc.w.values()]).numpy()
+    scale = np.abs(flat).max()
+    assert np.abs(got['flat'] - flat).max() < 2e-5 * scale + 1e-7
+    assert abs(got['loss'][1] - float(out['xe_loss'])) < 1e-5 and abs(got['loss'][0] - float(out['total_loss'])) < 1e-5

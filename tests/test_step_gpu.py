@@ -113,3 +113,35 @@ def test_training_curve_matches_oracle(gpu):
     w_hip = model.rt.logical_weights()
     for k, v in orc.w.items():
         assert float(np.abs(w_hip[k] - v.detach().numpy()).max()) < 2.5 * p['lr'] * len(batches), k
+
+
+def test_row_shards_sum_to_full_batch(gpu):
+    """Data-parallel launch parameters: two row shards (row_begin, GLOBAL ids / denominators) reproduce the
+    full-batch negatives and logits, and their gradient buffers SUM to the full-batch gradient (what the RCCL all-reduce
+    computes)."""
+    from chameleon_recsys_amd.nar import parallel
+    p = H.tiny_params()
+    batches = synthetic.make_batches(4, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, _ = H.make_pair(p)
+    f, l = batches[3]
+    model.feed_state(st.get_articles_recent_pop_norm(), st.get_recent_clicks_buffer())
+    model.forward(model.upload_batch(f, l)); model.backward()
+    torch.cuda.synchronize()
+    full = model.outputs_numpy()
+    g_full = model.rt.grads.clone()
+    g_sum = torch.zeros_like(g_full)
+    xe, negs, logits = 0.0, [], []
+    for r in range(3):
+        b, e = parallel.shard_rows(64, r, 3)
+        fl, ll = parallel.slice_batch(f, l, b, e)
+        model.forward(model.upload_batch(fl, ll, f, l, row_begin=b)); model.backward()
+        torch.cuda.synchronize()
+        out = model.outputs_numpy()
+        g_sum += model.rt.grads
+        xe += out['loss'][1]; negs.append(out['neg_items']); logits.append(out['logits'])
+    assert np.array_equal(np.concatenate(negs), full['neg_items'])
+    assert np.abs(np.concatenate(logits) - full['logits']).max() < 1e-5
+    assert abs(xe - full['loss'][1]) < 1e-5
+    scale = float(g_full.abs().max())
+    assert float((g_sum - g_full).abs().max()) < 2e-5 * scale + 1e-7
