@@ -3,14 +3,20 @@
 //   C[M,N] (+)= epi( op(A)[M,K] * op(B)[K,N] )
 //
 // Replaces the tf.layers.Dense / tf.matmul clusters of nar_module/nar/nar_model.py:374-405 (CAR),
-// :410-426 (session FCs), :447-500 (scorer), the UGRNN input projection (:1308-1361) and all of their
+// :410-426 (session FCs), :447-500 (scorer), the RNN input projection (:1308-1361) and all of their
 // autodiff twins (dgrad = NT, wgrad = TN + split-K).
 //
 // Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cyc/SIMD, 157.3 TFLOP/s chip peak).  Operand
 // fragments are one f32 VGPR per lane: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]
-// (cdna_hip_programming.md §3), so both LDS tiles are stored k-major with the free index contiguous:
+// (cdna_hip_programming.md section 3), so both LDS tiles are stored k-major with the free index contiguous:
 // every ds_read_b32 of a fragment is 32 consecutive dwords per half-wave = conflict free.
 //
+//   * ALL global traffic goes through buffer descriptors (buffer_load/store_dword[x4] ... offen) whose base is
+//     the workgroup's tile window (wave-uniform, advanced along K with scalar adds): ragged edges are handled
+//     by steering the 32-bit offset of an out-of-range element to an out-of-window sentinel - the hardware
+//     returns 0 / drops the store.  No divergent branch around any memory operation: the loads of K-tile t+1
+//     stay in flight behind the MFMAs of tile t (with `if (ok) load` hipcc drained vmcnt(0) right after every
+//     load and exposed the full L2/HBM latency once per K-tile).
 //   * operand stored with the REDUCTION index contiguous (XK=true; A of NN/NT, B of NT): float4 global
 //     reads along k, transposed on the LDS write (4 x ds_write_b32, row stride BF+pad chosen so the
 //     writes of a half-wave hit distinct banks).
@@ -22,9 +28,20 @@
 //     on the same XCD; bijective form for any grid size.
 //   * prologue: optional row-broadcast scale of A (the "candidate (.) predicted-embedding" product of
 //     nar_model.py:478-495 fused into the scorer's first layer and its wgrad).
-//   * epilogue: bias + {none, leaky_relu(0.2), tanh}; or multiply by act'(saved output) for dgrad;
-//     optional accumulate.  Split-K (grid.y) writes raw partials, reduced in fixed order (deterministic).
+//   * epilogue (compile-time specialised): bias + {none, leaky_relu(0.2), tanh}; or multiply by act'(saved output)
+//     for dgrad; optional accumulate.  Split-K (grid.y) writes raw partials, reduced in fixed order (deterministic).
 #include "common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF 0x80000000u          // > every window size below: loads return 0, stores are dropped
+#define WINDOW_BYTES 0x7FFFF000
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_window(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, WINDOW_BYTES, 0x00020000);
+}
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 struct GemmParams {
     const float* A; const float* B; float* C;
@@ -37,43 +54,73 @@ struct GemmParams {
     int nbm, nbn;
 };
 
+// One operand tile [BF x BK].  Offsets are tile-window-local bytes, computed once; per K tile only the k-validity
+// select and the loads remain.
 template <int BF, int BK, bool XK, int NTH>
 struct TileLoader {
     static constexpr int NF4 = BF * BK / 4;               // float4 in the tile
     static constexpr int NV = (NF4 + NTH - 1) / NTH;      // float4 per thread
     static constexpr int LD = XK ? (BF + (BK == 16 ? 2 : 1)) : (BF + 4);
-    float4 r[NV];
-    float4 sc[NV];                                        // row-broadcast scale (multiplied at store time)
+    u32x4 r[NV];
+    u32x4 sc[NV];                                         // row-broadcast scale (multiplied at store time)
+    unsigned off[NV];                                     // window-local byte offset (OOB_OFF when the free index is out of range)
+    unsigned soff[NV];                                    // scale offset (XK only: affine in k0 -> soffset)
+    int kidx[NV];                                         // tile-local k of this float4
 
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int f0, int F, int k0, int kend,
-                                         const float* __restrict__ rs, int ldrs, int rs_div) {
+    __device__ __forceinline__ void init(int ld, int limF, int f0, int ldrs, int rs_div, bool has_rs) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * NTH;
-            int srow, scol;   // stored row / col of this float4
-            bool ok;
-            if (NF4 % NTH != 0 && idx >= NF4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            unsigned o; int kk; bool fok;
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
-                srow = f0 + fr; scol = k0 + kq * 4;
-                ok = (srow < F) && (scol < kend);
+                o = ((unsigned)fr * (unsigned)ld + (unsigned)kq * 4u) * 4u; kk = kq * 4; fok = fr < limF;
+                soff[i] = has_rs ? ((unsigned)((f0 + fr) / rs_div) * (unsigned)ldrs + (unsigned)kq * 4u) * 4u : 0u;
             } else {
-                const int kk = idx / (BF / 4), f4 = idx % (BF / 4);
-                srow = k0 + kk; scol = f0 + f4 * 4;
-                ok = (srow < kend) && (scol < F);
+                const int k = idx / (BF / 4), f4 = idx % (BF / 4);
+                o = ((unsigned)k * (unsigned)ld + (unsigned)f4 * 4u) * 4u; kk = k; fok = f4 * 4 < limF;
+                soff[i] = 0u;
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(base + (size_t)srow * ld + scol);
-                if (rs) sc[i] = *reinterpret_cast<const float4*>(rs + (size_t)(srow / rs_div) * ldrs + scol);
-            }
-            r[i] = v;
+            if (NF4 % NTH != 0 && idx >= NF4) fok = false;
+            off[i] = fok ? o : OOB_OFF;
+            kidx[i] = kk;
+        }
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t win, int limK) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned o = kidx[i] < limK ? off[i] : OOB_OFF;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(win, o, 0, 0);
+        }
+    }
+    // XK operand (A of NN): scale[(row / rs_div), k] - rows fixed per thread, k advances with the tile (soffset)
+    __device__ __forceinline__ void load_scale_xk(__amdgpu_buffer_rsrc_t rsw, int k0, int limK) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned o = (kidx[i] < limK && off[i] != OOB_OFF) ? soff[i] : OOB_OFF;
+            sc[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o, k0 * 4, 0);
+        }
+    }
+    // non-XK operand (A of TN, stored [K rows, M cols]): scale[((k0+kk) / rs_div), f0 + col]
+    __device__ __forceinline__ void load_scale_fk(__amdgpu_buffer_rsrc_t rsw, int krow0, int f0, int ldrs, int rs_div, int limK) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NTH;
+            const int f4 = idx % (BF / 4);
+            const unsigned o = ((unsigned)((krow0 + kidx[i]) / rs_div) * (unsigned)ldrs + (unsigned)(f0 + f4 * 4)) * 4u;
+            sc[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (kidx[i] < limK && off[i] != OOB_OFF) ? o : OOB_OFF, 0, 0);
         }
     }
     __device__ __forceinline__ void apply_scale() {      // after the loads have landed, just before the LDS store
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { r[i].x *= sc[i].x; r[i].y *= sc[i].y; r[i].z *= sc[i].z; r[i].w *= sc[i].w; }
+        for (int i = 0; i < NV; ++i) {
+            r[i].x = __float_as_uint(__uint_as_float(r[i].x) * __uint_as_float(sc[i].x));
+            r[i].y = __float_as_uint(__uint_as_float(r[i].y) * __uint_as_float(sc[i].y));
+            r[i].z = __float_as_uint(__uint_as_float(r[i].z) * __uint_as_float(sc[i].z));
+            r[i].w = __float_as_uint(__uint_as_float(r[i].w) * __uint_as_float(sc[i].w));
+        }
     }
     __device__ __forceinline__ void store(float* __restrict__ S) const {
         const int tid = threadIdx.x;
@@ -84,16 +131,30 @@ struct TileLoader {
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
                 float* d = S + (kq * 4) * LD + fr;
-                d[0] = r[i].x; d[LD] = r[i].y; d[2 * LD] = r[i].z; d[3 * LD] = r[i].w;
+                d[0] = __uint_as_float(r[i].x); d[LD] = __uint_as_float(r[i].y);
+                d[2 * LD] = __uint_as_float(r[i].z); d[3 * LD] = __uint_as_float(r[i].w);
             } else {
                 const int kk = idx / (BF / 4), f4 = idx % (BF / 4);
-                *reinterpret_cast<float4*>(S + kk * LD + f4 * 4) = r[i];
+                *reinterpret_cast<float4*>(S + kk * LD + f4 * 4) = as_f4(r[i]);
             }
         }
     }
 };
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
+template <int ACT> __device__ __forceinline__ float act_fwd_c(float v) {
+    if (ACT == ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    if (ACT == ACT_TANH) return tanhf(v);
+    return v;
+}
+template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
+    if (ACT == ACT_LEAKY) return y > 0.f ? 1.f : 0.2f;
+    if (ACT == ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// EPI: 0 = plain / accumulate (no bias, no act), 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref),
+//      5 = bias only, 6 = split-K partial store
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
     using LA = TileLoader<BM, BK, AK, NTH>;
@@ -104,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     float* As = smem;                 // [2][BK][LDA]
     float* Bs = smem + 2 * ASZ;       // [2][BK][LDB]   (2*ASZ*4 bytes is a multiple of 16 for every instance)
 
-    // ---- XCD-aware, bijective tile mapping -------------------------------------------------------
+    // ---- XCD-aware, bijective tile mapping (all scalar) --------------------------------------------
     const int nwg = p.nbm * p.nbn;
     const int id = blockIdx.x;
     const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
@@ -126,12 +187,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // tile windows: byte pointers advanced along K by scalar adds
+    const char* aw = reinterpret_cast<const char*>(p.A) + (AK ? ((size_t)m0 * p.lda + kbeg) : ((size_t)kbeg * p.lda + m0)) * 4;
+    const char* bw = reinterpret_cast<const char*>(p.B) + (BKC ? ((size_t)n0 * p.ldb + kbeg) : ((size_t)kbeg * p.ldb + n0)) * 4;
+    const size_t astep = (AK ? (size_t)BK : (size_t)BK * p.lda) * 4, bstep = (BKC ? (size_t)BK : (size_t)BK * p.ldb) * 4;
+    const bool has_rs = p.rs != nullptr;
+    const __amdgpu_buffer_rsrc_t rsw = make_window(p.rs);
+
     LA la; LB lb;
+    la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, has_rs);
+    lb.init(p.ldb, p.N - n0, n0, 0, 1, false);
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        la.load(p.A, p.lda, m0, p.M, kbeg, kend, p.rs, p.ldrs, p.rs_div);
-        lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, nullptr, 0, 1);
-        if (p.rs) la.apply_scale();
+        la.load(make_window(aw), kend - kbeg);
+        lb.load(make_window(bw), kend - kbeg);
+        if (has_rs) {
+            if (AK) la.load_scale_xk(rsw, kbeg, kend - kbeg);
+            else la.load_scale_fk(rsw, kbeg, m0, p.ldrs, p.rs_div, kend - kbeg);
+            la.apply_scale();
+        }
         la.store(As); lb.store(Bs);
     }
     __syncthreads();
@@ -140,8 +214,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             const int k0 = kbeg + (kt + 1) * BK;
-            la.load(p.A, p.lda, m0, p.M, k0, kend, p.rs, p.ldrs, p.rs_div);
-            lb.load(p.B, p.ldb, n0, p.N, k0, kend, nullptr, 0, 1);
+            aw += astep; bw += bstep;
+            la.load(make_window(aw), kend - k0);
+            lb.load(make_window(bw), kend - k0);
+            if (has_rs) {
+                if (AK) la.load_scale_xk(rsw, k0, kend - k0);
+                else la.load_scale_fk(rsw, k0, m0, p.ldrs, p.rs_div, kend - k0);
+            }
         }
         const float* Ac = As + cur * ASZ + wm0 + fl;
         const float* Bc = Bs + cur * BSZ + wn0 + fl;
@@ -167,7 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            if (p.rs) la.apply_scale();
+            if (has_rs) la.apply_scale();
             la.store(As + (cur ^ 1) * ASZ);
             lb.store(Bs + (cur ^ 1) * BSZ);
         }
@@ -175,31 +254,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     }
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
+    // windows at the tile origin; offsets are tile-local, out-of-range elements get OOB_OFF
+    const int limM = p.M - m0, limN = p.N - n0;
+    float* cbase = (EPI == 6) ? p.partial + ((size_t)split * p.M + m0) * p.N + n0 : p.C + (size_t)m0 * p.ldc + n0;
+    const unsigned ldc = (EPI == 6) ? (unsigned)p.N : (unsigned)p.ldc;
+    const __amdgpu_buffer_rsrc_t cw = make_window(cbase);
+    const __amdgpu_buffer_rsrc_t dw = make_window((EPI == 3 || EPI == 4) ? p.dref + (size_t)m0 * p.ldr + n0 : p.C);
+    const __amdgpu_buffer_rsrc_t biasw = make_window((EPI == 1 || EPI == 2 || EPI == 5) ? p.bias + n0 : p.C);
+    const bool accum = (EPI == 0 || EPI == 3 || EPI == 4) && p.accumulate;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn0 + j * 32 + fl;
-            if (col >= p.N) continue;
-            const float bv = (p.bias != nullptr && p.splits == 1) ? p.bias[col] : 0.f;
+            const int col = wn0 + j * 32 + fl;
+            const bool cok = col < limN;
+            float bv = 0.f;
+            if (EPI == 1 || EPI == 2 || EPI == 5)
+                bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(biasw, cok ? (unsigned)col * 4u : OOB_OFF, 0, 0));
+            unsigned offs[16];
+            float aux[16], old[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
-                if (row >= p.M) continue;
+                const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const bool ok = cok && row < limM;
+                offs[e] = ok ? ((unsigned)row * ldc + (unsigned)col) * 4u : OOB_OFF;
+                if (EPI == 3 || EPI == 4)
+                    aux[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 4u : OOB_OFF, 0, 0));
+                if (EPI == 0 || EPI == 3 || EPI == 4)
+                    old[e] = accum ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cw, offs[e], 0, 0)) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e];
-                if (p.splits > 1) {
-                    p.partial[((size_t)split * p.M + row) * p.N + col] = v;
-                } else {
-                    v = act_fwd(v + bv, p.act);
-                    if (p.dref) v *= act_bwd_from_out(p.dref[(size_t)row * p.ldr + col], p.dact);
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    *c = p.accumulate ? (*c + v) : v;
-                }
+                if (EPI == 1) v = act_fwd_c<ACT_LEAKY>(v + bv);
+                else if (EPI == 2) v = act_fwd_c<ACT_TANH>(v + bv);
+                else if (EPI == 5) v = v + bv;
+                else if (EPI == 3) v = v * act_bwd_c<ACT_LEAKY>(aux[e]) + old[e];
+                else if (EPI == 4) v = v * act_bwd_c<ACT_TANH>(aux[e]) + old[e];
+                else if (EPI == 0) v += old[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
             }
         }
 }
 
-// fixed-order reduction of split-K partials (+ the same epilogue)
+// fixed-order reduction of split-K partials (+ the generic epilogue)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
     const size_t n = (size_t)p.M * p.N;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -214,14 +313,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
-static int launch_cfg(GemmParams& p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
+static int launch_epi(GemmParams& p, hipStream_t st) {
     using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
     using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
     const size_t smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
-    p.nbm = (p.M + BM - 1) / BM;
-    p.nbn = (p.N + BN - 1) / BN;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -231,14 +328,37 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
+static int launch_cfg(GemmParams& p, hipStream_t st) {
+    p.nbm = (p.M + BM - 1) / BM;
+    p.nbn = (p.N + BN - 1) / BN;
+    int rc;
     if (p.splits > 1) {
+        rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
+        if (rc != CHAM_OK) return rc;
         const size_t n = (size_t)p.M * p.N;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
         CHAM_CHECK_LAUNCH();
+        return CHAM_OK;
     }
-    return CHAM_OK;
+    if (p.dref) {
+        if (p.bias || p.act != ACT_NONE) return -CHAM_ERR_ARG;
+        if (p.dact == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3>(p, st);
+        if (p.dact == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4>(p, st);
+        return -CHAM_ERR_ARG;
+    }
+    if (p.bias || p.act != ACT_NONE) {
+        if (!p.bias || p.accumulate) return -CHAM_ERR_ARG;       // every activated layer of the model has a bias
+        if (p.act == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1>(p, st);
+        if (p.act == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2>(p, st);
+        return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5>(p, st);
+    }
+    return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0>(p, st);
 }
 
 static int g_variant = -1;     // -1 = automatic
@@ -247,15 +367,14 @@ extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
 template <bool AK, bool BKC>
 static int launch_by_shape(GemmParams& p, hipStream_t st) {
     if (p.N > 64) {
-        // default: 256x128 tile / 8 waves for large outputs (best on MI355X: 113-117 TFLOP/s on the CAR shapes),
-        // 128x128 / 4 waves when the grid would otherwise be too small to fill 256 CUs
+        // default: 256x128 tile / 8 waves for large outputs, 128x128 / 4 waves when the grid would otherwise be too
+        // small to fill 256 CUs
         const int v = g_variant >= 0 ? g_variant : (((long)p.M * p.N >= (1L << 20)) ? 2 : 0);
         switch (v) {
             case 1: return launch_cfg<128, 128, 2, 2, 32, AK, BKC>(p, st);
             case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
-            case 3: return launch_cfg<128, 256, 2, 2, 16, AK, BKC>(p, st);
+            case 3: return launch_cfg<256, 128, 4, 2, 32, AK, BKC>(p, st);
             case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
-            case 5: return launch_cfg<256, 128, 2, 2, 16, AK, BKC>(p, st);
             default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
         }
     }
@@ -278,6 +397,11 @@ extern "C" int cham_gemm_f32(const float* A, int lda, int transA, const float* B
     if (!transB && (N & 3)) return -CHAM_ERR_ARG;        // B[K,N] row-major
     if (transB && (K & 3)) return -CHAM_ERR_ARG;         // B stored [N,K]
     if (rowscale && ((ldrs & 3) || rs_div <= 0)) return -CHAM_ERR_ARG;
+    // tile windows address 2^31 bytes with 32-bit offsets: a 256-row (or 32-k-row) slab of any operand must fit
+    if ((size_t)lda * 4 * 256 >= WINDOW_BYTES || (size_t)ldb * 4 * 256 >= WINDOW_BYTES || (size_t)ldc * 4 * 256 >= WINDOW_BYTES ||
+        (size_t)ldr * 4 * 256 >= WINDOW_BYTES)
+        return -CHAM_ERR_ARG;
+    if (rowscale && (size_t)((transA ? K : M) / (rs_div > 0 ? rs_div : 1) + 1) * ldrs * 4 >= WINDOW_BYTES) return -CHAM_ERR_ARG;
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.act = act; p.dref = dref; p.ldr = ldr; p.dact = dact;
@@ -297,8 +421,8 @@ extern "C" int cham_gemm_f32(const float* A, int lda, int transA, const float* B
     }
     p.splits = splits;
     int kchunk = (K + splits - 1) / splits;
-    kchunk = ((kchunk + 15) / 16) * 16;                  // multiple of BK
-    if (kchunk == 0) kchunk = 16;
+    kchunk = ((kchunk + 31) / 32) * 32;                  // multiple of every BK
+    if (kchunk == 0) kchunk = 32;
     p.kchunk = kchunk;
     p.splits = (K + kchunk - 1) / kchunk;
     if (p.splits < 1) p.splits = 1;

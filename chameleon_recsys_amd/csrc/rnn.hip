@@ -1,4 +1,4 @@
-// Recurrent session encoder time-step kernels (UGRNN = the reference's cell; GRU selectable).
+// Recurrent session encoder time-step kernels (UGRNN = the reference's cell; GRU selectable: cell_kind 1).
 //
 // Replaces nar_module/nar/nar_model.py:1308-1361: MultiRNNCell([DropoutWrapper(UGRNNCell(H))]) unrolled by
 // tf.nn.dynamic_rnn(sequence_length).  UGRNN step (tf.contrib.rnn.UGRNNCell, TF r1.12):
@@ -148,6 +148,226 @@ __global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dou
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// GRU (tf.nn.rnn_cell.GRUCell, TF r1.12; BASELINE config 4 / north-star "stacked GRU"):
+//     [r, u] = sigmoid([x, h] W_g + b_g) ;  c = tanh([x, r*h] W_c + b_c) ;  h' = u*h + (1-u)*c
+// xproj [B,T,3Hp] = x W_x + b with column blocks r | u | c;  Wh = W_gh [Hp,2Hp] followed by W_ch [Hp,Hp].
+// Same ownership as the UGRNN kernel (one workgroup = 32 sessions, all time steps, h in LDS); the candidate needs
+// r*h of ALL hidden units, so a step is two MFMA phases with an LDS exchange of r*h in between.
+template <int NT>
+__global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
+                                                 const int* __restrict__ seq_len, int B, int T,
+                                                 float* __restrict__ out, float* __restrict__ hprev, float* __restrict__ U,
+                                                 float* __restrict__ Cc, float* __restrict__ R, float* __restrict__ RH) {
+    constexpr int Hp = 128 * NT, LDH = Hp + 1, H2 = 2 * Hp, H3 = 3 * Hp;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hL = sm;                    // [32][LDH]  h_{t-1}
+    float* rhL = sm + 32 * LDH;        // [32][LDH]  r * h_{t-1}
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 32;
+    const int fl = lane & 31, kl = lane >> 5;
+    const float* Wgh = Wh;
+    const float* Wch = Wh + (size_t)Hp * H2;
+    for (int i = threadIdx.x; i < 64 * LDH; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int hid0 = wave * (Hp / 4);
+    for (int t = 0; t < T; ++t) {
+        floatx16 ar[NT], au[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ar[j][e] = 0.f; au[j][e] = 0.f; }
+        {
+            const float* hrow = hL + fl * LDH + kl;
+            const float* wg = Wgh + (size_t)kl * H2 + hid0 + fl;
+#pragma unroll 8
+            for (int k = 0; k < Hp; k += 2) {
+                const float a = hrow[k];
+                const float* w = wg + (size_t)k * H2;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    ar[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ar[j], 0, 0, 0);
+                    au[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], au[j], 0, 0, 0);
+                }
+            }
+        }
+        // gates; r*h -> LDS (each wave writes its own hidden columns of rhL; hL is only read here)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                float r = 0.f, u = 0.f;
+                if (b < B) {
+                    const size_t bt = (size_t)b * T + t;
+                    r = sigmoidf_(ar[j][e] + xproj[bt * H3 + hid]);
+                    u = sigmoidf_(au[j][e] + xproj[bt * H3 + Hp + hid]);
+                }
+                ar[j][e] = r; au[j][e] = u;
+                rhL[row * LDH + hid] = r * hL[row * LDH + hid];
+            }
+        }
+        __syncthreads();
+        floatx16 ac[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ac[j][e] = 0.f;
+        {
+            const float* rrow = rhL + fl * LDH + kl;
+            const float* wc = Wch + (size_t)kl * Hp + hid0 + fl;
+#pragma unroll 8
+            for (int k = 0; k < Hp; k += 2) {
+                const float a = rrow[k];
+                const float* w = wc + (size_t)k * Hp;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ac[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // all reads of hL / rhL of this step are done
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                if (b >= B) continue;
+                const size_t bt = (size_t)b * T + t;
+                const float c = tanhf(ac[j][e] + xproj[bt * H3 + H2 + hid]);
+                const float ho = hL[row * LDH + hid];
+                const float r = ar[j][e], u = au[j][e];
+                const float hn = u * ho + (1.f - u) * c;
+                const bool valid = t < seq_len[b];
+                const size_t o = bt * Hp + hid;
+                out[o] = valid ? hn : 0.f;
+                hprev[o] = ho; U[o] = u; Cc[o] = c; R[o] = r; RH[o] = r * ho;
+                if (valid) hL[row * LDH + hid] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// WhT = [ transpose(W_gh) [2Hp,Hp] ; transpose(W_ch) [Hp,Hp] ].  dxproj [B,T,3Hp] = dL/d[r_act, u_act, c_act].
+template <int NT>
+__global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
+                                                 const int* __restrict__ seq_len, int B, int T,
+                                                 const float* __restrict__ hprev, const float* __restrict__ U,
+                                                 const float* __restrict__ Cc, const float* __restrict__ R,
+                                                 float* __restrict__ dxproj) {
+    constexpr int Hp = 128 * NT, H2 = 2 * Hp, H3 = 3 * Hp, LDZ = H2 + 1, LDC = Hp + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dzL = sm;                   // [32][LDZ]  dz_r | dz_u
+    float* dcL = sm + 32 * LDZ;        // [32][LDC]  dz_c
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 32;
+    const int fl = lane & 31, kl = lane >> 5;
+    const int hid0 = wave * (Hp / 4);
+    const float* WghT = WhT;
+    const float* WchT = WhT + (size_t)H2 * Hp;
+    floatx16 carry[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) carry[j][e] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        floatx16 direct[NT], duz[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                float dzc = 0.f, dzu = 0.f, dd = 0.f;
+                if (b < B && t < seq_len[b]) {
+                    const size_t o = ((size_t)b * T + t) * Hp + hid;
+                    const float dh = dout[o] + carry[j][e];
+                    const float u = U[o], c = Cc[o], hp = hprev[o];
+                    dzu = dh * (hp - c) * u * (1.f - u);
+                    dzc = dh * (1.f - u) * (1.f - c * c);
+                    dd = dh * u;
+                }
+                direct[j][e] = dd; duz[j][e] = dzu;
+                dcL[row * LDC + hid] = dzc;
+                if (b < B) dxproj[((size_t)b * T + t) * H3 + H2 + hid] = dzc;
+            }
+        }
+        __syncthreads();
+        // d(r*h) = dz_c * W_ch^T
+        floatx16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        {
+            const float* zrow = dcL + fl * LDC + kl;
+            const float* wt = WchT + (size_t)kl * Hp + hid0 + fl;
+#pragma unroll 8
+            for (int k = 0; k < Hp; k += 2) {
+                const float a = zrow[k];
+                const float* w = wt + (size_t)k * Hp;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int hid = hid0 + j * 32 + fl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                float dzr = 0.f;
+                if (b < B && t < seq_len[b]) {
+                    const size_t o = ((size_t)b * T + t) * Hp + hid;
+                    const float r = R[o], hp = hprev[o], drh = acc[j][e];
+                    dzr = drh * hp * r * (1.f - r);
+                    direct[j][e] += drh * r;
+                }
+                dzL[row * LDZ + hid] = dzr;
+                dzL[row * LDZ + Hp + hid] = duz[j][e];
+                if (b < B) {
+                    const size_t o2 = ((size_t)b * T + t) * H3;
+                    dxproj[o2 + hid] = dzr;
+                    dxproj[o2 + Hp + hid] = duz[j][e];
+                }
+            }
+        }
+        __syncthreads();
+        // dh_{t-1} += [dz_r, dz_u] * W_gh^T
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        {
+            const float* zrow = dzL + fl * LDZ + kl;
+            const float* wt = WghT + (size_t)kl * Hp + hid0 + fl;
+#pragma unroll 8
+            for (int k = 0; k < H2; k += 2) {
+                const float a = zrow[k];
+                const float* w = wt + (size_t)k * Hp;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int b = b0 + row;
+                const bool valid = (b < B) && (t < seq_len[b]);
+                carry[j][e] = valid ? (direct[j][e] + acc[j][e]) : carry[j][e];
+            }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ outp) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -197,12 +417,46 @@ static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_
     return CHAM_OK;
 }
 
+template <int NT>
+static int launch_gru_fwd(const float* xproj, const float* Wh, const int* seq_len, int B, int T, float* out, float* hprev,
+                          float* U, float* Cc, float* R, float* RH, hipStream_t st) {
+    size_t smem = (size_t)64 * (128 * NT + 1) * sizeof(float);
+    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
+    auto kern = k_gru_fwd<NT>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, U, Cc, R, RH);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+template <int NT>
+static int launch_gru_bwd(const float* dout, const float* WhT, const int* seq_len, int B, int T, const float* hprev,
+                          const float* U, const float* Cc, const float* R, float* dxproj, hipStream_t st) {
+    size_t smem = (size_t)32 * (384 * NT + 2) * sizeof(float);
+    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
+    auto kern = k_gru_bwd<NT>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, dout, WhT, seq_len, B, T, hprev, U, Cc, R, dxproj);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
 // cell_kind: 0 = UGRNN
 extern "C" int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp,
-                            float* out, float* hprev, float* G, float* Cc, void* stream) {
+                            float* out, float* hprev, float* G, float* Cc, float* R, float* RH, void* stream) {
     if (!xproj || !Wh || !seq_len || !out || !hprev || !G || !Cc || B <= 0 || T <= 0) return -CHAM_ERR_ARG;
-    if (cell_kind != 0) return -CHAM_ERR_ARG;
+    if (cell_kind != 0 && cell_kind != 1) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (cell_kind == 1) {
+        if (!R || !RH) return -CHAM_ERR_ARG;
+        switch (Hp) {
+            case 128: return launch_gru_fwd<1>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, R, RH, st);
+            case 256: return launch_gru_fwd<2>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, R, RH, st);
+            case 384: return launch_gru_fwd<3>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, R, RH, st);
+            default: return -CHAM_ERR_ARG;
+        }
+    }
     switch (Hp) {
         case 128: return launch_ugrnn_fwd<1>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
         case 256: return launch_ugrnn_fwd<2>(xproj, Wh, seq_len, B, T, out, hprev, G, Cc, st);
@@ -213,10 +467,19 @@ extern "C" int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, 
 }
 
 extern "C" int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
-                            const float* hprev, const float* G, const float* Cc, float* dxproj, void* stream) {
+                            const float* hprev, const float* G, const float* Cc, const float* R, float* dxproj, void* stream) {
     if (!dout || !WhT || !seq_len || !hprev || !G || !Cc || !dxproj || B <= 0 || T <= 0) return -CHAM_ERR_ARG;
-    if (cell_kind != 0) return -CHAM_ERR_ARG;
+    if (cell_kind != 0 && cell_kind != 1) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (cell_kind == 1) {
+        if (!R) return -CHAM_ERR_ARG;
+        switch (Hp) {
+            case 128: return launch_gru_bwd<1>(dout, WhT, seq_len, B, T, hprev, G, Cc, R, dxproj, st);
+            case 256: return launch_gru_bwd<2>(dout, WhT, seq_len, B, T, hprev, G, Cc, R, dxproj, st);
+            case 384: return launch_gru_bwd<3>(dout, WhT, seq_len, B, T, hprev, G, Cc, R, dxproj, st);
+            default: return -CHAM_ERR_ARG;
+        }
+    }
     switch (Hp) {
         case 128: return launch_ugrnn_bwd<1>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);
         case 256: return launch_ugrnn_bwd<2>(dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj, st);

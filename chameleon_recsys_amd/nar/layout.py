@@ -56,8 +56,11 @@ class ParamLayout:
             raise ValueError("rnn_units > 512 is not supported by the recurrent kernel")
         self.L = rnn_num_layers
         self.cell = rnn_cell
-        if rnn_cell != 'ugrnn':
-            raise NotImplementedError("rnn_cell=%r: only the reference's UGRNN cell is implemented in this build" % rnn_cell)
+        if rnn_cell not in ('ugrnn', 'gru'):
+            raise ValueError("rnn_cell=%r: 'ugrnn' (the reference's cell, nar_model.py:1317) or 'gru'" % rnn_cell)
+        if rnn_cell == 'gru' and Hp > 384:
+            raise ValueError("rnn_units > 384 is not supported by the GRU recurrent kernel (LDS budget)")
+        self.NG = 2 if rnn_cell == 'ugrnn' else 3          # gate/candidate column blocks of the input projection
         self.n_items = n_items
         self.D = ace_dim
         scfg = session_features_config['sequence_features']
@@ -138,8 +141,10 @@ class ParamLayout:
         ents += [Entry('b1', (C,), False, 'zeros'), Entry('b2', (C,), False, 'zeros')]
         for l in range(self.L):
             Ip = C if l == 0 else Hp
-            ents += [Entry('rnn%d/Wx' % l, (Ip, 2 * Hp), False, 'pad'), Entry('rnn%d/Wh' % l, (Hp, 2 * Hp), False, 'pad'),
-                     Entry('rnn%d/b' % l, (2 * Hp,), False, 'zeros')]
+            ents += [Entry('rnn%d/Wx' % l, (Ip, self.NG * Hp), False, 'pad'), Entry('rnn%d/Wh' % l, (Hp, 2 * Hp), False, 'pad')]
+            if rnn_cell == 'gru':    # W_ch directly behind W_gh: the recurrent kernel takes ONE pointer (chameleon_nar.h)
+                ents.append(Entry('rnn%d/Wch' % l, (Hp, Hp), False, 'pad'))
+            ents.append(Entry('rnn%d/b' % l, (self.NG * Hp,), False, 'zeros'))
         ents += [Entry('bf1', (512,), False, 'zeros'), Entry('bf2', (C,), False, 'zeros'), Entry('bs1', (128,), False, 'zeros'),
                  Entry('bs2', (64,), False, 'zeros'), Entry('bs3', (32,), False, 'zeros'), Entry('bs4', (1,), False, 'zeros')]
         off = 0
@@ -188,8 +193,14 @@ class ParamLayout:
         specs['CAR/bias'] = ((C,), 'zeros', False)
         for l in range(self.L):
             I = C if l == 0 else H
-            specs['rnn/%d/kernel' % l] = ((I + H, 2 * H), 'xavier', False)
-            specs['rnn/%d/bias' % l] = ((2 * H,), 'zeros', False)
+            if self.cell == 'ugrnn':
+                specs['rnn/%d/kernel' % l] = ((I + H, 2 * H), 'xavier', False)
+                specs['rnn/%d/bias' % l] = ((2 * H,), 'zeros', False)
+            else:     # tf.nn.rnn_cell.GRUCell variables: gates (bias init 1.0) and candidate
+                specs['rnn/%d/gates/kernel' % l] = ((I + H, 2 * H), 'xavier', False)
+                specs['rnn/%d/gates/bias' % l] = ((2 * H,), 'ones', False)
+                specs['rnn/%d/candidate/kernel' % l] = ((I + H, H), 'xavier', False)
+                specs['rnn/%d/candidate/bias' % l] = ((H,), 'zeros', False)
         specs['FC1/kernel'] = ((H, 512), 'variance_scaling', True)
         specs['FC1/bias'] = ((512,), 'zeros', False)
         specs['FC2/kernel'] = ((512, C), 'xavier', True)
@@ -251,8 +262,15 @@ class ParamLayout:
         v('W2')[...] = logical['CAR/kernel']; v('b2')[...] = logical['CAR/bias']
         for l in range(self.L):
             I = C if l == 0 else H
-            K = np.asarray(logical['rnn/%d/kernel' % l]); bb = np.asarray(logical['rnn/%d/bias' % l])
             Wx, Wh, rb = v('rnn%d/Wx' % l), v('rnn%d/Wh' % l), v('rnn%d/b' % l)
+            if self.cell == 'ugrnn':
+                K = np.asarray(logical['rnn/%d/kernel' % l]); bb = np.asarray(logical['rnn/%d/bias' % l])
+            else:
+                K = np.asarray(logical['rnn/%d/gates/kernel' % l]); bb = np.asarray(logical['rnn/%d/gates/bias' % l])
+                Kc = np.asarray(logical['rnn/%d/candidate/kernel' % l]); bc = np.asarray(logical['rnn/%d/candidate/bias' % l])
+                Wx[:I, 2 * Hp:2 * Hp + H] = Kc[:I]
+                v('rnn%d/Wch' % l)[:H, :H] = Kc[I:]
+                rb[2 * Hp:2 * Hp + H] = bc
             Wx[:I, :H] = K[:I, :H]; Wx[:I, Hp:Hp + H] = K[:I, H:]
             Wh[:H, :H] = K[I:, :H]; Wh[:H, Hp:Hp + H] = K[I:, H:]
             rb[:H] = bb[:H]; rb[Hp:Hp + H] = bb[H:]
@@ -283,8 +301,14 @@ class ParamLayout:
             Wx, Wh, rb = v('rnn%d/Wx' % l), v('rnn%d/Wh' % l), v('rnn%d/b' % l)
             top = np.concatenate([Wx[:I, :H], Wx[:I, Hp:Hp + H]], 1)
             bot = np.concatenate([Wh[:H, :H], Wh[:H, Hp:Hp + H]], 1)
-            out['rnn/%d/kernel' % l] = np.concatenate([top, bot], 0)
-            out['rnn/%d/bias' % l] = np.concatenate([rb[:H], rb[Hp:Hp + H]])
+            if self.cell == 'ugrnn':
+                out['rnn/%d/kernel' % l] = np.concatenate([top, bot], 0)
+                out['rnn/%d/bias' % l] = np.concatenate([rb[:H], rb[Hp:Hp + H]])
+            else:
+                out['rnn/%d/gates/kernel' % l] = np.concatenate([top, bot], 0)
+                out['rnn/%d/gates/bias' % l] = np.concatenate([rb[:H], rb[Hp:Hp + H]])
+                out['rnn/%d/candidate/kernel' % l] = np.concatenate([Wx[:I, 2 * Hp:2 * Hp + H], v('rnn%d/Wch' % l)[:H, :H]], 0)
+                out['rnn/%d/candidate/bias' % l] = rb[2 * Hp:2 * Hp + H].copy()
         out['FC1/kernel'] = v('Wf1')[:H].copy(); out['FC1/bias'] = v('bf1').copy()
         out['FC2/kernel'] = v('Wf2').copy(); out['FC2/bias'] = v('bf2').copy()
         for i, (w, bn) in enumerate([('Ws1', 'bs1'), ('Ws2', 'bs2'), ('Ws3', 'bs3')]):

@@ -120,12 +120,15 @@ class NARRuntime:
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
-        self.side_stream = torch.cuda.Stream(device=dev)
+        import os
+        self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "-1")))
         self.gemm_ws_side = torch.empty(16 << 20, dtype=torch.float32, device=dev)
         self.colsum_ws_side = torch.empty(1 << 20, dtype=torch.float32, device=dev)
         # Measured on MI355X (profiles/r01_notes.md): with a second stream the 8 recurrent workgroups are starved by the
         # 15k-workgroup GEMM grid (no CU reservation), so the overlap is OFF by default; kept as an experiment switch.
-        self.overlap = False
+        self.overlap = os.environ.get("CHAM_OVERLAP", "0") == "1"
+        if os.environ.get("CHAM_RNN_LDS_HOG"):
+            self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._plans = {}
         self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
@@ -247,14 +250,18 @@ class StepPlan:
         self.dZ1 = f32(Rall, C)
         # RNN
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.xproj = [f32(BT, 2 * Hp) for _ in range(L.L)]
-        self.dxproj = f32(BT, 2 * Hp)
+        NG = L.NG
+        self.xproj = [f32(BT, NG * Hp) for _ in range(L.L)]
+        self.dxproj = f32(BT, NG * Hp)
         self.rnn_out = [f32(BT, Hp) for _ in range(L.L)]
         self.hprev = [f32(BT, Hp) for _ in range(L.L)]
         self.G = [f32(BT, Hp) for _ in range(L.L)]
         self.Cc = [f32(BT, Hp) for _ in range(L.L)]
+        gru = L.cell == 'gru'
+        self.R = [f32(BT, Hp) if gru else None for _ in range(L.L)]
+        self.RH = [f32(BT, Hp) if gru else None for _ in range(L.L)]
         self.drnn = f32(BT, Hp)
-        self.WhT = f32(2 * Hp, Hp)
+        self.WhT = f32(NG * Hp, Hp)
         # FCs / scorer
         self.FC1, self.dFC1 = f32(BT, 512), f32(BT, 512)
         self.pred, self.dpred = f32(BT, C), f32(BT, C)
@@ -281,7 +288,7 @@ class NARModuleModel:
                  diversity_reg_factor=0.0,
                  internal_features_config={'recency': True, 'novelty': True, 'article_content_embeddings': True,
                                            'item_clicked_embeddings': True},
-                 eval_cold_start=False, runtime=None):
+                 eval_cold_start=False, runtime=None, rnn_cell='ugrnn'):
         if elapsed_days_smooth_log_base != 1.3 or popularity_smooth_log_base != 2.0:
             raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
         if novelty_reg_factor != 0.0:
@@ -309,7 +316,7 @@ class NARModuleModel:
                                       articles_features_config=articles_features_config,
                                       content_article_embeddings_matrix=content_article_embeddings_matrix,
                                       articles_metadata=articles_metadata, CAR_embedding_size=CAR_embedding_size,
-                                      rnn_units=rnn_units, rnn_num_layers=rnn_num_layers,
+                                      rnn_units=rnn_units, rnn_num_layers=rnn_num_layers, rnn_cell=rnn_cell,
                                       internal_features_config=internal_features_config,
                                       max_cardinality_for_ohe=max_cardinality_for_ohe,
                                       recent_clicks_buffer_max_size=recent_clicks_buffer_max_size,
@@ -406,6 +413,7 @@ class NARModuleModel:
         s = _stream()
         BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         if step is None:
             step = rt.global_step if self.is_training else self.eval_step_key(rt.global_step, self._eval_iter)
         p = rt.p
@@ -450,9 +458,10 @@ class NARModuleModel:
         with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
             x, ldx, K = pl.Z2, C, C
             for l in range(L.L):
-                rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, 2 * Hp, K, ldx, 2 * Hp, 2 * Hp, bias=p('rnn%d/b' % l))
-                check(lib.cham_rnn_fwd(0, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
-                                       ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), _stream()), "cham_rnn_fwd")
+                rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, NGH, K, ldx, NGH, NGH, bias=p('rnn%d/b' % l))
+                check(lib.cham_rnn_fwd(cell, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
+                                       ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
+                                       ptr(pl.RH[l]), _stream()), "cham_rnn_fwd")
                 x, ldx, K = pl.rnn_out[l], Hp, Hp
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
             rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
@@ -480,6 +489,7 @@ class NARModuleModel:
         B, T, N = pl.B, pl.T, pl.N
         BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         p, g = rt.p, rt.g
         rt.grads[:L.emb_end].zero_()
         check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
@@ -512,16 +522,20 @@ class NARModuleModel:
             rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
             for l in range(last, -1, -1):
                 check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), ss), "cham_transpose_f32")
-                check(lib.cham_rnn_bwd(0, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
-                                       ptr(pl.Cc[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
+                if cell == 1:
+                    check(lib.cham_transpose_f32(ptr(p('rnn%d/Wch' % l)), Hp, Hp, pl.WhT[2 * Hp:].data_ptr(), ss), "cham_transpose_f32")
+                check(lib.cham_rnn_bwd(cell, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
+                                       ptr(pl.Cc[l]), ptr(pl.R[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
                 x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
-                rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, 2 * Hp, BT, ldx, 2 * Hp, 2 * Hp, transA=1, splits=0)
-                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, 2 * Hp, 2 * Hp, transA=1, splits=0)
-                rt.colsum(pl.dxproj, 2 * Hp, BT, 2 * Hp, g('rnn%d/b' % l))
+                rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, NGH, BT, ldx, NGH, NGH, transA=1, splits=0)
+                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, NGH, 2 * Hp, transA=1, splits=0)
+                if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
+                    rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BT, Hp, NGH, Hp, transA=1, splits=0)
+                rt.colsum(pl.dxproj, NGH, BT, NGH, g('rnn%d/b' % l))
                 if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows
-                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, 2 * Hp, 2 * Hp, 2 * Hp, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
+                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
                 else:
-                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1)
+                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, NGH, NGH, NGH, Hp, transB=1)
         # ... overlapped with the candidate-row dgrad of CAR layer 2 (needs dZ2c only)
         rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
         rt.join()

@@ -80,11 +80,16 @@ size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax);
 int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
                      float* workspace, size_t workspace_bytes, void* stream);
 
-/* --- K3 recurrent cell time steps: nar_model.py:1308-1361 (cell_kind 0 = UGRNN) */
+/* --- K3 recurrent cell time steps: nar_model.py:1308-1361.
+ * cell_kind 0 = UGRNN (tf.contrib.rnn.UGRNNCell, the reference's cell, :1317): xproj [B,T,2Hp] = x W_x + b (gate | candidate),
+ *   Wh [Hp,2Hp]; saves hprev, G (gate), Cc (candidate); R / RH unused (NULL).
+ * cell_kind 1 = GRU (tf.nn.rnn_cell.GRUCell, commented alternative at :1315; BASELINE config 4): xproj [B,T,3Hp] (r | u | c),
+ *   Wh = W_gh [Hp,2Hp] followed by W_ch [Hp,Hp]; saves hprev, G (= u), Cc, R (= r) and RH (= r*h_prev, the wgrad operand).
+ * backward: WhT = transpose(Wh) [2Hp,Hp] (GRU: transpose(W_gh) then transpose(W_ch)); dxproj = dL/d(pre-activations). */
 int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp, float* out,
-                 float* hprev, float* G, float* Cc, void* stream);
+                 float* hprev, float* G, float* Cc, float* R, float* RH, void* stream);
 int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
-                 const float* hprev, const float* G, const float* Cc, float* dxproj, void* stream);
+                 const float* hprev, const float* G, const float* Cc, const float* R, float* dxproj, void* stream);
 /* scheduling hook: recurrent workgroups request this much LDS so that no other workgroup shares their CU */
 void cham_rnn_set_exclusive_lds(size_t bytes);
 int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);

@@ -145,3 +145,25 @@ def test_row_shards_sum_to_full_batch(gpu):
     assert abs(xe - full['loss'][1]) < 1e-5
     scale = float(g_full.abs().max())
     assert float((g_sum - g_full).abs().max()) < 2e-5 * scale + 1e-7
+
+
+@pytest.mark.parametrize("cell,layers,Hn", [("gru", 1, 100), ("gru", 2, 256), ("ugrnn", 2, 255)])
+def test_step_parity_rnn_variants(gpu, cell, layers, Hn):
+    """GRU (north-star / BASELINE config 4: 2-layer GRU, hidden 256) and stacked cells vs the oracle."""
+    p = H.tiny_params(C=128, H=Hn, neg=9, batch_size=40, rnn_cell=cell, rnn_num_layers=layers)
+    batches = synthetic.make_batches(4, 40, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=5)
+    flips = [_compare_step(model, orc, *batches[i], st) for i in (2, 3)]
+    assert min(flips) == 0, flips
+
+
+def test_adressa_shape_tiny(gpu):
+    """Adressa feature schema (3 metadata embeddings, 3 large context embeddings), GRU x2, seq_len 30 -> T = 29."""
+    p = synthetic.default_params(800, 32, seq_len=30, batch_size=24, neg=20, neg_from_buffer=200, buffer_size=1500, for_norm=300,
+                                 C=128, H=128, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2,
+                                 reg_weight_decay=1e-4, lr=3e-4)
+    batches = synthetic.make_batches(3, 24, 30, 800, p['session_features_config'], length_dist='g1', seed=3)
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=2)
+    _compare_step(model, orc, *batches[2], st)
