@@ -369,7 +369,11 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
     if (p.N > 64) {
         // default: 256x128 tile / 8 waves for large outputs, 128x128 / 4 waves when the grid would otherwise be too
         // small to fill 256 CUs
-        const int v = g_variant >= 0 ? g_variant : (((long)p.M * p.N >= (1L << 20)) ? 2 : 0);
+        // measured on MI355X at the CAR shapes (profiles/r01_gemm_variants.md): NN 256x128 126-130 TFLOP/s; NT (dgrad) and
+        // TN (wgrad, long K) prefer the 256x256 tile (123 / 133 TFLOP/s)
+        int v = ((long)p.M * p.N >= (1L << 20)) ? 2 : 0;
+        if (v == 2 && (!AK || BKC) && p.K >= 512 && p.M >= 1024 && p.N >= 512) v = 4;
+        if (g_variant >= 0) v = g_variant;
         switch (v) {
             case 1: return launch_cfg<128, 128, 2, 2, 32, AK, BKC>(p, st);
             case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);

@@ -124,9 +124,10 @@ class NARRuntime:
         self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "-1")))
         self.gemm_ws_side = torch.empty(16 << 20, dtype=torch.float32, device=dev)
         self.colsum_ws_side = torch.empty(1 << 20, dtype=torch.float32, device=dev)
-        # Measured on MI355X (profiles/r01_notes.md): with a second stream the 8 recurrent workgroups are starved by the
-        # 15k-workgroup GEMM grid (no CU reservation), so the overlap is OFF by default; kept as an experiment switch.
-        self.overlap = os.environ.get("CHAM_OVERLAP", "0") == "1"
+        # Measured on MI355X (profiles/r01_notes.md): with a HIGH-PRIORITY side stream the 8 recurrent workgroups get
+        # CUs as soon as GEMM workgroups retire: 22.2 -> 20.7 ms per G1 step.  (With a default-priority stream they were
+        # starved behind the 7.7k-workgroup GEMM grid.)  CHAM_OVERLAP=0 turns it off.
+        self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)

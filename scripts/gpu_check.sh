@@ -5,11 +5,11 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-( timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $O/pytest_gpu.log
+( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 ) > $O/pytest_gpu.log
 ( timeout 200 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 ) > $O/smoke.log
-( timeout 400 python bench.py --steps 20 --warmup 5 2>&1 | tail -5 ) > $O/bench.log
+( timeout 400 python bench.py --steps 20 --warmup 5 2>&1 | tail -2 ) > $O/bench.log
 cd /tmp
-( timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o r01 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -5 ) > $O/rocprof.log
+( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ${TAG:-r01} -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -3 ) > $O/rocprof.log
 cd $R
-find $O/prof -name '*kernel_stats*' | head; find $O/prof -name '*kernel_trace*' -size +20M -delete
+find $O/prof -name '*kernel_trace*' -size +30M -delete
 cat $O/pytest_gpu.log $O/smoke.log $O/bench.log

@@ -98,9 +98,9 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     assert abs(log['hitrate_at_n_chameleon'] - res['hitrate_at_n']) < 1e-9 and abs(log['mrr_at_n_chameleon'] - res['mrr_at_n']) < 1e-6
     assert abs(res['loss'] - np.mean(losses)) < 1e-3
     assert len(T.sessions_negative_items_log) == 60
-    # training resumes from the restored state (evaluation clicks did not leak into the buffer)
-    assert np.array_equal(T.clicked_items_state.pop_recent_clicks_buffer, st.pop_recent_clicks_buffer)
     oracle_train(files[2:4], cap2)
+    # training resumed from the restored state (evaluation clicks did not leak into the buffer)
+    assert np.array_equal(T.clicked_items_state.pop_recent_clicks_buffer, st.pop_recent_clicks_buffer)
     # checkpoint round trip: a new Estimator on the same model_dir restores weights, Adam slots and the global step
     est2 = T.build_estimator(str(tmp_path / "model"), ace, meta, acfg, scfg)
     res2 = est2.evaluate(input_fn(files[4]))
