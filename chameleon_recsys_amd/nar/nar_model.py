@@ -186,7 +186,8 @@ class NARRuntime:
                                      ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
         if prof is not None:
             e1.record()
-            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=splits, ev=(e0, e1)))
+            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=splits, act=act, dref=dref is not None,
+                             ev=(e0, e1)))
 
     def colsum(self, X, ld, R, F, out, w=None, accumulate=0):
         ws = self.colsum_ws_side if torch.cuda.current_stream() == self.side_stream else self.colsum_ws
