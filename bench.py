@@ -76,13 +76,15 @@ def main():
     ap.add_argument("--length-dist", default="full", choices=["full", "g1"],
                     help="full: every session has seq_len clicks (no padded rows); g1: G1-like ragged lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--state", default="device", choices=["device", "host"],
+                    help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from chameleon_recsys_amd.nar import synthetic
-    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, DeviceClickedItemsState, batch_clicks_for_state
     from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel, NARRuntime
     from chameleon_recsys_amd.nar.parallel import DataParallelNAR
 
@@ -113,15 +115,23 @@ def main():
                            articles_metadata=params['articles_metadata'], CAR_embedding_size=cfg['C'], rnn_units=cfg['H'],
                            runtime=rt)
     dp = DataParallelNAR(model)
-    state = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
+    if args.state == "device":
+        state = DeviceClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'], device="cuda:%d" % local_rank)
+    else:
+        state = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
     dev_batches = [dp.upload(f, l) for f, l in batches]          # inputs resident in HBM before the timed region
     host_clicks = [batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']) for f, l in batches]
 
     def one_step(i):
         k = i % n_distinct
-        model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())   # hook.before_run
-        model.train_step(dev_batches[k])
-        state.update_items_state(*host_clicks[k])                                                   # hook.after_run
+        if args.state == "device":
+            model.feed_state(state, state)                                                              # hook.before_run
+            model.train_step(dev_batches[k])
+            state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])        # hook.after_run
+        else:
+            model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())
+            model.train_step(dev_batches[k])
+            state.update_items_state(*host_clicks[k])
 
     def barrier():
         if world > 1:
@@ -184,7 +194,7 @@ def main():
                        "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": "ugrnn",
-                       "session_lengths": args.length_dist, "parallelism": "dp%d" % world,
+                       "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": DOM_SYMBOL + " = fp32 MFMA GEMM, NN, bias+tanh (CAR layer 2 forward), all launches of a step",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

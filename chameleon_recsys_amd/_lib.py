@@ -2,7 +2,7 @@
 missing or a kernel call fails this raises - the product path never silently degrades."""
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchameleon_nar.so")
@@ -16,6 +16,7 @@ _SIGNATURES = {
     "cham_ctx_assemble": (c_int, [P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "cham_item_dynamic_raw": (c_int, [P, P, c_int, P, P, P, P, P]),
     "cham_norm_stats_from_recent": (c_int, [P, c_int, c_int64, P, P, P, P, P]),
+    "cham_norm_stats_from_buffer": (c_int, [P, c_int, c_int64, P, P, P, P, P]),
     "cham_norm_stats_from_rows": (c_int, [P, P, P, c_int, P, P]),
     "cham_row_weights": (c_int, [P, c_int, P, c_size_t, c_int, P, P, P, P]),
     "cham_item_assemble": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
@@ -34,6 +35,8 @@ _SIGNATURES = {
     "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, P]),
     "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, P]),
     "cham_rank_items": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
+    "cham_state_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cham_state_update": (c_int, [P, P, c_int, c_int, c_double, P, P, c_int, P, P, P, c_int, c_int, P, P, c_size_t, P]),
     "cham_sumsq_partial": (c_int, [P, c_size_t, P, P]),
     "cham_loss_finalize": (c_int, [P, c_int, c_float, P, c_float, P, P]),
     "cham_adam_tf": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),

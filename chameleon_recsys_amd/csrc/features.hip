@@ -229,6 +229,22 @@ extern "C" int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, 
     return CHAM_OK;
 }
 
+// same statistics straight from the device-resident recent-clicks buffer (csrc/state.hip): population = the first
+// min(n_prefix, #valid) entries (valid entries are a zero-padded prefix; nar_model.py:1041-1044).  scratch: 3 * n_prefix floats.
+extern "C" int cham_norm_stats_from_buffer(const int64_t* buffer_ids, int n_prefix, int64_t max_ts, const int64_t* created,
+                                           const float* pop_norm, float* scratch, float* stats /*[3][8]*/, void* stream) {
+    if (!buffer_ids || n_prefix <= 0 || !created || !pop_norm || !scratch || !stats) return -CHAM_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* w = scratch + 2 * (size_t)n_prefix;
+    hipLaunchKernelGGL(k_nonzero_weights, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, w);
+    hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, max_ts, created,
+                       pop_norm, scratch, scratch + n_prefix);
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)w, n_prefix, stats, 3);
+    hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_prefix, (const float*)w, n_prefix, stats + 4, 3);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
 // stats from the call's own rows (empty buffer = very first batch): one group at a time
 extern "C" int cham_norm_stats_from_rows(const float* rec_raw, const float* nov_raw, const float* weights, int n,
                                          float* stats_group /*[8]*/, void* stream) {

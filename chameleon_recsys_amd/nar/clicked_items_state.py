@@ -98,3 +98,93 @@ def batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps):
     last_ts = np.max(clicked_timestamps, axis=1).reshape(-1, 1)
     ts = np.concatenate([clicked_timestamps, last_ts], axis=1).reshape(-1)
     return batch_clicked_items[nz], ts[nz]
+
+
+class DeviceClickedItemsState:
+    """The same state kept in HBM: recent-clicks ring buffer (ids, timestamps), recent popularity histogram,
+    ``articles_recent_pop_norm`` (float32, what the graph is fed) and global popularity, updated by the HIP kernels of
+    csrc/state.hip straight from the batch tensors the step already has on the device - no host round trip per step.
+    Same public methods as ClickedItemsState (the getters download); bit-identical results (tests/test_state_gpu.py)."""
+    is_device = True
+
+    def __init__(self, recent_clicks_buffer_hours, recent_clicks_buffer_max_size, recent_clicks_for_normalization, num_items,
+                 device='cuda:0'):
+        import torch
+        from .. import _lib
+        self.lib = _lib.load()
+        self.torch = torch
+        self.device = torch.device(device)
+        self.recent_clicks_buffer_hours = recent_clicks_buffer_hours
+        self.recent_clicks_buffer_max_size = recent_clicks_buffer_max_size
+        self.recent_clicks_for_normalization = recent_clicks_for_normalization
+        self.num_items = num_items
+        self._ws = None
+        self.reset_state()
+
+    def reset_state(self):
+        t, dev, n, m = self.torch, self.device, self.num_items, self.recent_clicks_buffer_max_size
+        self.buf_ids = t.zeros(m, dtype=t.int64, device=dev)
+        self.buf_ts = t.zeros(m, dtype=t.int64, device=dev)
+        self.recent_pop = t.zeros(n, dtype=t.int32, device=dev)
+        self.articles_pop = t.zeros(n, dtype=t.int64, device=dev)
+        # _update_recent_pop_norm(zeros): max(0 / 1, 1 / for_norm)
+        self.pop_norm = t.full((n,), float(np.float32(1.0 / self.recent_clicks_for_normalization)), dtype=t.float32, device=dev)
+        self.n_valid = t.zeros(1, dtype=t.int32, device=dev)
+        self.n_updates = 0
+        self.current_step = 0
+
+    # ---- updates
+    def update_from_device_batch(self, aci, event_ts):
+        """aci [B, T+1] int64 = concat(item_clicked, label_last_item), event_ts [B, T] int64 - device tensors of the GLOBAL batch."""
+        from .._lib import check, ptr
+        t = self.torch
+        B, T1 = aci.shape
+        need = self.lib.cham_state_workspace_bytes(B, self.recent_clicks_buffer_max_size)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = t.empty(need, dtype=t.uint8, device=self.device)
+        check(self.lib.cham_state_update(ptr(aci), ptr(event_ts), B, T1 - 1, float(self.recent_clicks_buffer_hours),
+                                         ptr(self.buf_ids), ptr(self.buf_ts), self.recent_clicks_buffer_max_size,
+                                         ptr(self.recent_pop), ptr(self.pop_norm), ptr(self.articles_pop), self.num_items,
+                                         self.recent_clicks_for_normalization, ptr(self.n_valid), ptr(self._ws), self._ws.numel(),
+                                         t.cuda.current_stream().cuda_stream), "cham_state_update")
+        self.n_updates += 1
+
+    def update_items_state(self, batch_clicked_items, batch_clicked_timestamps):
+        """Host-array entry point of the reference class (flattened non-zero ids / timestamps)."""
+        t = self.torch
+        ids = np.ascontiguousarray(batch_clicked_items, dtype=np.int64).reshape(-1)
+        ts = np.ascontiguousarray(batch_clicked_timestamps, dtype=np.int64).reshape(-1, 1)
+        aci = np.stack([ids, np.zeros_like(ids)], axis=1)          # one "session" per click: [id, no label]
+        self.update_from_device_batch(t.from_numpy(aci).to(self.device), t.from_numpy(ts).to(self.device))
+
+    # ---- the reference's getters (download)
+    def get_recent_clicks_buffer(self):
+        return self.buf_ids.cpu().numpy()
+
+    def get_articles_recent_pop_norm(self):
+        return self.pop_norm.cpu().numpy()
+
+    def get_articles_recent_pop(self):
+        return self.recent_pop.cpu().numpy().astype(np.int64)
+
+    def get_articles_pop(self):
+        return self.articles_pop.cpu().numpy()
+
+    @property
+    def pop_recent_clicks_buffer(self):
+        return np.stack([self.buf_ids.cpu().numpy(), self.buf_ts.cpu().numpy()], axis=1)
+
+    def increment_current_step(self):
+        self.current_step += 1
+
+    def get_current_step(self):
+        return self.current_step
+
+    # ---- snapshot around evaluation (clicked_items_state.py:49-79: buffer + global pop; pop_norm is NOT restored)
+    def save_state_checkpoint(self):
+        self._chkp = (self.articles_pop.clone(), self.buf_ids.clone(), self.buf_ts.clone(), self.n_valid.clone(),
+                      self.n_updates, self.current_step)
+
+    def restore_state_checkpoint(self):
+        self.articles_pop, self.buf_ids, self.buf_ts, self.n_valid, self.n_updates, self.current_step = self._chkp
+        del self._chkp

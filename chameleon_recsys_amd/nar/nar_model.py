@@ -122,8 +122,8 @@ class NARRuntime:
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
         import os
         self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "-1")))
-        self.gemm_ws_side = torch.empty(16 << 20, dtype=torch.float32, device=dev)
-        self.colsum_ws_side = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+        self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
+        self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
         # Measured on MI355X (profiles/r01_notes.md): with a HIGH-PRIORITY side stream the 8 recurrent workgroups get
         # CUs as soon as GEMM workgroups retire: 22.2 -> 20.7 ms per G1 step.  (With a default-priority stream they were
         # starved behind the 7.7k-workgroup GEMM grid.)  CHAM_OVERLAP=0 turns it off.
@@ -239,7 +239,7 @@ class StepPlan:
         self.ref_ts = i64(RV)
         self.rec_raw, self.nov_raw = f32(RV), f32(RV)
         self.stats = f32(3, 8)
-        self.stat_scratch = f32(2 * max(1, int(rt.params['recent_clicks_for_normalization'])))
+        self.stat_scratch = f32(3 * max(1, int(rt.params['recent_clicks_for_normalization'])))
         self.w_rows = f32(RV)
         self.Xc_raw, self.Xc_s, self.dXc = f32(BT, Fc), f32(BT, Fc), f32(BT, Fc)
         self.Xi_raw, self.Xi_s, self.dXi = f32(RV, Fi), f32(RV, Fi), f32(RV, Fi)
@@ -366,8 +366,18 @@ class NARModuleModel:
         self.feed_state(by_name['articles_recent_pop_norm'], by_name['pop_recent_items_buffer'])
 
     # ------------------------------------------------------------------ host -> device
+    def feed_device_state(self, state):
+        """Device-resident state (clicked_items_state.DeviceClickedItemsState): nothing is uploaded."""
+        self.articles_recent_pop_norm = state
+        self.pop_recent_items_buffer = state
+        self._dev_state = dict(buffer=state.buf_ids, pop_norm=state.pop_norm, last=state.buf_ids,
+                               n_last=min(self.recent_clicks_for_normalization, state.buf_ids.numel()) if state.n_updates > 0 else 0,
+                               device=True)
+
     def feed_state(self, pop_norm, buffer_ids):
         """The hook's feed_dict (nar_model.py:1458-1463)."""
+        if getattr(pop_norm, 'is_device', False):
+            return self.feed_device_state(pop_norm)
         self.articles_recent_pop_norm = pop_norm
         self.pop_recent_items_buffer = buffer_ids
         dev = self.rt.device
@@ -399,8 +409,9 @@ class NARModuleModel:
         num = np.stack([np.asarray(features[n], np.float32).reshape(-1) for n in L.ctx_num_names]) if L.ctx_num_names \
             else np.zeros((1, B * T), np.float32)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        g_ets = ets if global_features is None else np.ascontiguousarray(gf['event_timestamp'], dtype=np.int64)
         return dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts,
-                    aci=t(aci), item_clicked=t(item_clicked), label_next=t(np.asarray(labels['label_next_item'], np.int64)),
+                    g_event_ts=t(g_ets), aci=t(aci), item_clicked=t(item_clicked), label_next=t(np.asarray(labels['label_next_item'], np.int64)),
                     event_ts=t(ets), seq_len=t(seq_len), mask=t(mask.astype(np.uint8).reshape(-1)), cat=t(cat), num=t(num))
 
     # ------------------------------------------------------------------ forward
@@ -432,7 +443,11 @@ class NARModuleModel:
         pl.ref_ts[BT:].fill_(d['max_ts'])
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
-        if st['n_last'] > 0:
+        if st['n_last'] > 0 and st.get('device'):
+            check(lib.cham_norm_stats_from_buffer(ptr(st['last']), st['n_last'], d['max_ts'], ptr(rt.created),
+                                                  ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
+                  "cham_norm_stats_from_buffer")
+        elif st['n_last'] > 0:
             check(lib.cham_norm_stats_from_recent(ptr(st['last']), st['n_last'], d['max_ts'], ptr(rt.created),
                                                   ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
                   "cham_norm_stats_from_recent")
@@ -485,6 +500,11 @@ class NARModuleModel:
 
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
     def backward(self):
+        """Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
+        PreCAR combine -> features); SIDE (high priority) carries everything that only produces weight gradients - wgrad GEMMs,
+        bias column sums - plus the session-FC / recurrent chain, so the HBM-bound elementwise kernels of one lane run beside the
+        MFMA-bound GEMMs of the other.  Every cross-lane dependency is an explicit event; with overlap off the same program
+        order runs on one stream."""
         rt, lib, L = self.rt, self.rt.lib, self.rt.layout
         pl, d = self._plan, self._d
         s = _stream()
@@ -493,28 +513,58 @@ class NARModuleModel:
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
         cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         p, g = rt.p, rt.g
+        main_stream, on = torch.cuda.current_stream(), rt.overlap
+
+        def mark():                      # event on the current stream
+            if not on:
+                return None
+            ev = torch.cuda.Event(); ev.record()
+            return ev
+
+        import contextlib
+
+        @contextlib.contextmanager
+        def side(*events):               # run the block on the side lane after `events`
+            if not on:
+                yield
+                return
+            for ev in events:
+                rt.side_stream.wait_event(ev)
+            with torch.cuda.stream(rt.side_stream):
+                yield
+
+        def main_wait(ev):
+            if on:
+                main_stream.wait_event(ev)
+
         rt.grads[:L.emb_end].zero_()
+        e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
         check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
                                          float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3), s),
               "cham_score_softmax_bwd")
-        rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
-        rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
-        # scorer layers 3, 2, 1
-        rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
-        rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
+        e_dS3 = mark()
+        with side(e_start, e_dS3):
+            rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
+            rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
+            rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
+            rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
         rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
-        rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
-        rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
+        e_dS2 = mark()
+        with side(e_dS2):
+            rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
+            rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
         rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+        e_dS1 = mark()
         Z2c, dZ2c = pl.Z2[BT:], pl.dZ2[BT:]
-        rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
-        rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
+        with side(e_dS1):
+            rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
+            rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
         rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         check(lib.cham_mulpred_bwd(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s), "cham_mulpred_bwd")
-        # session FCs + recurrent layers on the side stream ...
+        e_dZ2c = mark()                  # dZ2c final + dpred
+        # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
-        rt.fork()
-        with rt.side():
+        with side(e_dZ2c):
             ss = _stream()
             rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
             rt.colsum(pl.dpred, C, BT, C, g('bf2'))
@@ -528,28 +578,33 @@ class NARModuleModel:
                     check(lib.cham_transpose_f32(ptr(p('rnn%d/Wch' % l)), Hp, Hp, pl.WhT[2 * Hp:].data_ptr(), ss), "cham_transpose_f32")
                 check(lib.cham_rnn_bwd(cell, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
                                        ptr(pl.Cc[l]), ptr(pl.R[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
+                if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows (main lane waits for it)
+                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
+                    e_dZ2in = mark()
+                else:
+                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, NGH, NGH, NGH, Hp, transB=1)
                 x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
                 rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, NGH, BT, ldx, NGH, NGH, transA=1, splits=0)
                 rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, NGH, 2 * Hp, transA=1, splits=0)
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
                     rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BT, Hp, NGH, Hp, transA=1, splits=0)
                 rt.colsum(pl.dxproj, NGH, BT, NGH, g('rnn%d/b' % l))
-                if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows
-                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
-                else:
-                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, NGH, NGH, NGH, Hp, transB=1)
-        # ... overlapped with the candidate-row dgrad of CAR layer 2 (needs dZ2c only)
+            # CAR layer-2 weight gradient over ALL rows (needs dZ2 of the clicked rows from just above)
+            rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
+            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only)
         rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
-        rt.join()
+        if on:
+            main_wait(e_dZ2in)
         rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
-        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
-        rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
         check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
                                    rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
-        rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
-        rt.colsum(pl.dU, C, BT, C, g('b1'))
+        e_dUV = mark()
+        with side(e_dUV):
+            rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+            rt.colsum(pl.dU, C, BT, C, g('b1'))
+            rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
         rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
-        rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
         rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
         # scale/center + embedding tables
         check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(rt.ctx_desc), ptr(p('gamma_ctx')), 0, ptr(d['cat']),
@@ -557,6 +612,7 @@ class NARModuleModel:
         check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(rt.item_desc), ptr(p('gamma_item')), 1, None,
                                    ptr(pl.ids_all), ptr(rt.meta_cat), rt.n_items, ptr(g('gamma_item')), ptr(g('beta_item')),
                                    ptr(rt.grads), s), "cham_feature_bwd")
+        rt.join()
 
     def apply_gradients(self):
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
@@ -664,8 +720,9 @@ class ItemsStateUpdaterHook:
             fetches.update(predicted_item_ids=m.predicted_item_ids, eval_batch_negative_items=m.batch_negative_items,
                            batch_items_count=m.batch_items_count, batch_unique_items_count=m.batch_unique_items_count,
                            predicted_item_probs=m.predicted_item_probs, label_rank=m.label_rank)
-        feed_dict = {m.ph_articles_recent_pop_norm: self.clicked_items_state.get_articles_recent_pop_norm(),
-                     m.ph_pop_recent_items_buffer: self.clicked_items_state.get_recent_clicks_buffer(),
+        dev = getattr(self.clicked_items_state, 'is_device', False)
+        feed_dict = {m.ph_articles_recent_pop_norm: self.clicked_items_state if dev else self.clicked_items_state.get_articles_recent_pop_norm(),
+                     m.ph_pop_recent_items_buffer: self.clicked_items_state if dev else self.clicked_items_state.get_recent_clicks_buffer(),
                      m.ph_content_article_embeddings_matrix: self.content_article_embeddings_matrix}
         for name in self.articles_metadata:
             if name in m.ph_articles_metadata:
@@ -711,6 +768,10 @@ class ItemsStateUpdaterHook:
             for metric in self.streaming_metrics:                              # evaluation.py:28-45
                 self.eval_streaming_metrics_last['{}_{}'.format(metric.name, 'chameleon')] = metric.result()
         # state update, nar_model.py:1635-1649
+        if getattr(self.clicked_items_state, 'is_device', False):     # straight from the batch tensors already in HBM
+            d = self.model._d
+            self.clicked_items_state.update_from_device_batch(d['aci'], d['g_event_ts'])
+            return
         from .clicked_items_state import batch_clicks_for_state
         ids, ts = batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps)
         self.clicked_items_state.update_items_state(ids, ts)

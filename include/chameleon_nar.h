@@ -46,6 +46,10 @@ int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, int R, cons
  * stats [3][8] = per call group {mean, sd, zmin, zmax} x {recency, novelty} */
 int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, int64_t max_ts, const int64_t* created,
                                 const float* pop_norm, float* scratch, float* stats, void* stream);
+/* the same statistics straight from the device-resident buffer (cham_state_update): population = the valid entries among
+ * the first n_prefix (= recent_clicks_for_normalization) buffer slots; scratch holds 3 * n_prefix floats */
+int cham_norm_stats_from_buffer(const int64_t* buffer_ids, int n_prefix, int64_t max_ts, const int64_t* created,
+                                const float* pop_norm, float* scratch, float* stats, void* stream);
 /* empty-buffer fallback (first batch): population = the call's own non-pad ids, nar_model.py:1078-1084, 1168-1181 */
 int cham_norm_stats_from_rows(const float* rec_raw, const float* nov_raw, const float* weights, int n, float* stats_group,
                               void* stream);
@@ -106,6 +110,16 @@ int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float
  * HitRate@n / MRR@n (metrics.py:40-66, 109-134; TF twins nar_model.py:826-835, 859-885) */
 int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t* neg_ids, const uint8_t* mask, int BT, int N,
                     int64_t* pred_ids, float* pred_probs, int32_t* label_rank, void* stream);
+
+/* --- device-resident recent-clicks state: ClickedItemsState.update_items_state, clicked_items_state.py:187-250, fed by the
+ * hook's flattening nar_model.py:1635-1646.  aci [B,T+1] = concat(item_clicked, label_last_item), event_ts [B,T] (both
+ * already in HBM); buf_ids / buf_ts [buffer_size] newest first, zero padded; recent_pop [n_items] int32; pop_norm [n_items]
+ * float32 = float32(max(recent_pop / (sum + 1), 1 / for_norm)) computed in float64; articles_pop [n_items] int64;
+ * n_valid = device scalar (number of valid buffer entries).  Bit-identical to the reference class. */
+size_t cham_state_workspace_bytes(int B, int buffer_size);
+int cham_state_update(const int64_t* aci, const int64_t* event_ts, int B, int T, double buffer_hours, int64_t* buf_ids,
+                      int64_t* buf_ts, int buffer_size, int32_t* recent_pop, float* pop_norm, int64_t* articles_pop, int n_items,
+                      int for_norm, int32_t* n_valid, void* workspace, size_t workspace_bytes, void* stream);
 
 /* --- K7 regularisation loss, loss finalisation, TF Adam, bias-gradient column sums: nar_model.py:655, 660-667, 708-722 */
 int cham_sumsq_partial(const float* params, size_t n_reg, float* partial, void* stream);
