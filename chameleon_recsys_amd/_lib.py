@@ -40,6 +40,8 @@ _SIGNATURES = {
     "cham_sumsq_partial": (c_int, [P, c_size_t, P, P]),
     "cham_loss_finalize": (c_int, [P, c_int, c_float, P, c_float, P, P]),
     "cham_adam_tf": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    "cham_accumulate": (c_int, [P, P, c_size_t, c_int, P]),
+    "cham_loss_accumulate": (c_int, [P, P, c_int, P]),
     "cham_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cham_colsum": (c_int, [P, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
 }

@@ -161,3 +161,42 @@ extern "C" int cham_colsum(const float* X, int ld, int R, int F, const float* w,
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+
+// ---- gradient accumulation over session micro-batches (large-catalog / large-batch configurations): the step's row
+// shards share the pool, the denominators and the weights, so their gradient buffers simply add up.
+__global__ __launch_bounds__(256) void k_accumulate(float* __restrict__ acc, const float* __restrict__ x, size_t n4, size_t n, int first) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 b = reinterpret_cast<const float4*>(x)[i];
+        float4 a = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(acc)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(acc)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        acc[i] = (first ? 0.f : acc[i]) + x[i];
+    }
+}
+// loss_acc = [xe_acc + reg, xe_acc (+)= xe, reg]
+__global__ void k_loss_accumulate(float* __restrict__ acc, const float* __restrict__ loss, int first) {
+    if (threadIdx.x == 0) {
+        const float xe = (first ? 0.f : acc[1]) + loss[1];
+        acc[1] = xe; acc[2] = loss[2]; acc[0] = xe + loss[2];
+    }
+}
+extern "C" int cham_accumulate(float* acc, const float* x, size_t n, int first, void* stream) {
+    if (!acc || !x || n == 0) return -CHAM_ERR_ARG;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, x, n4, n, first);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" int cham_loss_accumulate(float* acc, const float* loss, int first, void* stream) {
+    if (!acc || !loss) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_loss_accumulate, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, loss, first);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

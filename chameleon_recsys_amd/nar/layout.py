@@ -212,14 +212,14 @@ class ParamLayout:
             specs['match%d/bias' % (i + 1)] = ((dims[i + 1],), 'zeros', False)
         return specs
 
-    def init_logical(self, seed=42):
+    def init_logical(self, seed=42, max_random_elems=None):
         """TF-1.12 initialiser distributions (xavier_initializer, variance_scaling_initializer(), lecun_uniform;
         nar_model.py:210, 377, 413, 449-470).  TF's own random streams are not reproducible."""
         rng = np.random.default_rng(seed)
         out = OrderedDict()
         for name, (shape, init, _) in self.logical_specs().items():
-            if init == 'zeros':
-                w = np.zeros(shape, np.float32)
+            if init == 'zeros' or (max_random_elems is not None and int(np.prod(shape)) > max_random_elems):
+                w = np.zeros(shape, np.float32)      # (stress configurations: multi-GB tables start at zero instead of xavier)
             elif init == 'ones':
                 w = np.ones(shape, np.float32)
             else:

@@ -625,6 +625,31 @@ class NARModuleModel:
         check(rt.lib.cham_adam_tf(ptr(rt.flat), ptr(rt.grads), ptr(rt.m), ptr(rt.v), L.total, L.n_reg,
                                   float(self.reg_weight_decay), float(lr_t), 0.9, 0.999, 1e-8, _stream()), "cham_adam_tf")
 
+    def train_step_microbatched(self, features, labels, micro_sessions, global_features=None, global_labels=None, row_begin=0):
+        """One optimizer step over the batch processed as row shards of ``micro_sessions`` sessions (activations of the
+        B*T*(1+N) candidate rows bounded by the shard; BASELINE config 5 = 4096 sessions x 200 negatives).  Every shard sees
+        the GLOBAL ids (pool, max timestamp, sum(mask), sampler keyed by the global row), gradients accumulate, ONE Adam.
+        Same result as train_step on the whole batch up to fp32 summation order (tests: shard-sum / micro-batch parity)."""
+        from .parallel import slice_batch
+        rt = self.rt
+        gf = features if global_features is None else global_features
+        gl = labels if global_labels is None else global_labels
+        n = np.asarray(features['item_clicked']).shape[0]
+        if getattr(rt, 'grads_acc', None) is None:
+            rt.grads_acc = torch.empty_like(rt.grads)
+            rt.loss_acc = torch.zeros(3, dtype=torch.float32, device=rt.device)
+        for k, b in enumerate(range(0, n, micro_sessions)):
+            e = min(n, b + micro_sessions)
+            f, l = slice_batch(features, labels, b, e)
+            self.forward(self.upload_batch(f, l, gf, gl, row_begin=row_begin + b))
+            self.backward()
+            check(rt.lib.cham_accumulate(ptr(rt.grads_acc), ptr(rt.grads), rt.layout.total, int(k == 0), _stream()), "cham_accumulate")
+            check(rt.lib.cham_loss_accumulate(ptr(rt.loss_acc), ptr(self._plan.loss), int(k == 0), _stream()), "cham_loss_accumulate")
+        rt.grads, rt.grads_acc = rt.grads_acc, rt.grads          # Adam (and the data-parallel all-reduce) read rt.grads
+        self.apply_gradients()
+        self.total_loss = rt.loss_acc
+        return self.total_loss
+
     def train_step(self, device_batch=None):
         """One optimizer step on the current batch (the reference's ``session.run(model.train)``)."""
         d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)

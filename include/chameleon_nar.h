@@ -127,6 +127,11 @@ int cham_loss_finalize(const float* nll, int BT, float sum_mask, const float* su
                        void* stream);
 int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda, float lr_t,
                  float beta1, float beta2, float eps, void* stream);
+/* gradient accumulation over session micro-batches of ONE optimizer step (row shards of the batch share pool, denominators
+ * and weights - SURVEY.md 8e - so their flat gradient buffers add): acc = (first ? 0 : acc) + x;
+ * loss_acc = [sum(xe) + reg, sum(xe), reg] */
+int cham_accumulate(float* acc, const float* x, size_t n, int first, void* stream);
+int cham_loss_accumulate(float* acc, const float* loss, int first, void* stream);
 size_t cham_colsum_workspace_bytes(int R, int F);
 int cham_colsum(const float* X, int ld, int R, int F, const float* w, float* out, int accumulate, float* workspace,
                 size_t workspace_bytes, void* stream);

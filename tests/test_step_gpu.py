@@ -167,3 +167,21 @@ def test_adressa_shape_tiny(gpu):
     st = H.warm_state(p, batches[:2])
     model, orc = H.make_pair(p, seed=2)
     _compare_step(model, orc, *batches[2], st)
+
+
+def test_microbatched_step_equals_whole_batch_step(gpu):
+    """Gradient accumulation over session micro-batches (BASELINE config 5 path) == one step on the whole batch."""
+    p = H.tiny_params()
+    batches = synthetic.make_batches(4, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    m1, _ = H.make_pair(p)
+    m2, _ = H.make_pair(p)
+    f, l = batches[3]
+    for m in (m1, m2):
+        m.feed_state(st.get_articles_recent_pop_norm(), st.get_recent_clicks_buffer())
+    a = m1.train_step(m1.upload_batch(f, l)).cpu().numpy()
+    b = m2.train_step_microbatched(f, l, 24).cpu().numpy()          # 24 + 24 + 16 sessions
+    assert np.abs(a - b).max() < 1e-5, (a, b)
+    assert m1.rt.global_step == m2.rt.global_step == 1
+    assert float((m1.rt.flat - m2.rt.flat).abs().max()) < 1e-6
+    assert float((m1.rt.m - m2.rt.m).abs().max()) < 1e-6 * max(1.0, float(m1.rt.m.abs().max()))
