@@ -245,26 +245,23 @@ def _append_json_lines(path, rows):
             fh.write(json.dumps(r) + '\n')
 
 
-def main(argv=None):
-    """nar_trainer_gcom.py:418-586."""
+def train_and_evaluate_loop(flags, ace, articles_metadata, articles_features_config, session_features_config,
+                            state_cls=ClickedItemsState):
+    """The hourly loop shared by both trainers: nar_trainer_gcom.py:476-582 / nar_trainer_adressa.py:472-570.
+    ``ace`` is the raw ACE matrix; it is L2-row-normalised and scaled here (:470-474)."""
     global FLAGS, clicked_items_state, eval_sessions_metrics_log, sessions_negative_items_log
     global sessions_chameleon_recommendations_log, global_eval_hour_id
-    FLAGS = define_flags().parse_args(argv)
+    FLAGS = flags
     if FLAGS.use_local_cache_model_dir or FLAGS.warmup_model_dir:
         raise NotImplementedError("GCS model-dir caching / warm start download is out of scope (copy model.ckpt.pt into --model_dir)")
     np.random.seed(RANDOM_SEED)
     os.makedirs(FLAGS.model_dir, exist_ok=True)
-    articles_metadata_df, ace = load_acr_module_resources(FLAGS.acr_module_articles_metadata_csv_path,
-                                                          FLAGS.acr_module_articles_content_embeddings_pickle_path)
-    ace = l2_normalize_rows(ace) * np.float32(FLAGS.content_embedding_scale_factor)                  # :470-474
-    articles_features_config = get_articles_features_config(n_items=ace.shape[0])
-    articles_metadata = process_articles_metadata(articles_metadata_df, articles_features_config)
-    session_features_config = get_session_features_config()
+    ace = l2_normalize_rows(ace) * np.float32(FLAGS.content_embedding_scale_factor)
     eval_sessions_metrics_log = []
     sessions_negative_items_log = [] if FLAGS.save_eval_sessions_negative_samples else None
     sessions_chameleon_recommendations_log = [] if FLAGS.save_eval_sessions_recommendations else None
-    clicked_items_state = ClickedItemsState(FLAGS.recent_clicks_buffer_hours, FLAGS.recent_clicks_buffer_max_size,
-                                            FLAGS.recent_clicks_for_normalization, ace.shape[0])
+    clicked_items_state = state_cls(FLAGS.recent_clicks_buffer_hours, FLAGS.recent_clicks_buffer_max_size,
+                                    FLAGS.recent_clicks_for_normalization, ace.shape[0])
     model = build_estimator(FLAGS.model_dir, ace, articles_metadata, articles_features_config, session_features_config)
     train_files = resolve_files(FLAGS.train_set_path_regex)
     if FLAGS.train_files_from > FLAGS.train_files_up_to:
@@ -303,6 +300,18 @@ def main(argv=None):
                            [dict(eval_hour_id=global_eval_hour_id, **r) for r in sessions_chameleon_recommendations_log])
     print('INFO:==== Finalized TRAINING Loop elapsed {:.1f} minutes'.format((time() - start_train) / 60.0), flush=True)
     return model
+
+
+def main(argv=None):
+    """nar_trainer_gcom.py:418-586."""
+    global FLAGS
+    FLAGS = define_flags().parse_args(argv)
+    articles_metadata_df, ace = load_acr_module_resources(FLAGS.acr_module_articles_metadata_csv_path,
+                                                          FLAGS.acr_module_articles_content_embeddings_pickle_path)
+    articles_features_config = get_articles_features_config(n_items=ace.shape[0])
+    articles_metadata = process_articles_metadata(articles_metadata_df, articles_features_config)
+    session_features_config = get_session_features_config()
+    return train_and_evaluate_loop(FLAGS, ace, articles_metadata, articles_features_config, session_features_config)
 
 
 if __name__ == '__main__':

@@ -109,3 +109,25 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     res1 = est.evaluate(input_fn(files[4]))
     assert abs(res1['loss'] - res2['loss']) < 1e-6 and res1['hitrate_at_n'] == res2['hitrate_at_n']
     torch.cuda.synchronize()
+
+
+def test_trainer_main_cli_end_to_end(gpu, tmp_path):
+    """`python -m chameleon_recsys_amd.nar.nar_trainer_gcom --flags` (the reference's CLI, nar_trainer_gcom.py:418-586): hourly
+    train -> evaluate loop over TFRecord files, metrics CSV, negative-samples / recommendations logs, checkpoint."""
+    import json
+    import os
+    files, csv, pkl = synthetic.write_dataset(str(tmp_path / "data"), 5, 40, 300, 16, seq_len=10, seed=5)
+    argv = ARGS + ['--train_set_path_regex', str(tmp_path / "data" / "sessions_hour_*.tfrecord.gz"),
+                   '--acr_module_articles_metadata_csv_path', csv, '--acr_module_articles_content_embeddings_pickle_path', pkl,
+                   '--model_dir', str(tmp_path / "model"), '--save_eval_sessions_recommendations', '--save_results_each_n_evals', '1']
+    est = T.main(argv)
+    md = str(tmp_path / "model")
+    assert os.path.exists(os.path.join(md, "model.ckpt.pt"))
+    lines = open(os.path.join(md, "eval_stats_benchmarks.csv")).read().strip().splitlines()
+    assert len(lines) == 1 + 2 and 'hitrate_at_n_chameleon' in lines[0] and 'mrr_at_n' in lines[0]       # 5 files, chunks of 2 -> 2 evals
+    recs = [json.loads(x) for x in open(os.path.join(md, "eval_chameleon_recommendations_log.json"))]
+    assert len(recs) == 80 and len(recs[0]['predicted_item_ids'][0]) == 13 and recs[-1]['eval_hour_id'] == 1
+    negs = [json.loads(x) for x in open(os.path.join(md, "eval_sessions_negative_samples.json"))]
+    assert len(negs) == 80
+    assert est.global_step == 8                                  # 4 training files x 40 sessions / batch 24 -> 2 steps each
+    assert len(T.eval_sessions_metrics_log) == 2 and 0.0 <= T.eval_sessions_metrics_log[-1]['hitrate_at_n'] <= 1.0
