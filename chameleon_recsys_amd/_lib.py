@@ -2,7 +2,7 @@
 missing or a kernel call fails this raises - the product path never silently degrades."""
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchameleon_nar.so")
@@ -24,7 +24,7 @@ _SIGNATURES = {
     "cham_gemm_f32": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int,
                               P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_set_variant": (None, [c_int]),
-    "cham_combine_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "cham_combine_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_long, c_long, P]),
     "cham_combine_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cham_combine_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P]),

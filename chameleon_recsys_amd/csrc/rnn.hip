@@ -9,14 +9,17 @@
 // independent across sessions, so one workgroup owns 32 session rows for ALL time steps - no inter-workgroup
 // synchronisation, h lives in LDS, h*W_h runs on v_mfma_f32_32x32x2_f32 (W_h streamed from L2: 512 KB at
 // H=256), gates / tanh / sigmoid / length masking fused into the MFMA epilogue.  Hidden size is padded to a
-// multiple of 128 (H=255 -> 256); pad lanes stay exactly 0 (zero weights, tanh(0)=0).
+// multiple of 128 (H=255 -> 256); pad lanes stay exactly 0 (zero weights, tanh(0)=0).  Each workgroup runs Hp/32 waves
+// (one 32-wide hidden tile per wave, two waves per SIMD at Hp=256): when the recurrence shares its CUs with the big CAR
+// GEMM on the other stream lane, its share of the MFMA issue slots scales with its wave count (4 waves: 4.8 ms, see
+// profiles/r01_notes.md).
 #include "common.h"
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // NT = 32-wide hidden tiles per wave (Hp = 128*NT)
-template <int NT>
-__global__ __launch_bounds__(256) void k_ugrnn_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
+template <int NT, int NTW>
+__global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
                                                    const int* __restrict__ seq_len, int B, int T,
                                                    float* __restrict__ out, float* __restrict__ hprev,
                                                    float* __restrict__ G, float* __restrict__ Cc) {
@@ -25,13 +28,13 @@ __global__ __launch_bounds__(256) void k_ugrnn_fwd(const float* __restrict__ xpr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.x * 32;
     const int fl = lane & 31, kl = lane >> 5;
-    for (int i = threadIdx.x; i < 32 * LDH; i += 256) hL[i] = 0.f;
+    for (int i = threadIdx.x; i < 32 * LDH; i += blockDim.x) hL[i] = 0.f;
     __syncthreads();
-    const int hid0 = wave * (Hp / 4);
+    const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
     for (int t = 0; t < T; ++t) {
-        floatx16 ag[NT], ac[NT];
+        floatx16 ag[NTW], ac[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ag[j][e] = 0.f; ac[j][e] = 0.f; }
         const float* hrow = hL + fl * LDH + kl;
@@ -41,14 +44,14 @@ __global__ __launch_bounds__(256) void k_ugrnn_fwd(const float* __restrict__ xpr
             const float a = hrow[k];
             const float* w = wg + (size_t)k * H2;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int j = 0; j < NTW; ++j) {
                 ag[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ag[j], 0, 0, 0);
                 ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], ac[j], 0, 0, 0);
             }
         }
         __syncthreads();                                   // every wave finished reading h_{t-1}
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(256) void k_ugrnn_fwd(const float* __restrict__ xpr
 
 // backward through time.  dout = dL/d(out) [B,T,Hp];  writes dxproj [B,T,2Hp] (= dL/d[g_act, c_act]).
 // WhT = transpose(Wh) [2Hp, Hp].
-template <int NT>
-__global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
+template <int NT, int NTW>
+__global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
                                                    const int* __restrict__ seq_len, int B, int T,
                                                    const float* __restrict__ hprev, const float* __restrict__ G,
                                                    const float* __restrict__ Cc, float* __restrict__ dxproj) {
@@ -86,16 +89,16 @@ __global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dou
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.x * 32;
     const int fl = lane & 31, kl = lane >> 5;
-    const int hid0 = wave * (Hp / 4);
-    floatx16 carry[NT];                                     // dL/dh_t flowing to step t (accumulator layout)
+    const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
+    floatx16 carry[NTW];                                     // dL/dh_t flowing to step t (accumulator layout)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) carry[j][e] = 0.f;
     for (int t = T - 1; t >= 0; --t) {
-        floatx16 direct[NT];
+        floatx16 direct[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dou
             }
         }
         __syncthreads();
-        floatx16 acc[NT];
+        floatx16 acc[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const float* zrow = dzL + fl * LDZ + kl;
@@ -133,10 +136,10 @@ __global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dou
             const float a = zrow[k];
             const float* w = wt + (size_t)k * Hp;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256) void k_ugrnn_bwd(const float* __restrict__ dou
 // xproj [B,T,3Hp] = x W_x + b with column blocks r | u | c;  Wh = W_gh [Hp,2Hp] followed by W_ch [Hp,Hp].
 // Same ownership as the UGRNN kernel (one workgroup = 32 sessions, all time steps, h in LDS); the candidate needs
 // r*h of ALL hidden units, so a step is two MFMA phases with an LDS exchange of r*h in between.
-template <int NT>
-__global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
+template <int NT, int NTW>
+__global__ __launch_bounds__(256 * NT / NTW) void k_gru_fwd(const float* __restrict__ xproj, const float* __restrict__ Wh,
                                                  const int* __restrict__ seq_len, int B, int T,
                                                  float* __restrict__ out, float* __restrict__ hprev, float* __restrict__ U,
                                                  float* __restrict__ Cc, float* __restrict__ R, float* __restrict__ RH) {
@@ -169,13 +172,13 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
     const int fl = lane & 31, kl = lane >> 5;
     const float* Wgh = Wh;
     const float* Wch = Wh + (size_t)Hp * H2;
-    for (int i = threadIdx.x; i < 64 * LDH; i += 256) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < 64 * LDH; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
-    const int hid0 = wave * (Hp / 4);
+    const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
     for (int t = 0; t < T; ++t) {
-        floatx16 ar[NT], au[NT];
+        floatx16 ar[NTW], au[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ar[j][e] = 0.f; au[j][e] = 0.f; }
         {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
                 const float a = hrow[k];
                 const float* w = wg + (size_t)k * H2;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int j = 0; j < NTW; ++j) {
                     ar[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ar[j], 0, 0, 0);
                     au[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], au[j], 0, 0, 0);
                 }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
         }
         // gates; r*h -> LDS (each wave writes its own hidden columns of rhL; hL is only read here)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
             }
         }
         __syncthreads();
-        floatx16 ac[NT];
+        floatx16 ac[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) ac[j][e] = 0.f;
         {
@@ -224,12 +227,12 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
                 const float a = rrow[k];
                 const float* w = wc + (size_t)k * Hp;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ac[j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ac[j], 0, 0, 0);
             }
         }
         __syncthreads();                                   // all reads of hL / rhL of this step are done
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ xproj
 }
 
 // WhT = [ transpose(W_gh) [2Hp,Hp] ; transpose(W_ch) [Hp,Hp] ].  dxproj [B,T,3Hp] = dL/d[r_act, u_act, c_act].
-template <int NT>
-__global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
+template <int NT, int NTW>
+__global__ __launch_bounds__(256 * NT / NTW) void k_gru_bwd(const float* __restrict__ dout, const float* __restrict__ WhT,
                                                  const int* __restrict__ seq_len, int B, int T,
                                                  const float* __restrict__ hprev, const float* __restrict__ U,
                                                  const float* __restrict__ Cc, const float* __restrict__ R,
@@ -266,18 +269,18 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.x * 32;
     const int fl = lane & 31, kl = lane >> 5;
-    const int hid0 = wave * (Hp / 4);
+    const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
     const float* WghT = WhT;
     const float* WchT = WhT + (size_t)H2 * Hp;
-    floatx16 carry[NT];
+    floatx16 carry[NTW];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) carry[j][e] = 0.f;
     for (int t = T - 1; t >= 0; --t) {
-        floatx16 direct[NT], duz[NT];
+        floatx16 direct[NTW], duz[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -299,9 +302,9 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout,
         }
         __syncthreads();
         // d(r*h) = dz_c * W_ch^T
-        floatx16 acc[NT];
+        floatx16 acc[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         {
@@ -312,11 +315,11 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout,
                 const float a = zrow[k];
                 const float* w = wt + (size_t)k * Hp;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout,
         __syncthreads();
         // dh_{t-1} += [dz_r, dz_u] * W_gh^T
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         {
@@ -352,11 +355,11 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ dout,
                 const float a = zrow[k];
                 const float* w = wt + (size_t)k * Hp;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
@@ -397,10 +400,10 @@ static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_
                             float* G, float* Cc, hipStream_t st) {
     size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
     if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
-    auto kern = k_ugrnn_fwd<NT>;
+    auto kern = k_ugrnn_fwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc);
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -409,10 +412,10 @@ static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_
                             const float* G, const float* Cc, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
     if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
-    auto kern = k_ugrnn_bwd<NT>;
+    auto kern = k_ugrnn_bwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj);
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -422,10 +425,10 @@ static int launch_gru_fwd(const float* xproj, const float* Wh, const int* seq_le
                           float* U, float* Cc, float* R, float* RH, hipStream_t st) {
     size_t smem = (size_t)64 * (128 * NT + 1) * sizeof(float);
     if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
-    auto kern = k_gru_fwd<NT>;
+    auto kern = k_gru_fwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, U, Cc, R, RH);
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, xproj, Wh, seq_len, B, T, out, hprev, U, Cc, R, RH);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -434,10 +437,10 @@ static int launch_gru_bwd(const float* dout, const float* WhT, const int* seq_le
                           const float* U, const float* Cc, const float* R, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (384 * NT + 2) * sizeof(float);
     if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
-    auto kern = k_gru_bwd<NT>;
+    auto kern = k_gru_bwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256), smem, st, dout, WhT, seq_len, B, T, hprev, U, Cc, R, dxproj);
+    hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, dout, WhT, seq_len, B, T, hprev, U, Cc, R, dxproj);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -23,8 +23,8 @@ __device__ __forceinline__ int cand_vrow(int bt, int c, int BT, int N, int pmax,
 // Z1[row,:] = leaky(U[u,:] + V[v,:])
 __global__ __launch_bounds__(256) void k_combine_fwd(const float* __restrict__ U, const float* __restrict__ V, int C,
                                                      int BT, int N, int pmax, const int* __restrict__ neg_slot,
-                                                     float* __restrict__ Z1) {
-    const int row = blockIdx.x;
+                                                     float* __restrict__ Z1, int row_begin) {
+    const int row = row_begin + blockIdx.x;
     int u, v;
     if (row < BT) { u = row; v = row; }
     else {
@@ -280,10 +280,12 @@ __global__ __launch_bounds__(256) void k_rank_items(const float* __restrict__ pr
 
 // ---------------------------------------------------------------------------------------------------
 extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot,
-                                float* Z1, void* stream) {
+                                float* Z1, long row_begin, long row_count, void* stream) {
     if (!U || !V || !neg_slot || !Z1 || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
     const long rows = (long)BT + (long)BT * (N + 1);
-    hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot, Z1);
+    if (row_begin < 0 || row_count <= 0 || row_begin + row_count > rows) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)row_count), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
+                       Z1, (int)row_begin);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -467,9 +467,9 @@ class NARModuleModel:
         # factorised PreCAR: U (per click) + V (per unique item row), then CAR
         rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
         rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
-        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), s), "cham_combine_fwd")
         pl.seq_len.copy_(d['seq_len']); pl.mask.copy_(d['mask'])
-        # CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
+        # PreCAR combine + CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
+        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
         rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.fork()
         with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
@@ -482,7 +482,8 @@ class NARModuleModel:
                 x, ldx, K = pl.rnn_out[l], Hp, Hp
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
             rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
-        # ... the dominant GEMM: CAR layer 2 on the B*T*(1+N) candidate rows
+        # ... the candidate rows: PreCAR combine (HBM-bound) + the dominant GEMM, CAR layer 2 on the B*T*(1+N) rows
+        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
         rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.join()
         # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL

@@ -77,9 +77,11 @@ int cham_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, 
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
 
-/* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward */
+/* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward.
+ * rows [row_begin, row_begin+row_count) of the BT + BT*(1+N) CAR rows (the BT clicked-input rows come first: they are
+ * combined ahead of the candidates so that the recurrent branch can start early) */
 int cham_combine_fwd(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* Z1,
-                     void* stream);
+                     long row_begin, long row_count, void* stream);
 size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax);
 int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
                      float* workspace, size_t workspace_bytes, void* stream);

@@ -1,6 +1,8 @@
 """Manual tool (not a test): times the fp32 MFMA GEMM tile variants on the three dominant shapes of the G1 step.
 python -m tests.bench_gemm"""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from chameleon_recsys_amd import _lib
 from chameleon_recsys_amd._lib import ptr, check
