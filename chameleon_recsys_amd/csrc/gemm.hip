@@ -152,8 +152,58 @@ template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
     return 1.f;
 }
 
-// EPI: 0 = plain / accumulate (no bias, no act), 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref),
-//      5 = bias only, 6 = split-K partial store
+// Shared epilogue of the fp32 and bf16 kernels (the 32x32 MFMA C/D layout is dtype independent).
+// EPI: 0 = plain / accumulate, 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref), 5 = bias only,
+//      6 = split-K partial store
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
+                                              int split, int kl, int fl) {
+    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
+    // windows at the tile origin; offsets are tile-local, out-of-range elements get OOB_OFF
+    const int limM = p.M - m0, limN = p.N - n0;
+    float* cbase = (EPI == 6) ? p.partial + ((size_t)split * p.M + m0) * p.N + n0 : p.C + (size_t)m0 * p.ldc + n0;
+    const unsigned ldc = (EPI == 6) ? (unsigned)p.N : (unsigned)p.ldc;
+    const __amdgpu_buffer_rsrc_t cw = make_window(cbase);
+    const __amdgpu_buffer_rsrc_t dw = make_window((EPI == 3 || EPI == 4) ? p.dref + (size_t)m0 * p.ldr + n0 : p.C);
+    const __amdgpu_buffer_rsrc_t biasw = make_window((EPI == 1 || EPI == 2 || EPI == 5) ? p.bias + n0 : p.C);
+    const bool accum = (EPI == 0 || EPI == 3 || EPI == 4) && p.accumulate;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn0 + j * 32 + fl;
+            const bool cok = col < limN;
+            float bv = 0.f;
+            if (EPI == 1 || EPI == 2 || EPI == 5)
+                bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(biasw, cok ? (unsigned)col * 4u : OOB_OFF, 0, 0));
+            unsigned offs[16];
+            float aux[16], old[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const bool ok = cok && row < limM;
+                offs[e] = ok ? ((unsigned)row * ldc + (unsigned)col) * 4u : OOB_OFF;
+                if (EPI == 3 || EPI == 4)
+                    aux[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 4u : OOB_OFF, 0, 0));
+                if (EPI == 0 || EPI == 3 || EPI == 4)
+                    old[e] = accum ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cw, offs[e], 0, 0)) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e];
+                if (EPI == 1) v = act_fwd_c<ACT_LEAKY>(v + bv);
+                else if (EPI == 2) v = act_fwd_c<ACT_TANH>(v + bv);
+                else if (EPI == 5) v = v + bv;
+                else if (EPI == 3) v = v * act_bwd_c<ACT_LEAKY>(aux[e]) + old[e];
+                else if (EPI == 4) v = v * act_bwd_c<ACT_TANH>(aux[e]) + old[e];
+                else if (EPI == 0) v += old[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
+            }
+        }
+}
+
+// EPI: see gemm_epilogue
 template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
@@ -253,49 +303,224 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
-    // windows at the tile origin; offsets are tile-local, out-of-range elements get OOB_OFF
-    const int limM = p.M - m0, limN = p.N - n0;
-    float* cbase = (EPI == 6) ? p.partial + ((size_t)split * p.M + m0) * p.N + n0 : p.C + (size_t)m0 * p.ldc + n0;
-    const unsigned ldc = (EPI == 6) ? (unsigned)p.N : (unsigned)p.ldc;
-    const __amdgpu_buffer_rsrc_t cw = make_window(cbase);
-    const __amdgpu_buffer_rsrc_t dw = make_window((EPI == 3 || EPI == 4) ? p.dref + (size_t)m0 * p.ldr + n0 : p.C);
-    const __amdgpu_buffer_rsrc_t biasw = make_window((EPI == 1 || EPI == 2 || EPI == 5) ? p.bias + n0 : p.C);
-    const bool accum = (EPI == 0 || EPI == 3 || EPI == 4) && p.accumulate;
+    gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
+}
+
+
+// =====================================================================================================================
+// bf16-input variant (BASELINE config 3: "bf16 compute, fp32 master weights + fp32 softmax / loss / Adam").
+// Storage stays fp32 everywhere; operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while they are staged into LDS and
+// multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - 16x the fp32 matrix rate, so these GEMMs become
+// bound by moving the fp32 operands (HBM / L2), not by the matrix cores.  Same tiles, windows, swizzle and epilogues.
+// LDS image: [row][k] bf16, k contiguous, row stride BK + 8 (80 B at BK = 32: 5 x 16-B slots, coprime with the 16 slots of
+// a 256-B bank row -> every ds_read_b128 lane group hits 16 distinct slots); fragment = 8 consecutive k per lane:
+// A[i = lane&31][k = 8*(lane>>5) .. +7], B[k = 8*(lane>>5) .. +7][j = lane&31].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 pack8(const u32x4& lo, const u32x4& hi) {
+    bf16x8 v;
+    v[0] = (__bf16)__uint_as_float(lo.x); v[1] = (__bf16)__uint_as_float(lo.y);
+    v[2] = (__bf16)__uint_as_float(lo.z); v[3] = (__bf16)__uint_as_float(lo.w);
+    v[4] = (__bf16)__uint_as_float(hi.x); v[5] = (__bf16)__uint_as_float(hi.y);
+    v[6] = (__bf16)__uint_as_float(hi.z); v[7] = (__bf16)__uint_as_float(hi.w);
+    return v;
+}
+__device__ __forceinline__ void mul4(u32x4& a, const u32x4& b) {
+    a.x = __float_as_uint(__uint_as_float(a.x) * __uint_as_float(b.x)); a.y = __float_as_uint(__uint_as_float(a.y) * __uint_as_float(b.y));
+    a.z = __float_as_uint(__uint_as_float(a.z) * __uint_as_float(b.z)); a.w = __float_as_uint(__uint_as_float(a.w) * __uint_as_float(b.w));
+}
+__device__ __forceinline__ unsigned comp(const u32x4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// One operand tile [BF x BK] staged as bf16.  XK: unit = 8 consecutive k of one row (2 float4).  !XK: unit = an 8(k) x 4(f)
+// block (8 float4 from 8 consecutive stored rows), transposed in registers into 4 x (8 bf16 along k).
+template <int BF, int BK, bool XK, int NTH, bool RS>
+struct TileLoaderBF {
+    static constexpr int LDK = BK + 8;
+    static constexpr int NU = XK ? BF * BK / 8 : (BK / 8) * (BF / 4);     // units in the tile
+    static constexpr int NV = (NU + NTH - 1) / NTH;                        // units per thread
+    static constexpr int NL = XK ? 2 : 8;                                  // float4 loads per unit
+    u32x4 r[NV][NL];
+    u32x4 sc[RS ? NV : 1][RS ? NL : 1];      // row-broadcast scale (only instantiated for the two GEMMs that use it)
+    unsigned off[NV];        // window-local byte offset of the unit's first float4 (OOB_OFF: free index out of range / no unit)
+    unsigned soff[NV];
+    int k8[NV];              // tile-local k of the unit's first element
+    unsigned ldb4;           // byte stride between the unit's float4s (!XK: one stored row; XK: 16)
+
+    __device__ __forceinline__ void init(int ld, int limF, int f0, int ldrs, int rs_div, bool has_rs) {
+        const int tid = threadIdx.x;
+        ldb4 = XK ? 16u : (unsigned)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = tid + i * NTH;
+            unsigned o; bool fok;
+            if (XK) {
+                const int fr = u / (BK / 8), kc = u % (BK / 8);
+                o = ((unsigned)fr * (unsigned)ld + (unsigned)kc * 8u) * 4u; k8[i] = kc * 8; fok = fr < limF;
+                soff[i] = has_rs ? ((unsigned)((f0 + fr) / rs_div) * (unsigned)ldrs + (unsigned)kc * 8u) * 4u : 0u;
+            } else {
+                const int kb = u / (BF / 4), f4 = u % (BF / 4);
+                o = ((unsigned)(kb * 8) * (unsigned)ld + (unsigned)f4 * 4u) * 4u; k8[i] = kb * 8; fok = f4 * 4 < limF;
+                soff[i] = 0u;
+            }
+            if (NU % NTH != 0 && u >= NU) fok = false;
+            off[i] = fok ? o : OOB_OFF;
+        }
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t win, int limK) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int kk = k8[i] + (XK ? 4 * j : j);
+                const unsigned o = (off[i] != OOB_OFF && kk < limK) ? off[i] + (unsigned)j * ldb4 : OOB_OFF;
+                r[i][j] = __builtin_amdgcn_raw_buffer_load_b128(win, o, 0, 0);
+            }
+    }
+    __device__ __forceinline__ void load_scale_xk(__amdgpu_buffer_rsrc_t rsw, int k0, int limK) {
+        if constexpr (RS) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const unsigned o = (off[i] != OOB_OFF && k8[i] + 4 * j < limK) ? soff[i] + 16u * j : OOB_OFF;
+                    sc[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o, k0 * 4, 0);
+                }
+        }
+    }
+    __device__ __forceinline__ void load_scale_fk(__amdgpu_buffer_rsrc_t rsw, int krow0, int f0, int ldrs, int rs_div, int limK) {
+        if constexpr (RS) {
+            const int tid = threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int u = tid + i * NTH;
+                const int f4 = u % (BF / 4);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const unsigned o = ((unsigned)((krow0 + k8[i] + j) / rs_div) * (unsigned)ldrs + (unsigned)(f0 + f4 * 4)) * 4u;
+                    sc[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (off[i] != OOB_OFF && k8[i] + j < limK) ? o : OOB_OFF, 0, 0);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void apply_scale() {
+        if constexpr (RS) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int j = 0; j < NL; ++j) mul4(r[i][j], sc[i][j]);
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = tid + i * NTH;
+            if (NU % NTH != 0 && u >= NU) continue;
+            if (XK) {
+                const int fr = u / (BK / 8), kc = u % (BK / 8);
+                *reinterpret_cast<bf16x8*>(S + fr * LDK + kc * 8) = pack8(r[i][0], r[i][1]);
+            } else {
+                const int kb = u / (BF / 4), f4 = u % (BF / 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)__uint_as_float(comp(r[i][j], c));
+                    *reinterpret_cast<bf16x8*>(S + (f4 * 4 + c) * LDK + kb * 8) = v;
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool RS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
+    using LA = TileLoaderBF<BM, BK, AK, NTH, RS>;
+    using LB = TileLoaderBF<BN, BK, BKC, NTH, false>;
+    constexpr int LDK = BK + 8;
+    constexpr int ASZ = BM * LDK, BSZ = BN * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);      // [2][BM][LDK]
+    __bf16* Bs = As + 2 * ASZ;                         // [2][BN][LDK]
+
+    const int nwg = p.nbm * p.nbn;
+    const int id = blockIdx.x;
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
+    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+    floatx16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn0 + j * 32 + fl;
-            const bool cok = col < limN;
-            float bv = 0.f;
-            if (EPI == 1 || EPI == 2 || EPI == 5)
-                bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(biasw, cok ? (unsigned)col * 4u : OOB_OFF, 0, 0));
-            unsigned offs[16];
-            float aux[16], old[16];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
-                const bool ok = cok && row < limM;
-                offs[e] = ok ? ((unsigned)row * ldc + (unsigned)col) * 4u : OOB_OFF;
-                if (EPI == 3 || EPI == 4)
-                    aux[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 4u : OOB_OFF, 0, 0));
-                if (EPI == 0 || EPI == 3 || EPI == 4)
-                    old[e] = accum ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cw, offs[e], 0, 0)) : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e];
-                if (EPI == 1) v = act_fwd_c<ACT_LEAKY>(v + bv);
-                else if (EPI == 2) v = act_fwd_c<ACT_TANH>(v + bv);
-                else if (EPI == 5) v = v + bv;
-                else if (EPI == 3) v = v * act_bwd_c<ACT_LEAKY>(aux[e]) + old[e];
-                else if (EPI == 4) v = v * act_bwd_c<ACT_TANH>(aux[e]) + old[e];
-                else if (EPI == 0) v += old[e];
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const char* aw = reinterpret_cast<const char*>(p.A) + (AK ? ((size_t)m0 * p.lda + kbeg) : ((size_t)kbeg * p.lda + m0)) * 4;
+    const char* bw = reinterpret_cast<const char*>(p.B) + (BKC ? ((size_t)n0 * p.ldb + kbeg) : ((size_t)kbeg * p.ldb + n0)) * 4;
+    const size_t astep = (AK ? (size_t)BK : (size_t)BK * p.lda) * 4, bstep = (BKC ? (size_t)BK : (size_t)BK * p.ldb) * 4;
+    constexpr bool has_rs = RS;
+    const __amdgpu_buffer_rsrc_t rsw = make_window(p.rs);
+
+    LA la; LB lb;
+    la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, has_rs);
+    lb.init(p.ldb, p.N - n0, n0, 0, 1, false);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(make_window(aw), kend - kbeg);
+        lb.load(make_window(bw), kend - kbeg);
+        if constexpr (RS) {
+            if (AK) la.load_scale_xk(rsw, kbeg, kend - kbeg);
+            else la.load_scale_fk(rsw, kbeg, m0, p.ldrs, p.rs_div, kend - kbeg);
+            la.apply_scale();
+        }
+        la.store(As); lb.store(Bs);
+    }
+    __syncthreads();
+    const int kl = lane >> 5, fl = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            aw += astep; bw += bstep;
+            la.load(make_window(aw), kend - k0);
+            lb.load(make_window(bw), kend - k0);
+            if constexpr (RS) {
+                if (AK) la.load_scale_xk(rsw, k0, kend - k0);
+                else la.load_scale_fk(rsw, k0, m0, p.ldrs, p.rs_div, kend - k0);
             }
         }
+        const __bf16* Ac = As + cur * ASZ + (wm0 + fl) * LDK + 8 * kl;
+        const __bf16* Bc = Bs + cur * BSZ + (wn0 + fl) * LDK + 8 * kl;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ac + i * 32 * LDK + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bc + j * 32 * LDK + kk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            if constexpr (RS) la.apply_scale();
+            la.store(As + (cur ^ 1) * ASZ);
+            lb.store(Bs + (cur ^ 1) * BSZ);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
 // fixed-order reduction of split-K partials (+ the generic epilogue)
@@ -313,31 +538,53 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool BF16>
 static int launch_epi(GemmParams& p, hipStream_t st) {
-    using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
-    using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
-    const size_t smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>;
+    size_t smem;
+    const void* kern;
+    if (BF16) {
+        smem = (size_t)2 * (BM + BN) * (BK + 8) * 2;
+        // the row-broadcast scale only ever accompanies the scorer's first layer (bias+leaky, NN) and its split-K wgrad (TN)
+        constexpr bool RSI = (EPI == 1 && AK && !BKC) || (EPI == 6 && !AK && !BKC);
+        if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
+        if (RSI && p.rs != nullptr) {
+            auto k = gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, RSI>;
+            static bool done_rs = false;
+            if (!done_rs) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                    return -CHAM_ERR_LAUNCH;
+                done_rs = true;
+            }
+            hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(WM * WN * 64), smem, st, p);
+            CHAM_CHECK_LAUNCH();
+            return CHAM_OK;
+        }
+        kern = reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>);
+    } else {
+        using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
+        using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
+        smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
+        kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>);
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -CHAM_ERR_LAUNCH;
         attr_done = true;
     }
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
+    if (BF16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>), grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, bool BF16 = false>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
     int rc;
     if (p.splits > 1) {
-        rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
+        rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6, BF16>(p, st);
         if (rc != CHAM_OK) return rc;
         const size_t n = (size_t)p.M * p.N;
         int blocks = (int)((n + 255) / 256);
@@ -348,17 +595,17 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     }
     if (p.dref) {
         if (p.bias || p.act != ACT_NONE) return -CHAM_ERR_ARG;
-        if (p.dact == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3>(p, st);
-        if (p.dact == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4>(p, st);
+        if (p.dact == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3, BF16>(p, st);
+        if (p.dact == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4, BF16>(p, st);
         return -CHAM_ERR_ARG;
     }
     if (p.bias || p.act != ACT_NONE) {
         if (!p.bias || p.accumulate) return -CHAM_ERR_ARG;       // every activated layer of the model has a bias
-        if (p.act == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1>(p, st);
-        if (p.act == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2>(p, st);
-        return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5>(p, st);
+        if (p.act == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1, BF16>(p, st);
+        if (p.act == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2, BF16>(p, st);
+        return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5, BF16>(p, st);
     }
-    return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0>(p, st);
+    return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0, BF16>(p, st);
 }
 
 static int g_variant = -1;     // -1 = automatic
@@ -386,7 +633,44 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
     return launch_cfg<256, 32, 4, 1, 16, AK, BKC>(p, st);
 }
 
+template <bool AK, bool BKC>
+static int launch_by_shape_bf16(GemmParams& p, hipStream_t st) {
+    if (p.N > 64) {
+        if ((long)p.M * p.N >= (1L << 20)) return launch_cfg<256, 128, 4, 2, 32, AK, BKC, true>(p, st);
+        return launch_cfg<128, 128, 2, 2, 32, AK, BKC, true>(p, st);
+    }
+    if (p.N > 32) return launch_cfg<256, 64, 4, 1, 32, AK, BKC, true>(p, st);
+    return launch_cfg<256, 32, 4, 1, 32, AK, BKC, true>(p, st);
+}
+
+static int gemm_dispatch(int precision, const float* A, int lda, int transA, const float* B, int ldb, int transB,
+                         float* C, int ldc, int M, int N, int K, const float* bias, int act, const float* dref, int ldr, int dact,
+                         const float* rowscale, int ldrs, int rs_div, int accumulate, float* workspace, size_t workspace_bytes,
+                         int splits_hint, void* stream);
+
 extern "C" int cham_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB,
+                             float* C, int ldc, int M, int N, int K,
+                             const float* bias, int act,
+                             const float* dref, int ldr, int dact,
+                             const float* rowscale, int ldrs, int rs_div,
+                             int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                             void* stream) {
+    return gemm_dispatch(0, A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, dref, ldr, dact, rowscale, ldrs, rs_div,
+                         accumulate, workspace, workspace_bytes, splits_hint, stream);
+}
+// same contract, operands rounded to bf16 on the fly, fp32 accumulate / epilogue / output
+extern "C" int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb, int transB,
+                              float* C, int ldc, int M, int N, int K,
+                              const float* bias, int act,
+                              const float* dref, int ldr, int dact,
+                              const float* rowscale, int ldrs, int rs_div,
+                              int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                              void* stream) {
+    return gemm_dispatch(1, A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, dref, ldr, dact, rowscale, ldrs, rs_div,
+                         accumulate, workspace, workspace_bytes, splits_hint, stream);
+}
+
+static int gemm_dispatch(int precision, const float* A, int lda, int transA, const float* B, int ldb, int transB,
                              float* C, int ldc, int M, int N, int K,
                              const float* bias, int act,
                              const float* dref, int ldr, int dact,
@@ -431,6 +715,12 @@ extern "C" int cham_gemm_f32(const float* A, int lda, int transA, const float* B
     p.splits = (K + kchunk - 1) / kchunk;
     if (p.splits < 1) p.splits = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (precision == 1) {
+        if (!transA && !transB) return launch_by_shape_bf16<true, false>(p, st);
+        if (!transA && transB) return launch_by_shape_bf16<true, true>(p, st);
+        if (transA && !transB) return launch_by_shape_bf16<false, false>(p, st);
+        return -CHAM_ERR_ARG;
+    }
     if (!transA && !transB) return launch_by_shape<true, false>(p, st);
     if (!transA && transB) return launch_by_shape<true, true>(p, st);
     if (transA && !transB) return launch_by_shape<false, false>(p, st);

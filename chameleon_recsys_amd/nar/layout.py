@@ -153,7 +153,7 @@ class ParamLayout:
             e.offset = off
             off += e.size
             self.entries[e.name] = e
-        self.total = off
+        self.total = ceil_to(off, 256)                          # pad: splits evenly over 1..64 data-parallel ranks, float4 slices
         self.n_reg = sum(e.size for e in ents if e.reg)
         self.emb_end = sum(e.size for e in emb)                 # embedding-gradient region [0, emb_end)
         # regularised entries must be a prefix

@@ -105,6 +105,11 @@ class NARRuntime:
         self.v = torch.zeros_like(self.flat)
         self.grads = torch.zeros_like(self.flat)
         self.global_step = 0
+        # 'f32': exact fp32 MFMA (BASELINE config 2, the default); 'bf16': operands of every Dense / matmul rounded to bf16 on
+        # the fly, fp32 accumulation, fp32 storage / softmax / loss / Adam (BASELINE config 3)
+        self.gemm_dtype = params.get('gemm_dtype', 'f32')
+        if self.gemm_dtype not in ('f32', 'bf16'):
+            raise ValueError("gemm_dtype must be 'f32' or 'bf16'")
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -134,7 +139,7 @@ class NARRuntime:
         self._plans = {}
         self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
         # data-parallel context (set by parallel.DataParallelNAR)
-        self.dp_rank, self.dp_world, self.dp_allreduce = 0, 1, None
+        self.dp_rank, self.dp_world, self.dp_allreduce, self.dp_sharded = 0, 1, None, None
 
     # ---- views into the flat buffers
     def view(self, flat, name):
@@ -173,7 +178,7 @@ class NARRuntime:
 
     # ---- thin kernel wrappers -------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
-             dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1):
+             dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False):
         ws = None
         if splits != 1:
             ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
@@ -181,7 +186,8 @@ class NARRuntime:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()       # torch's current stream == the stream the kernel is launched on (_stream())
-        check(self.lib.cham_gemm_f32(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
+        fn = self.lib.cham_gemm_bf16 if (self.gemm_dtype == 'bf16' and not force_f32) else self.lib.cham_gemm_f32
+        check(fn(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
                                      ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
                                      ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
         if prof is not None:
@@ -586,9 +592,10 @@ class NARModuleModel:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, NGH, NGH, NGH, Hp, transB=1)
                 x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
                 rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, NGH, BT, ldx, NGH, NGH, transA=1, splits=0)
-                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, NGH, 2 * Hp, transA=1, splits=0)
+                # recurrent weights: their forward product runs in the fp32 time-step kernel -> fp32 wgrad in every mode
+                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, NGH, 2 * Hp, transA=1, splits=0, force_f32=True)
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
-                    rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BT, Hp, NGH, Hp, transA=1, splits=0)
+                    rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BT, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
                 rt.colsum(pl.dxproj, NGH, BT, NGH, g('rnn%d/b' % l))
             # CAR layer-2 weight gradient over ALL rows (needs dZ2 of the clicked rows from just above)
             rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
@@ -618,13 +625,22 @@ class NARModuleModel:
     def apply_gradients(self):
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
         rt, L = self.rt, self.rt.layout
-        if rt.dp_allreduce is not None:
-            rt.dp_allreduce(rt.grads)
         rt.global_step += 1
         t = rt.global_step
         lr_t = self.lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
-        check(rt.lib.cham_adam_tf(ptr(rt.flat), ptr(rt.grads), ptr(rt.m), ptr(rt.v), L.total, L.n_reg,
-                                  float(self.reg_weight_decay), float(lr_t), 0.9, 0.999, 1e-8, _stream()), "cham_adam_tf")
+
+        def adam(a, b, grads, g_off):       # Adam on the parameter range [a, b); grads[g_off + i] pairs with flat[a + i]
+            n_reg = min(max(L.n_reg - a, 0), b - a)
+            check(rt.lib.cham_adam_tf(rt.flat.data_ptr() + 4 * a, grads.data_ptr() + 4 * g_off, rt.m.data_ptr() + 4 * a,
+                                      rt.v.data_ptr() + 4 * a, b - a, n_reg, float(self.reg_weight_decay), float(lr_t),
+                                      0.9, 0.999, 1e-8, _stream()), "cham_adam_tf")
+
+        if rt.dp_sharded is not None:       # reduce-scatter -> Adam on this rank's slice -> all-gather (parallel.py)
+            rt.dp_sharded(rt.grads, rt.flat, adam)
+            return
+        if rt.dp_allreduce is not None:
+            rt.dp_allreduce(rt.grads)
+        adam(0, L.total, rt.grads, 0)
 
     def train_step_microbatched(self, features, labels, micro_sessions, global_features=None, global_labels=None, row_begin=0):
         """One optimizer step over the batch processed as row shards of ``micro_sessions`` sessions (activations of the

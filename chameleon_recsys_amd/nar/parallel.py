@@ -29,22 +29,54 @@ def slice_batch(features, labels, begin, end):
 
 class DataParallelNAR:
     """Wraps a NARModuleModel: ``upload(global_features, global_labels)`` -> this rank's device batch;
-    gradients are all-reduced (SUM - the local loss is already divided by the GLOBAL sum(mask))."""
+    gradients are summed over ranks (the local loss is already divided by the GLOBAL sum(mask)).
 
-    def __init__(self, model, process_group=None):
+    mode "allreduce" (default): ONE all-reduce of the flat gradient buffer, every rank runs the full Adam.
+    mode "sharded" (env CHAM_DP_MODE=sharded; the large-catalog layout): reduce-scatter of the flat gradients, each rank runs
+    TF-Adam on its contiguous 1/world slice of (weights, m, v) - the embedding tables are >90 % of it - and the updated
+    slices are all-gathered.  Same result bit for bit (Adam is elementwise); optimizer HBM traffic per rank / world."""
+
+    def __init__(self, model, process_group=None, mode=None):
+        import os
         self.model = model
         self.pg = process_group
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.mode = mode or os.environ.get("CHAM_DP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "sharded"):
+            raise ValueError("CHAM_DP_MODE must be 'allreduce' or 'sharded'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
         if self.world > 1:
-            rt.dp_allreduce = self._allreduce
+            if self.mode == "sharded":
+                if rt.flat.numel() % self.world:
+                    raise ValueError("flat parameter buffer (%d) does not split over %d ranks" % (rt.flat.numel(), self.world))
+                rt.dp_sharded = self._sharded_step
+                self._grad_slice = torch.empty(rt.flat.numel() // self.world, dtype=rt.flat.dtype, device=rt.flat.device)
+            else:
+                rt.dp_allreduce = self._allreduce
             # identical initial weights on every rank
             dist.broadcast(rt.flat, src=0, group=self.pg)
 
     def _allreduce(self, flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _sharded_step(self, flat_grads, flat_params, adam):
+        n = flat_params.numel() // self.world
+        a = self.rank * n
+        if dist.get_backend(self.pg) == "gloo":      # gloo has no reduce_scatter: same arithmetic through all_reduce (tests)
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            self._grad_slice.copy_(flat_grads[a:a + n])
+        else:
+            dist.reduce_scatter_tensor(self._grad_slice, flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+        adam(a, a + n, self._grad_slice, 0)
+        if dist.get_backend(self.pg) == "gloo":
+            parts = [torch.empty_like(self._grad_slice) for _ in range(self.world)]
+            dist.all_gather(parts, flat_params[a:a + n].clone(), group=self.pg)
+            for r, t in enumerate(parts):
+                flat_params[r * n:(r + 1) * n].copy_(t)
+        else:
+            dist.all_gather_into_tensor(flat_params, flat_params[a:a + n].clone(), group=self.pg)
 
     def upload(self, global_features, global_labels):
         n = np.asarray(global_features['item_clicked']).shape[0]

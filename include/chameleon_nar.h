@@ -74,6 +74,12 @@ int cham_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, 
                   int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
                   int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 
+/* bf16-compute variant (BASELINE config 3): identical contract and fp32 storage; op(A), op(B) are rounded to bf16
+ * (round-to-nearest-even) while staged into LDS, multiplied on v_mfma_f32_32x32x16_bf16, accumulated / finished in fp32 */
+int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
+                   int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
+                   int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
 

@@ -26,6 +26,24 @@ def get_embedding_size(unique_val_count, const_mult=8):
     return int(math.floor(const_mult * unique_val_count ** 0.25))
 
 
+class _BF16MatMul(torch.autograd.Function):
+    """a @ b with both operands rounded to bf16 (round-to-nearest-even) and fp32 accumulation, forward AND backward -
+    the arithmetic of the HIP path's bf16 GEMM mode (BASELINE config 3; csrc/gemm.hip gemm_bf16_kernel)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a.bfloat16().float() @ b.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gb = g.bfloat16().float()
+        ga = gb @ b.bfloat16().float().transpose(-1, -2)
+        a2 = a.bfloat16().float().reshape(-1, a.shape[-1])
+        return ga, a2.t() @ gb.reshape(-1, g.shape[-1])
+
+
 def _leaky(x):
     return torch.nn.functional.leaky_relu(x, 0.2)   # tf.nn.leaky_relu default alpha=0.2
 
@@ -162,6 +180,11 @@ class NAROracle:
         self.max_ohe = params.get('max_cardinality_for_ohe', 10)
         self.cell = params.get('rnn_cell', 'ugrnn')
         self.seed = params.get('tf_random_seed', 42)
+        self.gemm_dtype = params.get('gemm_dtype', 'f32')
+
+    def _mm(self, a, b):
+        """Dense / matmul of the graph; bf16-rounded operands when the bf16 compute mode is emulated."""
+        return _BF16MatMul.apply(a, b) if self.gemm_dtype == 'bf16' else a @ b
 
     # -- nar_model.py:730-773 get_features
     def _get_features(self, values, config, ignore, prefix):
@@ -248,9 +271,9 @@ class NAROracle:
 
     def _car(self, x):
         w = self.w
-        pre = _leaky(x @ w['PreCAR/kernel'] + w['PreCAR/bias'])        # nar_model.py:375-382
+        pre = _leaky(self._mm(x, w['PreCAR/kernel']) + w['PreCAR/bias'])        # nar_model.py:375-382
         self._tap('Z1', pre)
-        return torch.tanh(pre @ w['CAR/kernel'] + w['CAR/bias'])       # :384-403
+        return torch.tanh(self._mm(pre, w['CAR/kernel']) + w['CAR/bias'])       # :384-403
 
     # -- nar_model.py:1308-1361 (UGRNNCell / GRUCell semantics: SURVEY A.6)
     def _rnn(self, x, lengths):
@@ -263,18 +286,28 @@ class NAROracle:
             ys = []
             for t in range(T):
                 xt = out[:, t]
+                I = xt.shape[1]
                 if self.cell == 'ugrnn':
-                    z = torch.cat([xt, h], 1) @ self.w['rnn/%d/kernel' % l] + self.w['rnn/%d/bias' % l]
+                    K = self.w['rnn/%d/kernel' % l]
+                    # [x, h] W = x W_x + h W_h; the input half is one hoisted GEMM on the HIP path (bf16 mode rounds it), the
+                    # recurrent half runs in the fp32 time-step kernel
+                    z = (self._mm(xt, K[:I]) + h @ K[I:] if self.gemm_dtype == 'bf16' else torch.cat([xt, h], 1) @ K) \
+                        + self.w['rnn/%d/bias' % l]
                     g_act, c_act = z[:, :H], z[:, H:]
                     c = torch.tanh(c_act)
                     g = torch.sigmoid(g_act + 1.0)
                     hn = g * h + (1 - g) * c
                 else:
-                    ru = torch.sigmoid(torch.cat([xt, h], 1) @ self.w['rnn/%d/gates/kernel' % l]
-                                       + self.w['rnn/%d/gates/bias' % l])
+                    Kg, Kc = self.w['rnn/%d/gates/kernel' % l], self.w['rnn/%d/candidate/kernel' % l]
+                    if self.gemm_dtype == 'bf16':
+                        ru = torch.sigmoid(self._mm(xt, Kg[:I]) + h @ Kg[I:] + self.w['rnn/%d/gates/bias' % l])
+                    else:
+                        ru = torch.sigmoid(torch.cat([xt, h], 1) @ Kg + self.w['rnn/%d/gates/bias' % l])
                     r, u = ru[:, :H], ru[:, H:]
-                    c = torch.tanh(torch.cat([xt, r * h], 1) @ self.w['rnn/%d/candidate/kernel' % l]
-                                   + self.w['rnn/%d/candidate/bias' % l])
+                    if self.gemm_dtype == 'bf16':
+                        c = torch.tanh(self._mm(xt, Kc[:I]) + (r * h) @ Kc[I:] + self.w['rnn/%d/candidate/bias' % l])
+                    else:
+                        c = torch.tanh(torch.cat([xt, r * h], 1) @ Kc + self.w['rnn/%d/candidate/bias' % l])
                     hn = u * h + (1 - u) * c
                 valid = (t < lengths).unsqueeze(1)
                 ys.append(torch.where(valid, hn, torch.zeros_like(hn)))   # dynamic_rnn: zero output past length
@@ -284,11 +317,11 @@ class NAROracle:
 
     def _scorer(self, m):
         w = self.w
-        s1 = _leaky(m @ w['match1/kernel'] + w['match1/bias'])
-        s2 = _leaky(s1 @ w['match2/kernel'] + w['match2/bias'])
-        s3 = _leaky(s2 @ w['match3/kernel'] + w['match3/bias'])
+        s1 = _leaky(self._mm(m, w['match1/kernel']) + w['match1/bias'])
+        s2 = _leaky(self._mm(s1, w['match2/kernel']) + w['match2/bias'])
+        s3 = _leaky(self._mm(s2, w['match3/kernel']) + w['match3/bias'])
         self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
-        return s3 @ w['match4/kernel'] + w['match4/bias']
+        return s3 @ w['match4/kernel'] + w['match4/bias']       # last layer: fused into the softmax kernel, fp32 in every mode
 
     def _tap(self, name, t):
         """Optional capture of leaky-ReLU outputs (tests use them to detect kink sign flips)."""
@@ -343,9 +376,9 @@ class NAROracle:
         x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364
         car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos), self._car(x_neg)                             # :374-405
         rnn_out = self._rnn(car_in, seq_len)                                                                      # :408
-        fc1 = _leaky(rnn_out @ self.w['FC1/kernel'] + self.w['FC1/bias'])                                        # :411
+        fc1 = _leaky(self._mm(rnn_out, self.w['FC1/kernel']) + self.w['FC1/bias'])                                        # :411
         self._tap('FC1', fc1)
-        pred = torch.tanh(fc1 @ self.w['FC2/kernel'] + self.w['FC2/bias'])                                       # :423
+        pred = torch.tanh(self._mm(fc1, self.w['FC2/kernel']) + self.w['FC2/bias'])                                       # :423
         s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
         s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500
         logits = torch.cat([s_pos, s_neg], 2)                                                                     # :511

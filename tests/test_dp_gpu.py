@@ -43,8 +43,8 @@ def _run(dp_world, rank, batches, p):
     return np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy()
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out_dir, mode):
+    os.environ.update(CHAM_DP_MODE=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p = _params()
@@ -54,9 +54,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_hip_training_equals_single_process(gpu, tmp_path):
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0, r1 = np.load(str(tmp_path / "rank0.npz")), np.load(str(tmp_path / "rank1.npz"))
     assert np.array_equal(r0['flat'], r1['flat']) and np.array_equal(r0['m'], r1['m'])      # replicas stay bit-identical
     assert np.allclose(r0['losses'], r1['losses'], atol=1e-7)

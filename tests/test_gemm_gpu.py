@@ -6,7 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, accumulate=0, splits=1, seed=0):
+def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, accumulate=0, splits=1, seed=0, bf16=False):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
     lib = _lib.load()
@@ -23,8 +23,12 @@ def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0
     Ae = A.double()
     if rowscale:
         Ae = Ae * rs_t.double()[torch.arange(A.shape[0]) // rs_div]
+    Be = B.double()
+    if bf16:      # operands rounded to bf16 (after the fp32 row-scale product), exact products, fp32-class accumulation
+        Ae = Ae.float().bfloat16().double()
+        Be = B.bfloat16().double()
     opA = Ae.t() if transA else Ae
-    opB = B.double().t() if transB else B.double()
+    opB = Be.t() if transB else Be
     R = opA @ opB
     if bias:
         R = R + bias_t.double()
@@ -42,7 +46,7 @@ def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0
     dref_t = ref_t.to(gpu) if dref else None
     drs = rs_t.to(gpu) if rowscale else None
     ws = torch.empty(32 << 20, dtype=torch.float32, device=gpu) if splits != 1 else None
-    rc = lib.cham_gemm_f32(ptr(dA), A.shape[1], transA, ptr(dB), B.shape[1], transB, ptr(dC), N, M, N, K, ptr(dbias), act,
+    rc = (lib.cham_gemm_bf16 if bf16 else lib.cham_gemm_f32)(ptr(dA), A.shape[1], transA, ptr(dB), B.shape[1], transB, ptr(dC), N, M, N, K, ptr(dbias), act,
                            ptr(dref_t), N, dact, ptr(drs), A.shape[1], rs_div, accumulate, ptr(ws),
                            (32 << 20) * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream)
     check(rc, "gemm")
@@ -92,3 +96,31 @@ def test_asymmetric_layout(gpu):
                             torch.cuda.current_stream().cuda_stream), "gemm")
     torch.cuda.synchronize()
     assert torch.equal(C, B)
+
+
+# ---- bf16-compute variant (BASELINE config 3): same contract, operands rounded to bf16 on the fly -------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 96), (77, 1024, 408), (1000, 64, 128), (513, 32, 64), (64, 72, 1024)])
+def test_bf16_nn(gpu, M, N, K):
+    assert _run(gpu, M, N, K, bf16=True) < 5e-5
+    assert _run(gpu, M, N, K, bias=True, act=1, bf16=True) < 5e-5
+    assert _run(gpu, M, N, K, bias=True, act=2, bf16=True) < 5e-5
+    assert _run(gpu, M, N, K, bias=True, bf16=True) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (259, 72, 1024), (1000, 408, 128), (123, 1024, 512), (400, 64, 32)])
+def test_bf16_nt_dgrad(gpu, M, N, K):
+    assert _run(gpu, M, N, K, transB=1, bf16=True) < 5e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=1, bf16=True) < 5e-5
+    assert _run(gpu, M, N, K, transB=1, dref=True, dact=2, accumulate=1, bf16=True) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 5000), (72, 1024, 777), (408, 128, 3001), (64, 32, 20000), (1024, 128, 4099)])
+def test_bf16_tn_wgrad_splitk(gpu, M, N, K):
+    assert _run(gpu, M, N, K, transA=1, bf16=True) < 1e-4
+    assert _run(gpu, M, N, K, transA=1, splits=0, bf16=True) < 1e-4
+    assert _run(gpu, M, N, K, transA=1, splits=7, bf16=True) < 1e-4
+
+
+def test_bf16_rowscale(gpu):
+    assert _run(gpu, 51 * 40, 128, 256, rowscale=51, bias=True, act=1, bf16=True) < 5e-5
+    assert _run(gpu, 256, 128, 51 * 40, transA=1, rowscale=51, splits=0, bf16=True) < 5e-5

@@ -186,3 +186,39 @@ def test_microbatched_step_equals_whole_batch_step(gpu):
     # first Adam step: dw = lr * g / (|g| + eps') is ill-conditioned where |g| ~ eps: compare the moments tightly, weights loosely
     assert float((m1.rt.m - m2.rt.m).abs().max()) < 2e-5 * float(m1.rt.m.abs().max()) + 1e-9
     assert float((m1.rt.flat - m2.rt.flat).abs().max()) < 2.1 * p['lr']
+
+
+def test_step_parity_bf16_compute_mode(gpu):
+    """BASELINE config 3 arithmetic: every Dense / matmul with bf16-rounded operands + fp32 accumulation (fp32 storage,
+    softmax, loss, Adam).  Checked against the oracle emulating exactly that rounding (forward AND backward); tolerances:
+    logits / loss 1e-3 (fp32 accumulation order only), gradients 2e-2 of the tensor's max (the HIP path rounds a few
+    gradient operands after summation where autograd rounds per row), and within 3e-2 of the fp32 oracle's loss."""
+    p = H.tiny_params(gemm_dtype='bf16')
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
+    f, l = batches[3]
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    model.feed_state(pop, buf)
+    model.forward(model.upload_batch(f, l))
+    out = model.outputs_numpy()
+    for v in orc.w.values():
+        v.grad = None
+    ref = orc.forward(f, l, buf, pop, 'train')
+    mask = ref['mask'].numpy()
+    assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
+    assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 2e-3
+    assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
+    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    from oracle.nar_oracle import NAROracle
+    ref32 = NAROracle(p32, weights=orc.weights_numpy()).forward(f, l, buf, pop, 'train')
+    assert abs(out['loss'][0] - float(ref32['total_loss'].detach())) < 3e-2
+    ref['xe_loss'].backward()
+    model.backward()
+    torch.cuda.synchronize()
+    g = model.rt.logical_grads()
+    for k, v in orc.w.items():
+        rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
+        scale = max(1e-6, float(np.abs(rg).max()))
+        assert float(np.abs(g[k] - rg).max()) < 2e-2 * scale + 2e-5, k
