@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--config", default="g1", choices=["g1", "tiny"])
     ap.add_argument("--length-dist", default="full", choices=["full", "g1"],
                     help="full: every session has seq_len clicks (no padded rows); g1: G1-like ragged lengths")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: exact fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16-rounded GEMM operands, fp32 accumulate/"
+                         "storage/softmax/loss/Adam (BASELINE configs[2] arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
@@ -104,6 +107,7 @@ def main():
     params = synthetic.default_params(cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'], batch_size=Bg, neg=cfg['neg'],
                                       neg_from_buffer=cfg['neg_from_buffer'], buffer_size=cfg['buffer'],
                                       for_norm=cfg['for_norm'], C=cfg['C'], H=cfg['H'], seed=args.seed)
+    params['gemm_dtype'] = args.dtype
     n_distinct = 8
     batches = synthetic.make_batches(n_distinct, Bg, cfg['seq_len'], cfg['n_items'], params['session_features_config'],
                                      seed=args.seed, length_dist=args.length_dist, sessions_per_hour=Bg * 2)
@@ -189,7 +193,7 @@ def main():
         out = {
             "metric": "NAR training sessions/sec", "value": round(Bg * args.steps / dt, 2), "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "G1-shape synthetic (BASELINE.json configs[1])" if args.config == "g1" else "G1-tiny synthetic",
                        "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
@@ -207,6 +211,12 @@ def main():
                          "all_gemm_tflops": round(fl_all / (ms_all * 1e-3) / 1e12, 2) if ms_all > 0 else 0.0,
                          "step_reference_dense_tflops": round(3 * dense_fwd / (ms_step * 1e-3) / 1e12, 2)},
         }
+        if args.dtype == "bf16":     # operands move as fp32, the matrix cores run 16x faster: the same launches are HBM/L2-bound
+            algo_bytes = out["roofline"]["algorithmic_bytes_per_launch"] or 0
+            gbs = algo_bytes / (ms_nn / max(1, n_nn) * 1e-3) / 1e9 if ms_nn > 0 else 0.0
+            out["roofline"].update(bound="hbm", kernel="gemm_bf16_kernel<256,128,4,2,32,true,false,2,false> = bf16-MFMA GEMM, NN, bias+tanh "
+                                   "(CAR layer 2 forward), all launches of a step", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
+                                   frac=round(gbs / 8000.0, 4), traffic=None, traffic_source=None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
         print(json.dumps(out), flush=True)
