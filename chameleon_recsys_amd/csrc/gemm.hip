@@ -152,6 +152,8 @@ template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
     return 1.f;
 }
 
+static int g_pipe = 1;          // software pipeline of the K loop (cham_gemm_set_variant(v + 100) turns it off for A/B runs)
+
 // Shared epilogue of the fp32 and bf16 kernels (the 32x32 MFMA C/D layout is dtype independent).
 // EPI: 0 = plain / accumulate, 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref), 5 = bias only,
 //      6 = split-K partial store
@@ -204,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx16 (&ac
 }
 
 // EPI: see gemm_epilogue
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
     using LA = TileLoader<BM, BK, AK, NTH>;
@@ -248,30 +250,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, has_rs);
     lb.init(p.ldb, p.N - n0, n0, 0, 1, false);
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        la.load(make_window(aw), kend - kbeg);
-        lb.load(make_window(bw), kend - kbeg);
+    // Software pipeline, prefetch distance 2: during the MFMAs of K-tile t the wave (1) writes tile t+1 - loaded one full tile
+    // ago, so its vmcnt wait is free - into the other LDS buffer and (2) issues the global loads of tile t+2 into the freed
+    // registers.  Every memory operation of the loop is in flight behind matrix work; the barrier at the end of a tile only
+    // collects stragglers (before: wait -> ds_write -> wait -> barrier -> ds_read sat exposed between two MFMA phases).
+    auto load_tile = [&](int t) {
+        const int k0 = kbeg + t * BK;
+        la.load(make_window(aw), kend - k0);
+        lb.load(make_window(bw), kend - k0);
         if (has_rs) {
-            if (AK) la.load_scale_xk(rsw, kbeg, kend - kbeg);
-            else la.load_scale_fk(rsw, kbeg, m0, p.ldrs, p.rs_div, kend - kbeg);
-            la.apply_scale();
+            if (AK) la.load_scale_xk(rsw, k0, kend - k0);
+            else la.load_scale_fk(rsw, k0, m0, p.ldrs, p.rs_div, kend - k0);
         }
+        aw += astep; bw += bstep;
+    };
+    if (nk > 0) {
+        load_tile(0);
+        if (has_rs) la.apply_scale();
         la.store(As); lb.store(Bs);
+        if (nk > 1) load_tile(1);
     }
     __syncthreads();
     const int kl = lane >> 5, fl = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            aw += astep; bw += bstep;
-            la.load(make_window(aw), kend - k0);
-            lb.load(make_window(bw), kend - k0);
-            if (has_rs) {
-                if (AK) la.load_scale_xk(rsw, k0, kend - k0);
-                else la.load_scale_fk(rsw, k0, m0, p.ldrs, p.rs_div, kend - k0);
-            }
-        }
         const float* Ac = As + cur * ASZ + wm0 + fl;
         const float* Bc = Bs + cur * BSZ + wn0 + fl;
         // fragment registers are double-buffered: the ds_reads of k-step kk+2 are issued before the MFMAs of kk
@@ -280,6 +282,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
         for (int i = 0; i < TM; ++i) a[0][i] = Ac[kl * LDA + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[0][j] = Bc[kl * LDB + j * 32];
+        if (PIPE && kt + 1 < nk) {        // tile kt+1: registers -> the LDS buffer every wave finished reading at the last barrier
+            if (has_rs) la.apply_scale();
+            la.store(As + (cur ^ 1) * ASZ);
+            lb.store(Bs + (cur ^ 1) * BSZ);
+            if (kt + 2 < nk) load_tile(kt + 2);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int c = (kk >> 1) & 1;
@@ -295,10 +303,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
+        if (!PIPE && kt + 1 < nk) {
             if (has_rs) la.apply_scale();
             la.store(As + (cur ^ 1) * ASZ);
             lb.store(Bs + (cur ^ 1) * BSZ);
+            if (kt + 2 < nk) load_tile(kt + 2);
         }
         __syncthreads();
     }
@@ -564,16 +573,18 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
         using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
         smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
-        kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>);
+        kern = g_pipe ? reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>)
+                      : reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[g_pipe]) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -CHAM_ERR_LAUNCH;
-        attr_done = true;
+        attr_done[g_pipe] = true;
     }
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
     if (BF16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI>), grid, dim3(WM * WN * 64), smem, st, p);
+    else if (g_pipe) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>), grid, dim3(WM * WN * 64), smem, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -609,7 +620,7 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 }
 
 static int g_variant = -1;     // -1 = automatic
-extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
+extern "C" void cham_gemm_set_variant(int v) { g_pipe = v >= 100 ? 0 : 1; g_variant = v >= 100 ? v - 100 : v; if (g_variant > 50) g_variant = -1; }
 
 template <bool AK, bool BKC>
 static int launch_by_shape(GemmParams& p, hipStream_t st) {

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restri
                                                            const float* __restrict__ b4, int BT, int N, float inv_tau,
                                                            const unsigned char* __restrict__ mask,
                                                            float* __restrict__ logits, float* __restrict__ probs,
-                                                           float* __restrict__ nll) {
+                                                           float* __restrict__ nll, float nov_factor,
+                                                           const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
+                                                           float* __restrict__ nov_aux /*[BT,3]*/) {
     const int lane = threadIdx.x & 63, bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BT) return;
     const int NC = N + 1;
@@ -217,10 +219,29 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restri
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int c = lane; c < NC; c += 64) probs[(size_t)bt * NC + c] *= inv;
+    // optional novelty regulariser (nar_model.py:673-683): - factor * sum_n softmax(s_neg / tau)_n * (-log2 pop_norm[neg_n]);
+    // the softmax over the negatives alone (:517) has its own max / normaliser; {max, sum, q.nov} are kept for the backward
+    float novterm = 0.f;
+    if (nov_factor > 0.f) {
+        float mxn = -INFINITY;
+        for (int c = lane; c < NC; c += 64)
+            if (c > 0) mxn = fmaxf(mxn, logits[(size_t)bt * NC + c] * inv_tau);
+        mxn = wave_max(mxn);
+        float sn = 0.f, acc = 0.f;
+        for (int c = lane; c < NC; c += 64)
+            if (c > 0) {
+                const float e = expf(logits[(size_t)bt * NC + c] * inv_tau - mxn);
+                sn += e;
+                acc += e * (-log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]));
+            }
+        sn = wave_sum(sn); acc = wave_sum(acc);
+        novterm = acc / sn;
+        if (lane == 0) { nov_aux[(size_t)bt * 3] = mxn; nov_aux[(size_t)bt * 3 + 1] = sn; nov_aux[(size_t)bt * 3 + 2] = novterm; }
+    }
     if (lane == 0) {
         // -log softmax_0 (log-softmax form of nar_model.py:660; identical wherever the reference is finite)
         const float z0 = logits[(size_t)bt * NC] * inv_tau;
-        nll[bt] = mask[bt] ? -((z0 - mx) - logf(sum)) : 0.f;
+        nll[bt] = mask[bt] ? -((z0 - mx) - logf(sum)) - nov_factor * novterm : 0.f;
     }
 }
 
@@ -229,12 +250,21 @@ template <int K3>
 __global__ __launch_bounds__(256) void k_score_softmax_bwd(const float* __restrict__ S3, const float* __restrict__ w4,
                                                            const float* __restrict__ probs, const unsigned char* __restrict__ mask,
                                                            int BT, int N, float scale /* 1/(tau*sum_mask) */,
-                                                           float* __restrict__ ds, float* __restrict__ dS3) {
+                                                           float* __restrict__ ds, float* __restrict__ dS3, float nov_factor,
+                                                           const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
+                                                           const float* __restrict__ logits, float inv_tau,
+                                                           const float* __restrict__ nov_aux) {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int NC = N + 1;
     if (row >= (size_t)BT * NC) return;
     const int bt = (int)(row / NC), c = (int)(row % NC);
-    const float g = mask[bt] ? (probs[row] - (c == 0 ? 1.f : 0.f)) * scale : 0.f;
+    float g = mask[bt] ? (probs[row] - (c == 0 ? 1.f : 0.f)) * scale : 0.f;
+    if (nov_factor > 0.f && c > 0 && mask[bt]) {
+        // d/ds_c of -factor * sum_n q_n nov_n with q = softmax(s_neg / tau): -factor/tau * q_c * (nov_c - q.nov)
+        const float q = expf(logits[row] * inv_tau - nov_aux[(size_t)bt * 3]) / nov_aux[(size_t)bt * 3 + 1];
+        const float nov_c = -log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]);
+        g -= nov_factor * scale * q * (nov_c - nov_aux[(size_t)bt * 3 + 2]);
+    }
     ds[row] = g;
     const float4* r = reinterpret_cast<const float4*>(S3 + row * K3);
     float4* o = reinterpret_cast<float4*>(dS3 + row * K3);
@@ -328,20 +358,26 @@ extern "C" int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, 
 }
 
 extern "C" int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
-                                      const uint8_t* mask, float* logits, float* probs, float* nll, void* stream) {
+                                      const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                                      const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream) {
     if (!S3 || !w4 || !b4 || !mask || !logits || !probs || !nll || K3 != 32 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !nov_aux)) return -CHAM_ERR_ARG;
     hipLaunchKernelGGL(k_score_softmax_fwd<32>, dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S3, w4, b4, BT, N,
-                       1.0f / tau, mask, logits, probs, nll);
+                       1.0f / tau, mask, logits, probs, nll, novelty_reg_factor, neg_ids, pop_norm, nov_aux);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
 
 extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
-                                      int BT, int N, float tau, float sum_mask, float* ds, float* dS3, void* stream) {
+                                      int BT, int N, float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor,
+                                      const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                      void* stream) {
     if (!S3 || !w4 || !probs || !mask || !ds || !dS3 || K3 != 32 || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
+    if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !logits || !nov_aux)) return -CHAM_ERR_ARG;
     const size_t rows = (size_t)BT * (N + 1);
     hipLaunchKernelGGL(k_score_softmax_bwd<32>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
-                       probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3);
+                       probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3, novelty_reg_factor, neg_ids, pop_norm, logits,
+                       1.0f / tau, nov_aux);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -279,6 +279,7 @@ class StepPlan:
         self.ds = f32(Rc)
         self.logits, self.probs = f32(BT, NC), f32(BT, NC)
         self.nll = f32(BT)
+        self.nov_aux = f32(BT, 3)
         self.mask = torch.zeros(BT, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
 
@@ -299,8 +300,7 @@ class NARModuleModel:
                  eval_cold_start=False, runtime=None, rnn_cell='ugrnn'):
         if elapsed_days_smooth_log_base != 1.3 or popularity_smooth_log_base != 2.0:
             raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
-        if novelty_reg_factor != 0.0:
-            raise NotImplementedError("novelty_reg_factor > 0 (nar_model.py:673-683) is not built yet")
+        self.novelty_reg_factor = float(novelty_reg_factor)
         self.is_training = (mode == ModeKeys.TRAIN)
         if self.is_training and keep_prob != 1.0:
             raise NotImplementedError("dropout_keep_prob < 1.0: the de-duplicated / factorised CAR path requires the "
@@ -498,7 +498,8 @@ class NARModuleModel:
         rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
         rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
         check(lib.cham_score_softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
-                                         ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), s), "cham_score_softmax_fwd")
+                                         ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
+                                         ptr(pl.neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
@@ -547,7 +548,9 @@ class NARModuleModel:
         rt.grads[:L.emb_end].zero_()
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
         check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
-                                         float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3), s),
+                                         float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3),
+                                         self.novelty_reg_factor, ptr(pl.neg_ids), ptr(self._dev_state['pop_norm']),
+                                         ptr(pl.logits), ptr(pl.nov_aux), s),
               "cham_score_softmax_bwd")
         e_dS3 = mark()
         with side(e_start, e_dS3):

@@ -108,10 +108,15 @@ int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* st
 
 /* --- K5 scoring tail + sampled softmax + masked NLL: nar_model.py:478-517, 639-667 */
 int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream);
+/* novelty_reg_factor > 0 adds the novelty regulariser of nar_model.py:673-683 to the per-click loss:
+ * - factor * sum_n softmax(s_neg / tau)_n * (-log2 pop_norm[neg_ids[n]])  (neg_ids [BT,N], pop_norm [n_items], nov_aux [BT,3]
+ * scratch carried from forward to backward; all three may be NULL when the factor is 0) */
 int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
-                           const uint8_t* mask, float* logits, float* probs, float* nll, void* stream);
+                           const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                           const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream);
 int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N,
-                           float tau, float sum_mask, float* ds, float* dS3, void* stream);
+                           float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor, const int64_t* neg_ids,
+                           const float* pop_norm, const float* logits, const float* nov_aux, void* stream);
 
 /* evaluation: rank_items_by_predicted_prob, nar_model.py:777-794 (tf.nn.top_k over 1+N: descending, lowest index wins
  * ties).  pred_ids/pred_probs [BT, 1+N]; label_rank[bt] = 0-based rank of the positive, -1 for padded clicks - the input of

@@ -48,7 +48,7 @@ def make_pair(p, seed=3):
                            recent_clicks_buffer_max_size=p['recent_clicks_buffer_max_size'],
                            recent_clicks_for_normalization=p['recent_clicks_for_normalization'],
                            articles_metadata=p['articles_metadata'], CAR_embedding_size=p['CAR_embedding_size'],
-                           rnn_units=p['rnn_units'], runtime=rt)
+                           rnn_units=p['rnn_units'], novelty_reg_factor=p.get('novelty_reg_factor', 0.0), runtime=rt)
     orc = NAROracle(p, weights=w)
     return model, orc
 
