@@ -297,7 +297,7 @@ class NARModuleModel:
                  diversity_reg_factor=0.0,
                  internal_features_config={'recency': True, 'novelty': True, 'article_content_embeddings': True,
                                            'item_clicked_embeddings': True},
-                 eval_cold_start=False, runtime=None, rnn_cell='ugrnn'):
+                 eval_cold_start=False, runtime=None, rnn_cell='ugrnn', gemm_dtype='f32'):
         if elapsed_days_smooth_log_base != 1.3 or popularity_smooth_log_base != 2.0:
             raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
         self.novelty_reg_factor = float(novelty_reg_factor)
@@ -324,7 +324,7 @@ class NARModuleModel:
                                       articles_features_config=articles_features_config,
                                       content_article_embeddings_matrix=content_article_embeddings_matrix,
                                       articles_metadata=articles_metadata, CAR_embedding_size=CAR_embedding_size,
-                                      rnn_units=rnn_units, rnn_num_layers=rnn_num_layers, rnn_cell=rnn_cell,
+                                      rnn_units=rnn_units, rnn_num_layers=rnn_num_layers, rnn_cell=rnn_cell, gemm_dtype=gemm_dtype,
                                       internal_features_config=internal_features_config,
                                       max_cardinality_for_ohe=max_cardinality_for_ohe,
                                       recent_clicks_buffer_max_size=recent_clicks_buffer_max_size,

@@ -84,6 +84,12 @@ def define_flags():
     a('--eval_cold_start', type=_bool, default=False, nargs='?', const=True)
     a('--use_local_cache_model_dir', type=_bool, default=False, nargs='?', const=True)
     a('--job-dir', default='./tmp')
+    # ---- extensions of this implementation (not in the reference's flag set)
+    a('--rnn_cell', default='ugrnn', choices=['ugrnn', 'gru'], help="recurrent cell: 'ugrnn' = the reference's tf.contrib.rnn.UGRNNCell "
+      "(nar_model.py:1317), 'gru' = its commented-out GRUCell alternative (:1315)")
+    a('--gemm_dtype', default='f32', choices=['f32', 'bf16'], help="f32: exact fp32 MFMA; bf16: bf16-rounded GEMM operands, fp32 accumulate")
+    a('--clicked_items_state', default='host', choices=['host', 'device'], help="keep the recent-clicks state in host numpy (reference "
+      "class) or in HBM (bit-identical, no host round trip per step)")
     return ap
 
 
@@ -186,7 +192,8 @@ def nar_module_model_fn(features, labels, mode, params):
                            rnn_num_layers=params.get('rnn_num_layers', 1),
                            metrics_top_n=eval_metrics_top_n, plot_histograms=params['save_histograms'],
                            novelty_reg_factor=params['novelty_reg_factor'], diversity_reg_factor=params['diversity_reg_factor'],
-                           internal_features_config=internal_features_config, eval_cold_start=params['eval_cold_start'])
+                           internal_features_config=internal_features_config, eval_cold_start=params['eval_cold_start'],
+                           rnn_cell=params.get('rnn_cell', 'ugrnn'), gemm_dtype=params.get('gemm_dtype', 'f32'))
     state = params.get('clicked_items_state') or clicked_items_state
     metrics_log = params.get('eval_sessions_metrics_log', eval_sessions_metrics_log)
     eval_metrics = {'hitrate_at_n': StreamingMean(), 'mrr_at_n': StreamingMean()} if mode == ModeKeys.EVAL else {}
@@ -217,6 +224,7 @@ def build_estimator(model_dir, content_article_embeddings_matrix, articles_metad
         'recent_clicks_for_normalization': FLAGS.recent_clicks_for_normalization,
         'eval_metrics_top_n': FLAGS.eval_metrics_top_n, 'CAR_embedding_size': FLAGS.CAR_embedding_size,
         'rnn_units': FLAGS.rnn_units, 'rnn_num_layers': 1,   # the reference never forwards --rnn_num_layers (:252-275)
+        'rnn_cell': FLAGS.rnn_cell, 'gemm_dtype': FLAGS.gemm_dtype,
         'train_total_negative_samples': FLAGS.train_total_negative_samples,
         'train_negative_samples_from_buffer': FLAGS.train_negative_samples_from_buffer,
         'eval_total_negative_samples': FLAGS.eval_total_negative_samples,
@@ -260,6 +268,9 @@ def train_and_evaluate_loop(flags, ace, articles_metadata, articles_features_con
     eval_sessions_metrics_log = []
     sessions_negative_items_log = [] if FLAGS.save_eval_sessions_negative_samples else None
     sessions_chameleon_recommendations_log = [] if FLAGS.save_eval_sessions_recommendations else None
+    if getattr(FLAGS, 'clicked_items_state', 'host') == 'device':
+        from .clicked_items_state import DeviceClickedItemsState
+        state_cls = DeviceClickedItemsState
     clicked_items_state = state_cls(FLAGS.recent_clicks_buffer_hours, FLAGS.recent_clicks_buffer_max_size,
                                     FLAGS.recent_clicks_for_normalization, ace.shape[0])
     model = build_estimator(FLAGS.model_dir, ace, articles_metadata, articles_features_config, session_features_config)
