@@ -637,6 +637,8 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
             case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
             case 3: return launch_cfg<256, 128, 4, 2, 32, AK, BKC>(p, st);
             case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
+            case 5: return launch_cfg<256, 128, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 128x64 per wave
+            case 6: return launch_cfg<128, 256, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 64x128 per wave
             default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
         }
     }

@@ -188,65 +188,67 @@ def test_microbatched_step_equals_whole_batch_step(gpu):
     assert float((m1.rt.flat - m2.rt.flat).abs().max()) < 2.1 * p['lr']
 
 
+def _mode_parity(p, grad_tol, loss_of, check_fwd, flip_sensitive=True):
+    """Forward + gradient parity on two batches; gradients are compared tightly on batches without a leaky-ReLU kink flip
+    (see _compare_step) - at least one of the two must be flip-free."""
+    batches = synthetic.make_batches(6, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    clean = 0
+    for f, l in batches[3:6]:
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        model.feed_state(pop, buf)
+        model.forward(model.upload_batch(f, l))
+        out = model.outputs_numpy()
+        for v in orc.w.values():
+            v.grad = None
+        orc.debug_taps = {}
+        ref = orc.forward(f, l, buf, pop, 'train')
+        mask = ref['mask'].numpy()
+        assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
+        check_fwd(model, orc, out, ref, mask, f, l, buf, pop)
+        flips = _kink_flips(model, orc, mask)
+        loss_of(ref).backward()
+        model.backward()
+        torch.cuda.synchronize()
+        g = model.rt.logical_grads()
+        tol = grad_tol if (flips == 0 or not flip_sensitive) else 0.25
+        clean += (flips == 0 or not flip_sensitive)
+        for k, v in orc.w.items():
+            rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
+            scale = max(1e-6, float(np.abs(rg).max()))
+            assert float(np.abs(g[k] - rg).max()) < tol * scale + 2e-5, (k, flips)
+        H.update_state(st, f, l)
+    assert clean >= 1
+
+
 def test_step_parity_bf16_compute_mode(gpu):
     """BASELINE config 3 arithmetic: every Dense / matmul with bf16-rounded operands + fp32 accumulation (fp32 storage,
     softmax, loss, Adam).  Checked against the oracle emulating exactly that rounding (forward AND backward); tolerances:
-    logits / loss 1e-3 (fp32 accumulation order only), gradients 1e-1 of the tensor's max (bf16 has 8 bits of mantissa, and the
-    HIP path rounds a few gradient operands AFTER summing them over a click's candidates (dU, dV) where autograd rounds per
-    row - measured 5.5e-2 on the small context-embedding gradients), and within 3e-2 of the fp32 oracle's loss."""
-    p = H.tiny_params(gemm_dtype='bf16')
-    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
-    st = H.warm_state(p, batches[:3])
-    model, orc = H.make_pair(p)
-    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
-    f, l = batches[3]
-    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
-    model.feed_state(pop, buf)
-    model.forward(model.upload_batch(f, l))
-    out = model.outputs_numpy()
-    for v in orc.w.values():
-        v.grad = None
-    ref = orc.forward(f, l, buf, pop, 'train')
-    mask = ref['mask'].numpy()
-    assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
-    assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 2e-3
-    assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
-    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    logits 2e-3 / loss 1e-3 (fp32 accumulation order only), gradients 8e-2 of the tensor's max (bf16 has 8 bits of mantissa,
+    and the HIP path rounds a few gradient operands AFTER summing them over a click's candidates (dU, dV) where autograd rounds
+    per row), and within 3e-2 of the fp32 oracle's loss."""
     from oracle.nar_oracle import NAROracle
-    ref32 = NAROracle(p32, weights=orc.weights_numpy()).forward(f, l, buf, pop, 'train')
-    assert abs(out['loss'][0] - float(ref32['total_loss'].detach())) < 3e-2
-    ref['xe_loss'].backward()
-    model.backward()
-    torch.cuda.synchronize()
-    g = model.rt.logical_grads()
-    for k, v in orc.w.items():
-        rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
-        scale = max(1e-6, float(np.abs(rg).max()))
-        assert float(np.abs(g[k] - rg).max()) < 1e-1 * scale + 2e-5, k
+    p = H.tiny_params(gemm_dtype='bf16')
+
+    def check_fwd(model, orc, out, ref, mask, f, l, buf, pop):
+        assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
+        assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 2e-3
+        assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
+        p32 = dict(p); p32['gemm_dtype'] = 'f32'
+        ref32 = NAROracle(p32, weights=orc.weights_numpy()).forward(f, l, buf, pop, 'train')
+        assert abs(out['loss'][0] - float(ref32['total_loss'].detach())) < 3e-2
+    # bf16 rounding turns last-bit fp32 differences of an activation into (rare) 1-bf16-ulp differences, so a handful of
+    # pre-activations near zero always take the other leaky-ReLU branch: far below the 8e-2 tolerance, no flip-free batch needed
+    _mode_parity(p, 8e-2, lambda ref: ref['xe_loss'], check_fwd, flip_sensitive=False)
 
 
 def test_step_parity_novelty_regularised_loss(gpu):
     """--novelty_reg_factor > 0 (nar_model.py:673-683): loss and gradients with the novelty term."""
     p = H.tiny_params(novelty_reg_factor=0.3)
-    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
-    st = H.warm_state(p, batches[:3])
-    model, orc = H.make_pair(p)
-    f, l = batches[3]
-    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
-    model.feed_state(pop, buf)
-    model.forward(model.upload_batch(f, l))
-    out = model.outputs_numpy()
-    for v in orc.w.values():
-        v.grad = None
-    ref = orc.forward(f, l, buf, pop, 'train')
-    plain = float(ref['xe_loss'].detach()) + float(ref['reg_loss'].detach())
-    assert abs(plain - float(ref['total_loss'].detach())) > 0.05            # the term is not negligible in this set-up
-    assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < LOGIT_TOL
-    (ref['total_loss'] - ref['reg_loss']).backward()
-    model.backward()
-    torch.cuda.synchronize()
-    g = model.rt.logical_grads()
-    for k, v in orc.w.items():
-        rg = v.grad.numpy() if v.grad is not None else np.zeros_like(v.detach().numpy())
-        scale = max(1e-6, float(np.abs(rg).max()))
-        assert float(np.abs(g[k] - rg).max()) < 2e-3 * scale + 2e-5, k
+
+    def check_fwd(model, orc, out, ref, mask, f, l, buf, pop):
+        plain = float(ref['xe_loss'].detach()) + float(ref['reg_loss'].detach())
+        assert abs(plain - float(ref['total_loss'].detach())) > 0.05        # the term is not negligible in this set-up
+        assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < LOGIT_TOL
+    _mode_parity(p, 3e-4, lambda ref: ref['total_loss'] - ref['reg_loss'], check_fwd)
