@@ -34,15 +34,50 @@ __global__ __launch_bounds__(256) void k_keys_pool(const int64_t* __restrict__ a
     keys[i] = v != 0 ? philox_sort_key((uint32_t)i, 0u, 0u, 1u, seed, step) : CHAM_INF_KEY;
 }
 
-// rank[i] = #{j : key[j] < key[i]}: 2-D grid (256 elements) x (slice of 2048 keys staged in LDS); integer atomics
-__global__ __launch_bounds__(256) void k_rank_count(const uint64_t* __restrict__ keys, int n, int* __restrict__ rank) {
+// ---- rank-select with a key-threshold prefilter -----------------------------------------------------------------
+// Only the `limit` smallest keys are ever used.  The upper 32 key bits are uniform (Philox), so all of them lie below
+// thr = ((1.5 * limit + 64) / n_valid) * 2^32 except with probability < 1e-40; ranks are then computed for those ~1.5 * limit
+// candidates only (n_cand x n comparisons instead of n x n: the pool of an 8-GPU global batch has n = 44 k keys).
+// sel[0] = #valid keys, sel[1] = #keys below thr, sel[2..3] = thr (uint64).  If fewer than min(limit, #valid) keys fall
+// below thr every kernel falls back to the full computation, so the result is ALWAYS the exact rank-select.
+__global__ __launch_bounds__(256) void k_sel_count_valid(const uint64_t* __restrict__ keys, int n, unsigned* __restrict__ sel) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && keys[i] != CHAM_INF_KEY;
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(sel, (unsigned)__popcll(b));
+}
+__global__ void k_sel_threshold(unsigned* __restrict__ sel, int limit) {
+    if (threadIdx.x != 0) return;
+    const double want = 1.5 * (double)limit + 64.0, nv = (double)sel[0];
+    uint64_t thr = CHAM_INF_KEY;
+    if (nv > want) thr = (uint64_t)((want / nv) * 4294967296.0) << 32;
+    *reinterpret_cast<uint64_t*>(sel + 2) = thr;
+}
+__global__ __launch_bounds__(256) void k_sel_count_below(const uint64_t* __restrict__ keys, int n, unsigned* __restrict__ sel) {
+    const uint64_t thr = *reinterpret_cast<const uint64_t*>(sel + 2);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && keys[i] < thr;
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(sel + 1, (unsigned)__popcll(b));
+}
+__device__ __forceinline__ uint64_t sel_threshold(const unsigned* __restrict__ sel, int limit) {
+    const unsigned need = min((unsigned)limit, sel[0]);
+    return sel[1] >= need ? *reinterpret_cast<const uint64_t*>(sel + 2) : CHAM_INF_KEY;     // not enough candidates: everything
+}
+
+// rank[i] = #{j : key[j] < key[i]} for the candidates: 2-D grid (256 elements) x (slice of 2048 keys staged in LDS)
+__global__ __launch_bounds__(256) void k_rank_count(const uint64_t* __restrict__ keys, int n, int* __restrict__ rank,
+                                                    const unsigned* __restrict__ sel, int limit) {
     __shared__ uint64_t tile[2048];
+    const uint64_t thr = sel_threshold(sel, limit);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const uint64_t mine = i < n ? keys[i] : CHAM_INF_KEY;
+    const bool cand = mine != CHAM_INF_KEY && mine < thr;
+    if (!__syncthreads_or(cand)) return;                 // no candidate in this block of 256 elements
     const int t0 = blockIdx.y * 2048;
     for (int t = threadIdx.x; t < 2048; t += 256) tile[t] = (t0 + t) < n ? keys[t0 + t] : CHAM_INF_KEY;
     __syncthreads();
-    if (i >= n || mine == CHAM_INF_KEY) return;
+    if (!cand) return;
     const int m = min(2048, n - t0);
     int r = 0;
 #pragma unroll 8
@@ -52,9 +87,9 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint64_t* __restrict__
 // out[rank(i)] = vals[i] for rank < limit; *count = min(limit, #valid)   (out / count / rank pre-zeroed)
 __global__ __launch_bounds__(256) void k_rank_place(const uint64_t* __restrict__ keys, const int64_t* __restrict__ vals,
                                                     const int* __restrict__ rank, int n, int limit, int64_t* __restrict__ out,
-                                                    int* __restrict__ count) {
+                                                    int* __restrict__ count, const unsigned* __restrict__ sel) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || keys[i] == CHAM_INF_KEY) return;
+    if (i >= n || keys[i] == CHAM_INF_KEY || keys[i] >= sel_threshold(sel, limit)) return;
     const int r = rank[i];
     if (r < limit) { out[r] = vals[i]; atomicAdd(count, 1); }
 }
@@ -155,23 +190,33 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
     const int ncat = n_aci + n_from_buffer;
     int64_t* cat_vals = reinterpret_cast<int64_t*>(w); w += align256((size_t)ncat * 8);
     uint64_t* keys1 = reinterpret_cast<uint64_t*>(w); w += align256((size_t)ncat * 8);
-    int* rank = reinterpret_cast<int*>(w);
+    int* rank = reinterpret_cast<int*>(w); w += align256((size_t)(ncat > buf_size ? ncat : buf_size) * 4);
+    unsigned* sel = reinterpret_cast<unsigned*>(w);          // two selections x 4 words
 
     if (hipMemsetAsync(meta, 0, 4 * sizeof(int), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    if (hipMemsetAsync(sel, 0, 8 * sizeof(unsigned), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (n_from_buffer > 0 && hipMemsetAsync(buf_sample, 0, (size_t)n_from_buffer * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (hipMemsetAsync(pool, 0, (size_t)pmax * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (buf_size > 0 && n_from_buffer > 0) {
         hipLaunchKernelGGL(k_keys_buffer, dim3((buf_size + 255) / 256), dim3(256), 0, st, buffer, buf_size, keys0, seed, step);
         if (hipMemsetAsync(rank, 0, (size_t)buf_size * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
-        hipLaunchKernelGGL(k_rank_count, dim3((buf_size + 255) / 256, (buf_size + 2047) / 2048), dim3(256), 0, st, keys0, buf_size, rank);
+        hipLaunchKernelGGL(k_sel_count_valid, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buf_size, sel);
+        hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(64), 0, st, sel, n_from_buffer);
+        hipLaunchKernelGGL(k_sel_count_below, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buf_size, sel);
+        hipLaunchKernelGGL(k_rank_count, dim3((buf_size + 255) / 256, (buf_size + 2047) / 2048), dim3(256), 0, st, keys0, buf_size, rank,
+                           sel, n_from_buffer);
         hipLaunchKernelGGL(k_rank_place, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buffer, rank, buf_size,
-                           n_from_buffer, buf_sample, meta + 1);
+                           n_from_buffer, buf_sample, meta + 1, sel);
     }
     hipLaunchKernelGGL(k_keys_pool, dim3((ncat + 255) / 256), dim3(256), 0, st, aci, n_aci, buf_sample, n_from_buffer,
                        cat_vals, keys1, seed, step);
     if (hipMemsetAsync(rank, 0, (size_t)ncat * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_rank_count, dim3((ncat + 255) / 256, (ncat + 2047) / 2048), dim3(256), 0, st, keys1, ncat, rank);
-    hipLaunchKernelGGL(k_rank_place, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, rank, ncat, pmax, pool, meta + 3);
+    hipLaunchKernelGGL(k_sel_count_valid, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, ncat, sel + 4);
+    hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(64), 0, st, sel + 4, pmax);
+    hipLaunchKernelGGL(k_sel_count_below, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, ncat, sel + 4);
+    hipLaunchKernelGGL(k_rank_count, dim3((ncat + 255) / 256, (ncat + 2047) / 2048), dim3(256), 0, st, keys1, ncat, rank, sel + 4, pmax);
+    hipLaunchKernelGGL(k_rank_place, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, rank, ncat, pmax, pool, meta + 3,
+                       sel + 4);
     hipLaunchKernelGGL(k_canon, dim3((pmax + 255) / 256), dim3(256), 0, st, pool, meta + 3, pmax, canon);
     if (row_count > 0) {
         const size_t smem = (size_t)pp * 8 + (size_t)T1 * 8;

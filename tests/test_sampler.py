@@ -155,3 +155,35 @@ def test_hip_sampler_row_shards(gpu):
     a = _gpu_sample(gpu, aci, buf, 8, 200, 42, 11, 0, 16)[0]
     b = _gpu_sample(gpu, aci, buf, 8, 200, 42, 11, 16, 16)[0]
     assert np.array_equal(full, np.concatenate([a, b]))
+
+
+@pytest.mark.gpu
+def test_hip_sampler_global_batch_of_8_gpus(gpu):
+    """Bg = 2048 sessions (8 ranks x 256): 44k pool keys -> the threshold-prefiltered rank-select must stay bit exact;
+    the oracle is evaluated for two row shards only (as rank 0 / rank 5 would)."""
+    rng = np.random.default_rng(77)
+    B, T1, N, n_buf = 2048, 20, 50, 3000
+    aci = rng.integers(1, 46000, size=(B, T1)).astype(np.int64)
+    lens = rng.integers(2, T1 + 1, size=B)
+    for b in range(B):
+        aci[b, lens[b]:] = 0
+    buf = rng.integers(1, 46000, size=20000).astype(np.int64)
+    for rb in (0, 5 * 256):
+        neg, slot, pool, canon, meta = _gpu_sample(gpu, aci, buf, N, n_buf, 42, 9, rb, 32)
+        ref, aux = S.batch_negative_samples(aci, buf, N, n_buf, 42, 9, rows=range(rb, rb + 32), return_aux=True)
+        assert np.array_equal(pool, aux['pool']) and np.array_equal(canon, aux['canon'])
+        assert meta[1] == len(aux['buf_sample']) == n_buf
+        assert np.array_equal(neg, ref)
+
+
+@pytest.mark.gpu
+def test_hip_sampler_nearly_empty_buffer_falls_back_to_full_select(gpu):
+    """Fewer valid keys than the selection size: the prefilter must not drop anything."""
+    rng = np.random.default_rng(3)
+    aci = rng.integers(1, 300, size=(8, 6)).astype(np.int64)
+    buf = np.zeros(5000, np.int64); buf[:40] = rng.integers(1, 300, size=40)
+    neg, slot, pool, canon, meta = _gpu_sample(gpu, aci, buf, 25, 500, 42, 2)
+    ref, aux = S.batch_negative_samples(aci, buf, 25, 500, 42, 2, return_aux=True)
+    P = len(aux['pool'])
+    assert meta[3] == P and meta[1] == len(aux['buf_sample']) == 40
+    assert np.array_equal(pool[:P], aux['pool']) and np.array_equal(neg, ref)
