@@ -67,6 +67,48 @@ def cpu_baseline(params, cfg, length_dist, seed):
                        "(PyTorch-CPU fp32, TF 1.12 unavailable), %d threads" % (len(times) - 1, cores))
 
 
+def hitrate_parity(seed):
+    """HitRate@5 / MRR@5 of the HIP path vs the CPU oracle on identical inputs (the second half of BASELINE.json's metric):
+    G1-tiny shape (configs[0]), 30 optimizer steps from the same initial weights on both, then 4 held-out batches ranked
+    against 20 sampled negatives (bit-identical negatives on both sides)."""
+    import torch
+    from chameleon_recsys_amd.nar import metrics, synthetic
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
+    from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel, NARRuntime
+    from oracle.nar_oracle import NAROracle
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 32))
+    p = synthetic.default_params(1000, 64, seq_len=8, batch_size=64, neg=10, neg_from_buffer=100, buffer_size=2000, for_norm=200,
+                                 C=128, H=255, seed=seed, lr=1e-3, eval_total_negative_samples=20, eval_negative_samples_from_buffer=200)
+    batches = synthetic.make_batches(34, 64, 8, 1000, p['session_features_config'], seed=seed, length_dist='g1')
+    rt = NARRuntime(p, seed=seed)
+    orc = NAROracle(p, weights=rt.logical_weights())
+    mk = lambda mode, n, nb: NARModuleModel(mode, None, None, p['session_features_config'], p['articles_features_config'], 64,
+                                            p['lr'], 1.0, n, nb, p['content_article_embeddings_matrix'],
+                                            softmax_temperature=p['softmax_temperature'], reg_weight_decay=p['reg_weight_decay'],
+                                            recent_clicks_buffer_max_size=2000, recent_clicks_for_normalization=200,
+                                            articles_metadata=p['articles_metadata'], CAR_embedding_size=128, rnn_units=255, runtime=rt)
+    train, ev = mk(ModeKeys.TRAIN, 10, 100), mk(ModeKeys.EVAL, 20, 200)
+    st = ClickedItemsState(1.0, 2000, 200, 1000)
+    for f, l in batches[:30]:
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        train.feed_state(pop, buf); train.train_step(train.upload_batch(f, l))
+        orc.train_step(f, l, buf, pop)
+        st.update_items_state(*batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']))
+    m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "cpu_oracle")}
+    for i, (f, l) in enumerate(batches[30:]):
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        ev.feed_state(pop, buf); ev.evaluate_step(ev.upload_batch(f, l))
+        ids = ev.predicted_item_ids.eval()
+        ref = orc.forward(f, l, buf, pop, mode='eval', step=NARModuleModel.eval_step_key(orc.global_step, i))
+        for k, pred in (("hip", ids), ("cpu_oracle", ref['predicted_item_ids'].numpy())):
+            m[k][0].add(pred, l['label_next_item']); m[k][1].add(pred, l['label_next_item'])
+        st.update_items_state(*batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']))
+    return {"hitrate_at_5": {k: round(v[0].result(), 5) for k, v in m.items()},
+            "mrr_at_5": {k: round(float(v[1].result()), 5) for k, v in m.items()},
+            "protocol": "G1-tiny synthetic, 30 training steps + 4 eval batches x 64 sessions, 20 eval negatives, same weights / inputs / "
+                        "negatives on both sides"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +261,7 @@ def main():
                                    frac=round(gbs / 8000.0, 4), traffic=None, traffic_source=None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
+            out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
