@@ -96,19 +96,21 @@ __global__ __launch_bounds__(256) void k_rank_place(const uint64_t* __restrict__
 
 __global__ __launch_bounds__(256) void k_canon(const int64_t* __restrict__ pool, const int* __restrict__ pcount, int pmax,
                                                int* __restrict__ canon) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int64_t* sp = reinterpret_cast<int64_t*>(smem_raw);             // the pool staged in LDS: every thread scans a prefix of it
     const int P = *pcount;
+    for (int t = threadIdx.x; t < P; t += 256) sp[t] = pool[t];
+    __syncthreads();
     for (int q = threadIdx.x + blockIdx.x * 256; q < pmax; q += gridDim.x * 256) {
         int c = q;
         if (q < P) {
-            const int64_t v = pool[q];
+            const int64_t v = sp[q];
             for (int t = 0; t < q; ++t)
-                if (pool[t] == v) { c = t; break; }
+                if (sp[t] == v) { c = t; break; }
         }
         canon[q] = c;
     }
 }
-
-// one workgroup per click (j = blockIdx.x, local row = blockIdx.y)
 __global__ __launch_bounds__(256) void k_click_select(const int64_t* __restrict__ aci, int T1, int row_begin,
                                                       const int64_t* __restrict__ pool, const int* __restrict__ canon,
                                                       const int* __restrict__ pcount, int pmax, int pp /*pow2 >= pmax*/,
@@ -217,7 +219,14 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
     hipLaunchKernelGGL(k_rank_count, dim3((ncat + 255) / 256, (ncat + 2047) / 2048), dim3(256), 0, st, keys1, ncat, rank, sel + 4, pmax);
     hipLaunchKernelGGL(k_rank_place, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, rank, ncat, pmax, pool, meta + 3,
                        sel + 4);
-    hipLaunchKernelGGL(k_canon, dim3((pmax + 255) / 256), dim3(256), 0, st, pool, meta + 3, pmax, canon);
+    {
+        static bool canon_attr = false;
+        if (!canon_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_canon), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            canon_attr = true;
+        }
+        hipLaunchKernelGGL(k_canon, dim3((pmax + 255) / 256), dim3(256), (size_t)pmax * 8, st, pool, meta + 3, pmax, canon);
+    }
     if (row_count > 0) {
         const size_t smem = (size_t)pp * 8 + (size_t)T1 * 8;
         static bool attr_done = false;

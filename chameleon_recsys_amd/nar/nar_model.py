@@ -270,6 +270,7 @@ class StepPlan:
         self.RH = [f32(BT, Hp) if gru else None for _ in range(L.L)]
         self.drnn = f32(BT, Hp)
         self.WhT = f32(NG * Hp, Hp)
+        self.W2T = f32(C, C)
         # FCs / scorer
         self.FC1, self.dFC1 = f32(BT, 512), f32(BT, 512)
         self.pred, self.dpred = f32(BT, C), f32(BT, C)
@@ -603,11 +604,14 @@ class NARModuleModel:
             # CAR layer-2 weight gradient over ALL rows (needs dZ2 of the clicked rows from just above)
             rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
             rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
-        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only)
-        rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only).  W2 is transposed once (4 MB) so
+        # that the 520-GFLOP dgrad runs in the NN layout (B tile staged with ds_write_b128 instead of 4 x ds_write_b32:
+        # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
+        check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
+        rt.gemm(pl.dZ2[BT:], pl.W2T, pl.dZ1[BT:], Rc, C, C, C, C, C, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
         if on:
             main_wait(e_dZ2in)
-        rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+        rt.gemm(pl.dZ2, pl.W2T, pl.dZ1, BT, C, C, C, C, C, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
         check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
                                    rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
         e_dUV = mark()
