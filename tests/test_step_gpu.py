@@ -224,23 +224,48 @@ def _mode_parity(p, grad_tol, loss_of, check_fwd, flip_sensitive=True):
 
 def test_step_parity_bf16_compute_mode(gpu):
     """BASELINE config 3 arithmetic: every Dense / matmul with bf16-rounded operands + fp32 accumulation (fp32 storage,
-    softmax, loss, Adam).  Checked against the oracle emulating exactly that rounding (forward AND backward); tolerances:
-    logits 2e-3 / loss 1e-3 (fp32 accumulation order only), gradients 8e-2 of the tensor's max (bf16 has 8 bits of mantissa,
-    and the HIP path rounds a few gradient operands AFTER summing them over a click's candidates (dU, dV) where autograd rounds
-    per row), and within 3e-2 of the fp32 oracle's loss."""
+    softmax, loss, Adam).  Forward: against the oracle emulating exactly that rounding - logits 2e-3 / loss 1e-3 (fp32
+    accumulation order only) - and within 3e-2 of the fp32 oracle's loss.  Gradients: bf16 noise is amplified by the
+    cancellation in the small context / embedding gradients, and the HIP path rounds a few operands after summing them over a
+    click's candidates (dU, dV) where autograd rounds per row, so two correct bf16 evaluations differ by more than they each
+    differ from fp32; the check is therefore accuracy against the FP32 oracle: the HIP bf16 gradient must be as close to it as
+    the emulated bf16 gradient is (x3 + 2 % of the tensor's max)."""
     from oracle.nar_oracle import NAROracle
     p = H.tiny_params(gemm_dtype='bf16')
-
-    def check_fwd(model, orc, out, ref, mask, f, l, buf, pop):
-        assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
-        assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 2e-3
-        assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
-        p32 = dict(p); p32['gemm_dtype'] = 'f32'
-        ref32 = NAROracle(p32, weights=orc.weights_numpy()).forward(f, l, buf, pop, 'train')
-        assert abs(out['loss'][0] - float(ref32['total_loss'].detach())) < 3e-2
-    # bf16 rounding turns last-bit fp32 differences of an activation into (rare) 1-bf16-ulp differences, so a handful of
-    # pre-activations near zero always take the other leaky-ReLU branch: far below the 8e-2 tolerance, no flip-free batch needed
-    _mode_parity(p, 8e-2, lambda ref: ref['xe_loss'], check_fwd, flip_sensitive=False)
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
+    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    orc32 = NAROracle(p32, weights=orc.weights_numpy())
+    for f, l in batches[3:5]:
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        model.feed_state(pop, buf)
+        model.forward(model.upload_batch(f, l))
+        out = model.outputs_numpy()
+        grads = {}
+        for name, o in (("bf16", orc), ("f32", orc32)):
+            for v in o.w.values():
+                v.grad = None
+            ref = o.forward(f, l, buf, pop, 'train')
+            if name == "bf16":
+                mask = ref['mask'].numpy()
+                assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
+                assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 2e-3
+                assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
+            else:
+                assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 3e-2
+            ref['xe_loss'].backward()
+            grads[name] = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros_like(v.detach().numpy())) for k, v in o.w.items()}
+        model.backward()
+        torch.cuda.synchronize()
+        g = model.rt.logical_grads()
+        for k in g:
+            scale = max(1e-6, float(np.abs(grads["f32"][k]).max()))
+            e_hip = float(np.abs(g[k] - grads["f32"][k]).max())
+            e_emu = float(np.abs(grads["bf16"][k] - grads["f32"][k]).max())
+            assert e_hip < 3.0 * e_emu + 2e-2 * scale + 2e-5, (k, e_hip, e_emu, scale)
+        H.update_state(st, f, l)
 
 
 def test_step_parity_novelty_regularised_loss(gpu):
