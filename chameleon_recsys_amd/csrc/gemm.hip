@@ -152,6 +152,10 @@ template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
     return 1.f;
 }
 
+// compile-time switch of the ds_read / MFMA interleave hint: on for the tile configurations with one wave per SIMD
+template <int BM, int BN, int WM, int WN>
+__host__ __device__ constexpr bool g_sched_hint_static() { return WM * WN <= 4 && BM * BN >= 256 * 256; }
+
 static int g_pipe = 1;          // software pipeline of the K loop (cham_gemm_set_variant(v + 100) turns it off for A/B runs)
 
 // Shared epilogue of the fp32 and bf16 kernels (the 32x32 MFMA C/D layout is dtype independent).
@@ -302,6 +306,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            if (g_sched_hint_static<BM, BN, WM, WN>()) {     // interleave the next fragments' ds_reads between this step's MFMAs
+#pragma unroll
+                for (int r = 0; r < TM * TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (r < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         }
         if (!PIPE && kt + 1 < nk) {
             if (has_rs) la.apply_scale();
@@ -639,6 +650,7 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
             case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
             case 5: return launch_cfg<256, 128, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 128x64 per wave
             case 6: return launch_cfg<128, 256, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 64x128 per wave
+            case 7: return launch_cfg<256, 256, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 128x128 per wave, 1 wave / SIMD
             default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
         }
     }

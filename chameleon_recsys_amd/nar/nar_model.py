@@ -133,6 +133,7 @@ class NARRuntime:
         # CUs as soon as GEMM workgroups retire: 22.2 -> 20.7 ms per G1 step.  (With a default-priority stream they were
         # starved behind the 7.7k-workgroup GEMM grid.)  CHAM_OVERLAP=0 turns it off.
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"
+        self.dgrad_nn = os.environ.get("CHAM_DGRAD_NN", "0") == "1"      # experiment switch (profiles/r01_notes.md item 9)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -607,11 +608,17 @@ class NARModuleModel:
         # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only).  W2 is transposed once (4 MB) so
         # that the 520-GFLOP dgrad runs in the NN layout (B tile staged with ds_write_b128 instead of 4 x ds_write_b32:
         # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
-        check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
-        rt.gemm(pl.dZ2[BT:], pl.W2T, pl.dZ1[BT:], Rc, C, C, C, C, C, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+        if rt.dgrad_nn:
+            check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
+            rt.gemm(pl.dZ2[BT:], pl.W2T, pl.dZ1[BT:], Rc, C, C, C, C, C, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+        else:
+            rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
         if on:
             main_wait(e_dZ2in)
-        rt.gemm(pl.dZ2, pl.W2T, pl.dZ1, BT, C, C, C, C, C, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+        if rt.dgrad_nn:
+            rt.gemm(pl.dZ2, pl.W2T, pl.dZ1, BT, C, C, C, C, C, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+        else:
+            rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
         check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
                                    rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
         e_dUV = mark()

@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+export PYTHONPATH=$R
+( timeout 300 python tests/bench_gemm.py 7 4 2 2>&1 | tail -30 ) > $O/gemm_v7.log
+( timeout 600 python -m pytest tests/test_gemm_gpu.py tests/test_step_gpu.py tests/test_sampler.py -m gpu -q 2>&1 | tail -8 ) > $O/pytest_part.log
+( timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 ) > $O/bench.log
+cat $O/gemm_v7.log; cat $O/pytest_part.log; python - <<PY
+import json
+d = json.loads(open("$O/bench.log").read().strip().splitlines()[-1]); print("bench", d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["traffic"])
+PY

@@ -24,7 +24,7 @@ def main():
         "NT dgrad   ": lambda: lib.cham_gemm_f32(ptr(D), C, 0, ptr(W), C, 1, ptr(Out), C, R, C, C, None, 0, ptr(A), C, 1, None, 0, 1, 0, None, 0, 1, st),
         "TN wgrad   ": lambda: lib.cham_gemm_f32(ptr(A), C, 1, ptr(D), C, 0, ptr(Wg), C, C, C, R, None, 0, None, 0, 0, None, 0, 1, 0, ptr(ws), ws.numel() * 4, 0, st),
     }
-    names = {0: "128x128x16 4w", 1: "128x128x32 4w", 2: "256x128x16 8w", 3: "256x128x32 8w", 4: "256x256x16 8w", 5: "256x128x16 4w (128x64/wave)", 6: "128x256x16 4w (64x128/wave)"}
+    names = {0: "128x128x16 4w", 1: "128x128x32 4w", 2: "256x128x16 8w", 3: "256x128x32 8w", 4: "256x256x16 8w", 5: "256x128x16 4w (128x64/wave)", 6: "128x256x16 4w (64x128/wave)", 7: "256x256x16 4w (128x128/wave, ds_read/MFMA interleave hint)"}
     names.update({100 + k: v + " (K-loop software pipeline OFF)" for k, v in list(names.items())})
     for v in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]:
         lib.cham_gemm_set_variant(v)
