@@ -156,7 +156,7 @@ template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
 template <int BM, int BN, int WM, int WN>
 __host__ __device__ constexpr bool g_sched_hint_static() { return WM * WN <= 4 && BM * BN >= 256 * 256; }
 
-static int g_pipe = 1;          // software pipeline of the K loop (cham_gemm_set_variant(v + 100) turns it off for A/B runs)
+static int g_pipe = 1;          // (the non-pipelined K loop was an A/B arm: neutral, removed; profiles/r01_notes.md item 9)
 
 // Shared epilogue of the fp32 and bf16 kernels (the 32x32 MFMA C/D layout is dtype independent).
 // EPI: 0 = plain / accumulate, 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref), 5 = bias only,
@@ -584,18 +584,16 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
         using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
         smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
-        kern = g_pipe ? reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>)
-                      : reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>);
+        kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>);
     }
     static bool attr_done[2] = {false, false};
-    if (!attr_done[g_pipe]) {
+    if (!attr_done[g_pipe]) {      // (g_pipe is always 1)
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -CHAM_ERR_LAUNCH;
         attr_done[g_pipe] = true;
     }
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
     if (BF16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
-    else if (g_pipe) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>), grid, dim3(WM * WN * 64), smem, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>), grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -631,7 +629,7 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 }
 
 static int g_variant = -1;     // -1 = automatic
-extern "C" void cham_gemm_set_variant(int v) { g_pipe = v >= 100 ? 0 : 1; g_variant = v >= 100 ? v - 100 : v; if (g_variant > 50) g_variant = -1; }
+extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
 
 template <bool AK, bool BKC>
 static int launch_by_shape(GemmParams& p, hipStream_t st) {
@@ -643,14 +641,9 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
         int v = ((long)p.M * p.N >= (1L << 20)) ? 2 : 0;
         if (v == 2 && (!AK || BKC) && p.K >= 512 && p.M >= 1024 && p.N >= 512) v = 4;
         if (g_variant >= 0) v = g_variant;
-        switch (v) {
-            case 1: return launch_cfg<128, 128, 2, 2, 32, AK, BKC>(p, st);
+        switch (v) {      // (other tile shapes were measured and dropped: profiles/r01_notes.md items 3 and 9)
             case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
-            case 3: return launch_cfg<256, 128, 4, 2, 32, AK, BKC>(p, st);
             case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
-            case 5: return launch_cfg<256, 128, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 128x64 per wave
-            case 6: return launch_cfg<128, 256, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 64x128 per wave
-            case 7: return launch_cfg<256, 256, 2, 2, 16, AK, BKC>(p, st);      // 4 waves, 128x128 per wave, 1 wave / SIMD
             default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
         }
     }
