@@ -31,6 +31,8 @@ _SIGNATURES = {
     "cham_combine_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "cham_ugrnn_point_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "cham_ugrnn_point_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_set_exclusive_lds": (None, [c_size_t]),
     "cham_transpose_f32": (c_int, [P, c_int, c_int, P, P]),
     "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),

@@ -491,3 +491,64 @@ extern "C" int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, 
         default: return -CHAM_ERR_ARG;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Step-wise fallback for hidden sizes beyond what the fused time-loop kernels hold in LDS (UGRNN Hp > 512, GRU Hp > 384;
+// the reference's hypertuning searches rnn_units up to 1024, nar_mlengine_hypertuning.yaml:28-33): the host runs the
+// recurrent products h W_h as GEMM launches per time step (csrc/gemm.hip) and these kernels do the gate arithmetic,
+// length masking and state carry.  zh = h_{t-1} W_h for the step (UGRNN: [B, 2Hp]; GRU gates: [B, 2Hp], candidate: [B, Hp]).
+__global__ __launch_bounds__(256) void k_ugrnn_point_fwd(const float* __restrict__ xproj, const float* __restrict__ zh,
+                                                         const int* __restrict__ seq_len, int B, int T, int t, int Hp,
+                                                         float* __restrict__ h /*[B,Hp] state in/out*/, float* __restrict__ out,
+                                                         float* __restrict__ hprev, float* __restrict__ G, float* __restrict__ Cc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Hp) return;
+    const int b = i / Hp, hid = i % Hp;
+    const size_t bt = (size_t)b * T + t, o = bt * Hp + hid;
+    const float g = sigmoidf_(zh[(size_t)b * 2 * Hp + hid] + xproj[bt * 2 * Hp + hid] + 1.0f);
+    const float c = tanhf(zh[(size_t)b * 2 * Hp + Hp + hid] + xproj[bt * 2 * Hp + Hp + hid]);
+    const float ho = h[i], hn = g * ho + (1.f - g) * c;
+    const bool valid = t < seq_len[b];
+    out[o] = valid ? hn : 0.f; hprev[o] = ho; G[o] = g; Cc[o] = c;
+    if (valid) h[i] = hn;
+}
+// dh = dout[:,t] + carry;  dz -> dxproj[:,t] and dzs [B,2Hp] (for carry_next = direct + dzs W_h^T, a GEMM);  direct [B,Hp]
+__global__ __launch_bounds__(256) void k_ugrnn_point_bwd(const float* __restrict__ dout, const float* __restrict__ carry,
+                                                         const int* __restrict__ seq_len, int B, int T, int t, int Hp,
+                                                         const float* __restrict__ hprev, const float* __restrict__ G,
+                                                         const float* __restrict__ Cc, float* __restrict__ dxproj,
+                                                         float* __restrict__ dzs, float* __restrict__ direct) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Hp) return;
+    const int b = i / Hp, hid = i % Hp;
+    const size_t bt = (size_t)b * T + t, o = bt * Hp + hid;
+    float dzg = 0.f, dzc = 0.f, dd = carry[i];                 // beyond the session's length the carry passes through unchanged
+    if (t < seq_len[b]) {
+        const float dh = dout[o] + carry[i];
+        const float g = G[o], c = Cc[o], hp = hprev[o];
+        dzg = dh * (hp - c) * g * (1.f - g);
+        dzc = dh * (1.f - g) * (1.f - c * c);
+        dd = dh * g;
+    }
+    dxproj[bt * 2 * Hp + hid] = dzg; dxproj[bt * 2 * Hp + Hp + hid] = dzc;
+    dzs[(size_t)b * 2 * Hp + hid] = dzg; dzs[(size_t)b * 2 * Hp + Hp + hid] = dzc;
+    direct[i] = dd;
+}
+extern "C" int cham_ugrnn_point_fwd(const float* xproj, const float* zh, const int32_t* seq_len, int B, int T, int t, int Hp,
+                                    float* h, float* out, float* hprev, float* G, float* Cc, void* stream) {
+    if (!xproj || !zh || !seq_len || !h || !out || !hprev || !G || !Cc || B <= 0 || T <= 0 || t < 0 || t >= T) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_ugrnn_point_fwd, dim3((B * Hp + 255) / 256), dim3(256), 0, (hipStream_t)stream, xproj, zh, seq_len, B, T, t,
+                       Hp, h, out, hprev, G, Cc);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" int cham_ugrnn_point_bwd(const float* dout, const float* carry, const int32_t* seq_len, int B, int T, int t, int Hp,
+                                    const float* hprev, const float* G, const float* Cc, float* dxproj, float* dzs, float* direct,
+                                    void* stream) {
+    if (!dout || !carry || !seq_len || !hprev || !G || !Cc || !dxproj || !dzs || !direct || B <= 0 || T <= 0 || t < 0 || t >= T)
+        return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_ugrnn_point_bwd, dim3((B * Hp + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, carry, seq_len, B, T, t,
+                       Hp, hprev, G, Cc, dxproj, dzs, direct);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

@@ -52,8 +52,9 @@ class ParamLayout:
             raise ValueError("CAR_embedding_size must be a multiple of 4")
         self.H = H = rnn_units
         self.Hp = Hp = ceil_to(H, 128)
-        if Hp > 512:
-            raise ValueError("rnn_units > 512 is not supported by the recurrent kernel")
+        if Hp > 512 and rnn_cell != 'ugrnn':
+            raise ValueError("rnn_units > 384 is not supported by the GRU recurrent kernel")
+        self.rnn_stepwise = Hp > 512            # UGRNN beyond the fused kernel's LDS budget: GEMM + pointwise kernel per time step
         self.L = rnn_num_layers
         self.cell = rnn_cell
         if rnn_cell not in ('ugrnn', 'gru'):

@@ -272,6 +272,9 @@ class StepPlan:
         self.drnn = f32(BT, Hp)
         self.WhT = f32(NG * Hp, Hp)
         self.W2T = f32(C, C)
+        if L.rnn_stepwise:
+            self.h_state, self.zh, self.carry = f32(B, Hp), f32(B, 2 * Hp), f32(B, Hp)
+            self.dzs, self.direct = f32(B, 2 * Hp), f32(B, Hp)
         # FCs / scorer
         self.FC1, self.dFC1 = f32(BT, 512), f32(BT, 512)
         self.pred, self.dpred = f32(BT, C), f32(BT, C)
@@ -484,9 +487,17 @@ class NARModuleModel:
             x, ldx, K = pl.Z2, C, C
             for l in range(L.L):
                 rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, NGH, K, ldx, NGH, NGH, bias=p('rnn%d/b' % l))
-                check(lib.cham_rnn_fwd(cell, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
-                                       ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
-                                       ptr(pl.RH[l]), _stream()), "cham_rnn_fwd")
+                if L.rnn_stepwise:      # large hidden size: one GEMM (h W_h) + one gate kernel per time step
+                    pl.h_state.zero_()
+                    for t in range(T):
+                        rt.gemm(pl.h_state, p('rnn%d/Wh' % l), pl.zh, B, 2 * Hp, Hp, Hp, 2 * Hp, 2 * Hp, force_f32=True)
+                        check(lib.cham_ugrnn_point_fwd(ptr(pl.xproj[l]), ptr(pl.zh), ptr(pl.seq_len), B, T, t, Hp, ptr(pl.h_state),
+                                                       ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), _stream()),
+                              "cham_ugrnn_point_fwd")
+                else:
+                    check(lib.cham_rnn_fwd(cell, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
+                                           ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
+                                           ptr(pl.RH[l]), _stream()), "cham_rnn_fwd")
                 x, ldx, K = pl.rnn_out[l], Hp, Hp
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
             rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
@@ -585,11 +596,21 @@ class NARModuleModel:
             rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
             rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
             for l in range(last, -1, -1):
-                check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), ss), "cham_transpose_f32")
-                if cell == 1:
-                    check(lib.cham_transpose_f32(ptr(p('rnn%d/Wch' % l)), Hp, Hp, pl.WhT[2 * Hp:].data_ptr(), ss), "cham_transpose_f32")
-                check(lib.cham_rnn_bwd(cell, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
-                                       ptr(pl.Cc[l]), ptr(pl.R[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
+                if L.rnn_stepwise:
+                    pl.carry.zero_()
+                    for t in range(T - 1, -1, -1):
+                        check(lib.cham_ugrnn_point_bwd(ptr(pl.drnn), ptr(pl.carry), ptr(pl.seq_len), B, T, t, Hp, ptr(pl.hprev[l]),
+                                                       ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.dxproj), ptr(pl.dzs), ptr(pl.direct), ss),
+                              "cham_ugrnn_point_bwd")
+                        # carry = direct + dzs W_h^T  (rows beyond their length: dzs = 0, direct = carry -> unchanged)
+                        pl.carry.copy_(pl.direct)
+                        rt.gemm(pl.dzs, p('rnn%d/Wh' % l), pl.carry, B, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1, accumulate=1, force_f32=True)
+                else:
+                    check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), ss), "cham_transpose_f32")
+                    if cell == 1:
+                        check(lib.cham_transpose_f32(ptr(p('rnn%d/Wch' % l)), Hp, Hp, pl.WhT[2 * Hp:].data_ptr(), ss), "cham_transpose_f32")
+                    check(lib.cham_rnn_bwd(cell, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
+                                           ptr(pl.Cc[l]), ptr(pl.R[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
                 if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows (main lane waits for it)
                     rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
                     e_dZ2in = mark()

@@ -102,6 +102,14 @@ int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32
                  float* hprev, float* G, float* Cc, float* R, float* RH, void* stream);
 int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
                  const float* hprev, const float* G, const float* Cc, const float* R, float* dxproj, void* stream);
+/* step-wise fallback for rnn_units beyond the fused kernels' LDS budget (UGRNN Hp > 512; hypertuning goes to 1024,
+ * nar_mlengine_hypertuning.yaml:28-33): the caller computes zh = h_{t-1} W_h (forward) / carry_next = direct + dzs W_h^T
+ * (backward) with cham_gemm_f32 per time step; these do the UGRNN gate arithmetic, length masking and state carry */
+int cham_ugrnn_point_fwd(const float* xproj, const float* zh, const int32_t* seq_len, int B, int T, int t, int Hp, float* h,
+                         float* out, float* hprev, float* G, float* Cc, void* stream);
+int cham_ugrnn_point_bwd(const float* dout, const float* carry, const int32_t* seq_len, int B, int T, int t, int Hp,
+                         const float* hprev, const float* G, const float* Cc, float* dxproj, float* dzs, float* direct,
+                         void* stream);
 /* scheduling hook: recurrent workgroups request this much LDS so that no other workgroup shares their CU */
 void cham_rnn_set_exclusive_lds(size_t bytes);
 int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);

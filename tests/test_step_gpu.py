@@ -147,7 +147,7 @@ def test_row_shards_sum_to_full_batch(gpu):
     assert float((g_sum - g_full).abs().max()) < 2e-5 * scale + 1e-7
 
 
-@pytest.mark.parametrize("cell,layers,Hn", [("gru", 1, 100), ("gru", 2, 256), ("ugrnn", 2, 255)])
+@pytest.mark.parametrize("cell,layers,Hn", [("gru", 1, 100), ("gru", 2, 256), ("ugrnn", 2, 255), ("ugrnn", 1, 1000)])   # 1000 -> step-wise path
 def test_step_parity_rnn_variants(gpu, cell, layers, Hn):
     """GRU (north-star / BASELINE config 4: 2-layer GRU, hidden 256) and stacked cells vs the oracle."""
     p = H.tiny_params(C=128, H=Hn, neg=9, batch_size=40, rnn_cell=cell, rnn_num_layers=layers)
