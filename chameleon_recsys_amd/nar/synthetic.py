@@ -178,3 +178,25 @@ def write_dataset(out_dir, n_hours, sessions_per_hour, n_items, ace_dim, seq_len
         tfm.save_rows_to_tf_record_file(ss, scfg, path)
         files.append(path)
     return files, os.path.join(out_dir, 'articles_metadata.csv'), os.path.join(out_dir, 'articles_embeddings.pickle')
+
+
+if __name__ == "__main__":      # python -m chameleon_recsys_amd.nar.synthetic --out /tmp/g1 --hours 8 --sessions-per-hour 2000
+    import argparse
+    ap = argparse.ArgumentParser(description="Write a synthetic G1-shaped dataset the NAR trainer can consume")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--hours", type=int, default=8)
+    ap.add_argument("--sessions-per-hour", type=int, default=2000)
+    ap.add_argument("--n-items", type=int, default=46000)
+    ap.add_argument("--ace-dim", type=int, default=250)
+    ap.add_argument("--seq-len", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=42)
+    a = ap.parse_args()
+    files, csv_path, pkl_path = write_dataset(a.out, a.hours, a.sessions_per_hour, a.n_items, a.ace_dim, a.seq_len, a.seed)
+    print("wrote %d session files, e.g. %s\n  articles metadata: %s\n  content embeddings: %s" % (len(files), files[0], csv_path, pkl_path))
+    print("train with:\n  python -m chameleon_recsys_amd.nar.nar_trainer_gcom --train_set_path_regex '%s/sessions_hour_*.tfrecord.gz' "
+          "--acr_module_articles_metadata_csv_path %s --acr_module_articles_content_embeddings_pickle_path %s --model_dir %s/model "
+          "--batch_size 256 --truncate_session_length %d --learning_rate 1e-4 --reg_l2 1e-5 --softmax_temperature 0.1 "
+          "--recent_clicks_buffer_max_size 20000 --recent_clicks_for_normalization 2000 --eval_metrics_top_n 5 --CAR_embedding_size 1024 "
+          "--rnn_units 255 --train_total_negative_samples 50 --train_negative_samples_from_buffer 3000 --eval_total_negative_samples 50 "
+          "--eval_negative_samples_from_buffer 3000 --content_embedding_scale_factor 6.0 --training_hours_for_each_eval 2 "
+          "--disable_eval_benchmarks" % (a.out, csv_path, pkl_path, a.out, a.seq_len))
