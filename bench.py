@@ -205,7 +205,7 @@ def main():
         one_step(args.warmup + args.steps + i)
     torch.cuda.synchronize()
     prof, rt.profile = rt.profile, None
-    # dominant kernel SYMBOL = gemm_f32_kernel<256,128,4,2,16,true,false,2,true>: NN layout, bias + tanh epilogue - the CAR layer-2
+    # dominant kernel SYMBOL = gemm_f32_kernel<256,128,4,2,16,true,false,2,true,0,false>: NN layout, bias + tanh epilogue - the CAR layer-2
     # forward over the B*T*(1+N) candidate rows (97 % of its time) plus the two small launches that share the symbol (CAR
     # layer 2 on the clicked rows, session FC2).  Aggregated over all of its launches exactly like `rocprofv3 --stats`
     # aggregates per kernel symbol, so avg_launch_ms is comparable with the committed kernel_stats.
@@ -218,7 +218,7 @@ def main():
     n_nn, ms_nn, fl_nn = agg(dom)
     n_all, ms_all, fl_all = agg(lambda r: True)
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
-    DOM_SYMBOL = "void gemm_f32_kernel<256, 128, 4, 2, 16, true, false, 2, true>(GemmParams)"
+    DOM_SYMBOL = "void gemm_f32_kernel<256, 128, 4, 2, 16, true, false, 2, true, 0, false>(GemmParams)"
     traffic, traffic_src = None, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if fn.endswith("_pmc_traffic.json"):     # PMC passes cannot be collected inside the timed bench: committed separately

@@ -88,10 +88,15 @@ struct TileLoader {
         }
     }
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t win, int limK) {
+        if (limK >= BK) {            // full K tile (wave-uniform): no per-load compare / select in the steady-state loop
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const unsigned o = kidx[i] < limK ? off[i] : OOB_OFF;
-            r[i] = __builtin_amdgcn_raw_buffer_load_b128(win, o, 0, 0);
+            for (int i = 0; i < NV; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(win, off[i], 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const unsigned o = kidx[i] < limK ? off[i] : OOB_OFF;
+                r[i] = __builtin_amdgcn_raw_buffer_load_b128(win, o, 0, 0);
+            }
         }
     }
     // XK operand (A of NN): scale[(row / rs_div), k] - rows fixed per thread, k advances with the tile (soffset)
@@ -130,9 +135,13 @@ struct TileLoader {
             if (NF4 % NTH != 0 && idx >= NF4) continue;
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
+#ifdef CHAM_PROBE_B128STORE     // probe only (wrong layout, same bytes): what would one ds_write_b128 instead of 4 x ds_write_b32 buy?
+                *reinterpret_cast<float4*>(S + ((kq * (BF / 4) + fr / 4) * 4) * 4 + (fr & 3) * LD * 0) = as_f4(r[i]);
+#else
                 float* d = S + (kq * 4) * LD + fr;
                 d[0] = __uint_as_float(r[i].x); d[LD] = __uint_as_float(r[i].y);
                 d[2 * LD] = __uint_as_float(r[i].z); d[3 * LD] = __uint_as_float(r[i].w);
+#endif
             } else {
                 const int kk = idx / (BF / 4), f4 = idx % (BF / 4);
                 *reinterpret_cast<float4*>(S + kk * LD + f4 * 4) = as_f4(r[i]);
@@ -143,7 +152,7 @@ struct TileLoader {
 
 template <int ACT> __device__ __forceinline__ float act_fwd_c(float v) {
     if (ACT == ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
-    if (ACT == ACT_TANH) return tanhf(v);
+    if (ACT == ACT_TANH) return cham_tanhf(v);
     return v;
 }
 template <int ACT> __device__ __forceinline__ float act_bwd_c(float y) {
@@ -173,6 +182,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx16 (&ac
     const __amdgpu_buffer_rsrc_t dw = make_window((EPI == 3 || EPI == 4) ? p.dref + (size_t)m0 * p.ldr + n0 : p.C);
     const __amdgpu_buffer_rsrc_t biasw = make_window((EPI == 1 || EPI == 2 || EPI == 5) ? p.bias + n0 : p.C);
     const bool accum = (EPI == 0 || EPI == 3 || EPI == 4) && p.accumulate;
+    if (limM >= wm0 + TM * 32 && limN >= wn0 + TN * 32) {
+        // interior wave tile (wave-uniform test): no per-element address arithmetic or range selects.  The row part of an
+        // element's address is uniform - c(e) * ld * 4 with c(e) = (e&3) + 8*(e>>2) - and rides in the SGPR soffset of the buffer
+        // instruction; one VGPR offset per 32x32 tile.  (VALU issue slots are MFMA issue slots: the generic path below cost
+        // ~6 % of a K = 1024 GEMM.)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned col = (unsigned)(wn0 + j * 32 + fl), rowb = (unsigned)(wm0 + i * 32 + 4 * kl);
+                const unsigned voff = (rowb * ldc + col) * 4u;
+                const unsigned voffr = (EPI == 3 || EPI == 4) ? (rowb * (unsigned)p.ldr + col) * 4u : 0u;
+                float bv = 0.f;
+                if (EPI == 1 || EPI == 2 || EPI == 5) bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(biasw, col * 4u, 0, 0));
+                float aux[16], old[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ce = (e & 3) + 8 * (e >> 2);
+                    if (EPI == 3 || EPI == 4)
+                        aux[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dw, voffr, ce * p.ldr * 4, 0));
+                    if (EPI == 0 || EPI == 3 || EPI == 4)
+                        old[e] = accum ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cw, voff, ce * (int)ldc * 4, 0)) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ce = (e & 3) + 8 * (e >> 2);
+                    float v = acc[i][j][e];
+                    if (EPI == 1) v = act_fwd_c<ACT_LEAKY>(v + bv);
+                    else if (EPI == 2) v = act_fwd_c<ACT_TANH>(v + bv);
+                    else if (EPI == 5) v = v + bv;
+                    else if (EPI == 3) v = v * act_bwd_c<ACT_LEAKY>(aux[e]) + old[e];
+                    else if (EPI == 4) v = v * act_bwd_c<ACT_TANH>(aux[e]) + old[e];
+                    else if (EPI == 0) v += old[e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, voff, ce * (int)ldc * 4, 0);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,7 +257,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx16 (&ac
 }
 
 // EPI: see gemm_epilogue
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE>
+// ABL (ablation bits, probe builds only - tests/probe_gemm.hip): 1 = no global loads / LDS writes inside the K loop,
+// 2 = no barrier inside the K loop, 4 = no LDS fragment reads, 8 = minimal epilogue.  0 in the product library.
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE, int ABL = 0, bool RS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
     using LA = TileLoader<BM, BK, AK, NTH>;
@@ -247,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     const char* aw = reinterpret_cast<const char*>(p.A) + (AK ? ((size_t)m0 * p.lda + kbeg) : ((size_t)kbeg * p.lda + m0)) * 4;
     const char* bw = reinterpret_cast<const char*>(p.B) + (BKC ? ((size_t)n0 * p.ldb + kbeg) : ((size_t)kbeg * p.ldb + n0)) * 4;
     const size_t astep = (AK ? (size_t)BK : (size_t)BK * p.lda) * 4, bstep = (BKC ? (size_t)BK : (size_t)BK * p.ldb) * 4;
-    const bool has_rs = p.rs != nullptr;
+    constexpr bool has_rs = RS;          // compile-time: the scale product / select must not cost VALU slots in every GEMM
     const __amdgpu_buffer_rsrc_t rsw = make_window(p.rs);
 
     LA la; LB lb;
@@ -277,29 +326,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     __syncthreads();
     const int kl = lane >> 5, fl = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const float* Ac = As + cur * ASZ + wm0 + fl;
-        const float* Bc = Bs + cur * BSZ + wn0 + fl;
+        const int cur = (ABL & 1) ? 0 : (kt & 1);
+        // one base register per fragment (kept opaque so that the compiler addresses every k-step with the 16-bit immediate of
+        // ds_read_b32 instead of re-basing a ds_read2_b32 pair with a v_add per k-step: VALU slots are MFMA slots)
+        int ai[TM], bj[TN];          // indices into smem[] (the array keeps its LDS address space -> ds_read_b32 base + immediate)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ai[i] = cur * ASZ + wm0 + fl + kl * LDA + i * 32; asm volatile("" : "+v"(ai[i])); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bj[j] = 2 * ASZ + cur * BSZ + wn0 + fl + kl * LDB + j * 32; asm volatile("" : "+v"(bj[j])); }
         // fragment registers are double-buffered: the ds_reads of k-step kk+2 are issued before the MFMAs of kk
         float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = Ac[kl * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[0][i] = smem[ai[i]];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = Bc[kl * LDB + j * 32];
-        if (PIPE && kt + 1 < nk) {        // tile kt+1: registers -> the LDS buffer every wave finished reading at the last barrier
+        for (int j = 0; j < TN; ++j) b[0][j] = smem[bj[j]];
+        if (PIPE && kt + 1 < nk && !(ABL & 1)) {        // tile kt+1: registers -> the LDS buffer every wave finished reading at the last barrier
             if (has_rs) la.apply_scale();
-            la.store(As + (cur ^ 1) * ASZ);
-            lb.store(Bs + (cur ^ 1) * BSZ);
-            if (kt + 2 < nk) load_tile(kt + 2);
+            if (!(ABL & 16)) {            // probe bit 16: global loads stay, LDS writes (and their vmcnt wait) go
+                la.store(As + (cur ^ 1) * ASZ);
+                lb.store(Bs + (cur ^ 1) * BSZ);
+            }
+            if (kt + 2 < nk && !(ABL & 32)) load_tile(kt + 2);      // probe bit 32: LDS writes stay, global loads go
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int c = (kk >> 1) & 1;
             if (kk + 2 < BK) {
+                if (ABL & 4) {         // probe: no LDS traffic, operands stay live in registers
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[c ^ 1][i] = Ac[(kk + 2 + kl) * LDA + i * 32];
+                    for (int i = 0; i < TM; ++i) a[c ^ 1][i] = a[c][i] + 1e-30f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[c ^ 1][j] = Bc[(kk + 2 + kl) * LDB + j * 32];
+                    for (int j = 0; j < TN; ++j) b[c ^ 1][j] = b[c][j] + 1e-30f;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[c ^ 1][i] = smem[ai[i] + (kk + 2) * LDA];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[c ^ 1][j] = smem[bj[j] + (kk + 2) * LDB];
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -320,7 +383,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
             lb.store(Bs + (cur ^ 1) * BSZ);
             if (kt + 2 < nk) load_tile(kt + 2);
         }
-        __syncthreads();
+        if (!(ABL & 2)) __syncthreads();
+    }
+    if (ABL & 8) {      // probe: one store per thread keeps the accumulators (and the last loaded tile) live
+        float v = __uint_as_float(la.r[0].x) * 1e-30f + __uint_as_float(lb.r[0].x) * 1e-30f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v += acc[i][j][e];
+        p.C[(size_t)(m0 + wm0 + fl) * p.ldc + n0 + wn0 + kl] = v;
+        return;
     }
 
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
@@ -584,6 +658,20 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
         using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
         smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
+        constexpr bool RSI = (EPI == 1 && AK && !BKC) || (EPI == 6 && !AK && !BKC);
+        if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
+        if (RSI && p.rs != nullptr) {
+            auto k = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true, 0, RSI>;
+            static bool done_rs = false;
+            if (!done_rs) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                    return -CHAM_ERR_LAUNCH;
+                done_rs = true;
+            }
+            hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(WM * WN * 64), smem, st, p);
+            CHAM_CHECK_LAUNCH();
+            return CHAM_OK;
+        }
         kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>);
     }
     static bool attr_done[2] = {false, false};
@@ -744,3 +832,39 @@ static int gemm_dispatch(int precision, const float* A, int lda, int transA, con
     if (transA && !transB) return launch_by_shape<false, false>(p, st);
     return -CHAM_ERR_ARG;                                // TT never occurs on this path
 }
+
+#ifdef CHAM_GEMM_PROBE
+// Ablation probe (NOT part of the product library): C[M,N] = A[M,K] * B[K,N], NN, full tiles only, 256x128x16 / 8 waves.
+template <int ABL>
+static int probe_launch(GemmParams& p, hipStream_t st) {
+    using LA = TileLoader<256, 16, true, 512>;
+    using LB = TileLoader<128, 16, false, 512>;
+    const size_t smem = (size_t)2 * 16 * (LA::LD + LB::LD) * sizeof(float);
+    auto kern = gemm_f32_kernel<256, 128, 4, 2, 16, true, false, 0, true, ABL>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    p.nbm = p.M / 256; p.nbn = p.N / 128;
+    hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int cham_gemm_probe(int abl, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
+    GemmParams p = {};
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N; p.rs_div = 1;
+    p.kchunk = K; p.splits = 1;
+    hipStream_t st = (hipStream_t)stream;
+    switch (abl) {
+        case 0: return probe_launch<0>(p, st);
+        case 1: return probe_launch<1>(p, st);
+        case 3: return probe_launch<3>(p, st);
+        case 7: return probe_launch<7>(p, st);
+        case 8: return probe_launch<8>(p, st);
+        case 9: return probe_launch<9>(p, st);
+        case 11: return probe_launch<11>(p, st);
+        case 15: return probe_launch<15>(p, st);
+        case 4: return probe_launch<4>(p, st);
+        case 24: return probe_launch<24>(p, st);
+        case 40: return probe_launch<40>(p, st);
+        case 12: return probe_launch<12>(p, st);
+        default: return -22;
+    }
+}
+#endif
