@@ -227,6 +227,39 @@ def main():
                 traffic, traffic_src = rec["traffic_bytes_per_launch"], "profiles/" + fn
             break
 
+    # ---- secondary leg: the same step on G1-LIKE session lengths (2 + min(Geometric(0.45), seq_len - 2), mean
+    # ~4 clicks, zero-padded to the batch maximum).  The headline above is the "all sessions full length" stress/roofline
+    # variant (no padded positions: the most work a session can carry); with ragged sessions the step runs its row-wise
+    # stages on the valid positions only (nar_model.upload_batch), so sessions/s rises with the padding fraction.
+    ragged = None
+    if args.length_dist == "full" and args.state == "device":
+        rb = synthetic.make_batches(n_distinct, Bg, cfg['seq_len'], cfg['n_items'], params['session_features_config'],
+                                    seed=args.seed + 1, length_dist="g1", sessions_per_hour=Bg * 2)
+        rdev = [dp.upload(f, l) for f, l in rb]
+
+        def ragged_step(i):
+            k = i % n_distinct
+            model.feed_state(state, state)
+            model.train_step(rdev[k])
+            state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
+        for i in range(max(3, args.warmup)):
+            ragged_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ragged_step(args.warmup + i)
+        barrier()
+        rdt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([rdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            rdt = float(tt.item())
+        ragged = {"session_lengths": "g1: 2 + min(Geometric(0.45), seq_len - 2), zero-padded to the batch maximum",
+                  "value": round(Bg * args.steps / rdt, 2), "unit": "sessions/s", "ms_per_step": round(rdt / args.steps * 1e3, 3),
+                  "mean_clicks_per_session": round(float(np.mean([np.asarray(f['session_size']).mean() for f, _ in rb])), 2),
+                  "valid_positions_of_padded": round(float(sum(d['P'] for d in rdev)) / float(sum(d['B'] * d['T'] for d in rdev)), 4),
+                  "padded_T": [int(d['T']) for d in rdev]}
+
     if rank == 0:
         L = rt.layout
         T = cfg['seq_len'] - 1
@@ -259,6 +292,8 @@ def main():
             out["roofline"].update(bound="hbm", kernel="gemm_bf16_kernel<256,128,4,2,32,true,false,2,false> = bf16-MFMA GEMM, NN, bias+tanh "
                                    "(CAR layer 2 forward), all launches of a step", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
                                    frac=round(gbs / 8000.0, 4), traffic=None, traffic_source=None)
+        if ragged is not None:
+            out["g1_like_session_lengths"] = ragged
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

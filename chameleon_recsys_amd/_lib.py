@@ -35,6 +35,8 @@ _SIGNATURES = {
     "cham_ugrnn_point_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_set_exclusive_lds": (None, [c_size_t]),
     "cham_transpose_f32": (c_int, [P, c_int, c_int, P, P]),
+    "cham_rows_gather": (c_int, [P, P, c_long, c_int, P, P]),
+    "cham_rows_scatter": (c_int, [P, P, c_long, c_int, P, P]),
     "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, c_float, P, P, P, P]),
     "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, c_float, P, P, P, P, P]),

@@ -638,8 +638,9 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
     const void* kern;
     if (BF16) {
         smem = (size_t)2 * (BM + BN) * (BK + 8) * 2;
-        // the row-broadcast scale only ever accompanies the scorer's first layer (bias+leaky, NN) and its split-K wgrad (TN)
-        constexpr bool RSI = (EPI == 1 && AK && !BKC) || (EPI == 6 && !AK && !BKC);
+        // the row-broadcast scale only ever accompanies the scorer's first layer (bias+leaky, NN) and its wgrad (TN; split-K, or
+        // plain when the reduction is too short to split: a batch with a handful of valid positions)
+        constexpr bool RSI = (EPI == 1 && AK && !BKC) || ((EPI == 6 || EPI == 0) && !AK && !BKC);
         if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
         if (RSI && p.rs != nullptr) {
             auto k = gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, RSI>;
@@ -658,7 +659,7 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         using LA = TileLoader<BM, BK, AK, WM * WN * 64>;
         using LB = TileLoader<BN, BK, BKC, WM * WN * 64>;
         smem = (size_t)2 * BK * (LA::LD + LB::LD) * sizeof(float);
-        constexpr bool RSI = (EPI == 1 && AK && !BKC) || (EPI == 6 && !AK && !BKC);
+        constexpr bool RSI = (EPI == 1 && AK && !BKC) || ((EPI == 6 || EPI == 0) && !AK && !BKC);
         if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
         if (RSI && p.rs != nullptr) {
             auto k = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true, 0, RSI>;

@@ -389,6 +389,44 @@ extern "C" int cham_transpose_f32(const float* in, int rows, int cols, float* ou
     return CHAM_OK;
 }
 
+// ---- valid-position compaction (nar_model.py:231 sequence_mask): the step runs its row-wise stages on the P non-padded
+// (session, time) positions only; the recurrent stack keeps the [B, T] layout.  These two move rows between the layouts
+// (rows are `words` 32-bit words wide: fp32 activations, int32 slots, int64 ids as 2 words).
+__global__ __launch_bounds__(256) void k_rows_gather(const uint32_t* __restrict__ src, const int32_t* __restrict__ pos, long n_rows,
+                                                     int words, uint32_t* __restrict__ dst) {
+    const long total = n_rows * words;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / words; const int c = (int)(i - r * words);
+        dst[i] = src[(size_t)pos[r] * words + c];
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_scatter(const uint32_t* __restrict__ src, const int32_t* __restrict__ pos, long n_rows,
+                                                      int words, uint32_t* __restrict__ dst) {
+    const long total = n_rows * words;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / words; const int c = (int)(i - r * words);
+        dst[(size_t)pos[r] * words + c] = src[i];
+    }
+}
+static int rows_move(bool gather, const void* src, const int32_t* pos, long n_rows, int words, void* dst, void* stream) {
+    if (!src || !pos || !dst || n_rows < 0 || words <= 0) return -CHAM_ERR_ARG;
+    if (n_rows == 0) return CHAM_OK;
+    long blocks = (n_rows * words + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather ? k_rows_gather : k_rows_scatter, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)src, pos, n_rows, words, (uint32_t*)dst);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+// dst[i, :] = src[pos[i], :]   (i < n_rows)
+extern "C" int cham_rows_gather(const void* src, const int32_t* pos, long n_rows, int words, void* dst, void* stream) {
+    return rows_move(true, src, pos, n_rows, words, dst, stream);
+}
+// dst[pos[i], :] = src[i, :]   (i < n_rows; pos holds distinct rows; rows of dst not named by pos are left untouched)
+extern "C" int cham_rows_scatter(const void* src, const int32_t* pos, long n_rows, int words, void* dst, void* stream) {
+    return rows_move(false, src, pos, n_rows, words, dst, stream);
+}
+
 // When the recurrent kernels run on a side stream next to the big CAR GEMM they must not share a CU with GEMM
 // workgroups (the MFMA pipes would be time-sliced and the latency-bound recurrence would stretch 5x): requesting
 // most of the 160 KB LDS makes every CU that hosts a recurrent workgroup exclusive to it.

@@ -134,6 +134,9 @@ class NARRuntime:
         # starved behind the 7.7k-workgroup GEMM grid.)  CHAM_OVERLAP=0 turns it off.
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"
         self.dgrad_nn = os.environ.get("CHAM_DGRAD_NN", "0") == "1"      # experiment switch (profiles/r01_notes.md item 9)
+        # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
+        # positions too and masks them, like the reference graph does
+        self.compact = os.environ.get("CHAM_COMPACT", "1") == "1"
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -287,6 +290,22 @@ class StepPlan:
         self.nov_aux = f32(BT, 3)
         self.mask = torch.zeros(BT, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
+        # valid-position compaction (see NARModuleModel.upload_batch): compact copies of the sampler output, and the
+        # [B, T]-layout staging buffers either side of the recurrent stack
+        self.neg_ids_c = i64(BT, N)
+        self.neg_slot_c = torch.zeros(BT, N, dtype=torch.int32, device=dev)
+        self.Z2f, self.rnn_c, self.drnn_c, self.dxproj_c = f32(BT, C), f32(BT, Hp), f32(BT, Hp), f32(BT, NG * Hp)
+        self.pos, self.P = None, BT
+
+    def full_rows(self, x, group=1):
+        """Debug / test helper: rows of the current step (one group of ``group`` rows per valid position) -> the [B*T*group, ...]
+        layout with zeros at padded positions."""
+        x = x[:self.P * group]
+        if self.pos is None:
+            return x
+        out = torch.zeros((self.BT * group,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        out.view(self.BT, -1)[self.pos.long()] = x.reshape(self.P, -1)
+        return out
 
 
 class NARModuleModel:
@@ -421,9 +440,25 @@ class NARModuleModel:
             else np.zeros((1, B * T), np.float32)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
         g_ets = ets if global_features is None else np.ascontiguousarray(gf['event_timestamp'], dtype=np.int64)
-        return dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts,
-                    g_event_ts=t(g_ets), aci=t(aci), item_clicked=t(item_clicked), label_next=t(np.asarray(labels['label_next_item'], np.int64)),
-                    event_ts=t(ets), seq_len=t(seq_len), mask=t(mask.astype(np.uint8).reshape(-1)), cat=t(cat), num=t(num))
+        label_next = np.ascontiguousarray(labels['label_next_item'], dtype=np.int64)
+        # Valid-position compaction.  The reference computes every padded (session, time) position and multiplies it
+        # away with sequence_mask (nar_model.py:231, 664); here the row-wise stages (features, CAR, scorer, softmax and
+        # their gradients) run on the P non-padded positions only - same loss and gradients, P/(B*T) of the work
+        # (G1-like session lengths: ~1/3).  Only the sampler (keyed by (row, position)) and the recurrent stack keep
+        # the [B, T] layout.
+        mrows = mask.reshape(-1)
+        pos = np.flatnonzero(mrows).astype(np.int32)
+        P = int(pos.shape[0])
+        d = dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts,
+                 g_event_ts=t(g_ets), aci=t(aci), item_clicked=t(item_clicked), label_next=t(label_next),
+                 event_ts=t(ets), seq_len=t(seq_len))
+        if self.rt.compact and 0 < P < B * T:
+            d.update(P=P, pos=t(pos), ic_rows=t(item_clicked.reshape(-1)[pos]), ln_rows=t(label_next.reshape(-1)[pos]),
+                     ets_rows=t(ets.reshape(-1)[pos]), mask=t(np.ones(P, np.uint8)), cat=t(cat[:, pos]), num=t(num[:, pos]))
+        else:
+            d.update(P=B * T, pos=None, ic_rows=d['item_clicked'].view(-1), ln_rows=d['label_next'].view(-1),
+                     ets_rows=d['event_ts'].view(-1), mask=t(mrows.astype(np.uint8)), cat=t(cat), num=t(num))
+        return d
 
     # ------------------------------------------------------------------ forward
     def forward(self, d, step=None):
@@ -435,7 +470,10 @@ class NARModuleModel:
         pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
         self._plan, self._d = pl, d
         s = _stream()
-        BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
+        # BT = rows of the row-wise stages = the P valid positions (all B*T when nothing is padded); BTf = the [B, T] layout
+        pos, BT, BTf, NC, pmax = d['pos'], d['P'], pl.BT, pl.NC, pl.pmax
+        pl.pos, pl.P = pos, BT
+        Rc = BT * NC; Rall = BT + Rc; RV = 2 * BT + pmax + 1
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
         cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         if step is None:
@@ -446,12 +484,20 @@ class NARModuleModel:
                                   rt.tf_random_seed, step, d['row_begin'], B, N, self.negative_sample_from_buffer,
                                   ptr(pl.neg_ids), ptr(pl.neg_slot), ptr(pl.pool), ptr(pl.canon), ptr(pl.meta),
                                   ptr(pl.sampler_ws), pl.ws_bytes, s), "cham_neg_sample")
+        neg_ids, neg_slot = pl.neg_ids, pl.neg_slot
+        if pos is not None:
+            neg_ids, neg_slot = pl.neg_ids_c, pl.neg_slot_c
+            check(lib.cham_rows_gather(ptr(pl.neg_ids), ptr(pos), BT, 2 * N, ptr(neg_ids), s), "cham_rows_gather")
+            check(lib.cham_rows_gather(ptr(pl.neg_slot), ptr(pos), BT, N, ptr(neg_slot), s), "cham_rows_gather")
+        pl.cur_neg_ids, pl.cur_neg_slot = neg_ids, neg_slot
         # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
-        pl.ids_all[:BT].copy_(d['item_clicked'].view(-1))
-        pl.ids_all[BT:2 * BT].copy_(d['label_next'].view(-1))
+        pl.ids_all[:BT].copy_(d['ic_rows'])
+        pl.ids_all[BT:2 * BT].copy_(d['ln_rows'])
         pl.ids_all[2 * BT:2 * BT + pmax].copy_(pl.pool)
-        pl.ref_ts[:BT].copy_(d['event_ts'].view(-1))
-        pl.ref_ts[BT:].fill_(d['max_ts'])
+        if pos is not None:
+            pl.ids_all[2 * BT + pmax:2 * BT + pmax + 1].zero_()      # the pad item row moves with P
+        pl.ref_ts[:BT].copy_(d['ets_rows'])
+        pl.ref_ts[BT:RV].fill_(d['max_ts'])
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
         if st['n_last'] > 0 and st.get('device'):
@@ -463,7 +509,7 @@ class NARModuleModel:
                                                   ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
                   "cham_norm_stats_from_recent")
         else:   # very first batch: population = the call's own non-pad ids (nar_model.py:1078-1084)
-            check(lib.cham_row_weights(ptr(pl.ids_all), 2 * BT, ptr(pl.neg_slot), BT * N, pmax, ptr(pl.pool),
+            check(lib.cham_row_weights(ptr(pl.ids_all), 2 * BT, ptr(neg_slot), BT * N, pmax, ptr(pl.pool),
                                        ptr(pl.w_rows), pl.w_rows[2 * BT:].data_ptr(), s), "cham_row_weights")
             for g, (a, b) in enumerate([(0, BT), (BT, 2 * BT), (2 * BT, RV)]):
                 check(lib.cham_norm_stats_from_rows(pl.rec_raw[a:].data_ptr(), pl.nov_raw[a:].data_ptr(),
@@ -478,15 +524,19 @@ class NARModuleModel:
         # factorised PreCAR: U (per click) + V (per unique item row), then CAR
         rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
         rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
-        pl.seq_len.copy_(d['seq_len']); pl.mask.copy_(d['mask'])
+        pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])
         # PreCAR combine + CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
-        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
+        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
         rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.fork()
         with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
             x, ldx, K = pl.Z2, C, C
+            if pos is not None:          # clicked rows back into the [B, T] layout of the recurrent stack (zeros at padded steps)
+                pl.Z2f.zero_()
+                check(lib.cham_rows_scatter(ptr(pl.Z2), ptr(pos), BT, C, ptr(pl.Z2f), _stream()), "cham_rows_scatter")
+                x = pl.Z2f
             for l in range(L.L):
-                rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BT, NGH, K, ldx, NGH, NGH, bias=p('rnn%d/b' % l))
+                rt.gemm(x, p('rnn%d/Wx' % l), pl.xproj[l], BTf, NGH, K, ldx, NGH, NGH, bias=p('rnn%d/b' % l))
                 if L.rnn_stepwise:      # large hidden size: one GEMM (h W_h) + one gate kernel per time step
                     pl.h_state.zero_()
                     for t in range(T):
@@ -499,20 +549,23 @@ class NARModuleModel:
                                            ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
                                            ptr(pl.RH[l]), _stream()), "cham_rnn_fwd")
                 x, ldx, K = pl.rnn_out[l], Hp, Hp
+            if pos is not None:
+                check(lib.cham_rows_gather(ptr(x), ptr(pos), BT, Hp, ptr(pl.rnn_c), _stream()), "cham_rows_gather")
+                x = pl.rnn_c
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
             rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
         # ... the candidate rows: PreCAR combine (HBM-bound) + the dominant GEMM, CAR layer 2 on the B*T*(1+N) rows
-        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
+        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
         rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.join()
         # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
-        Z2c = pl.Z2[BT:]
+        Z2c = pl.Z2[BT:Rall]
         rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
         rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
         rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
         check(lib.cham_score_softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
                                          ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
-                                         ptr(pl.neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
+                                         ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
@@ -530,7 +583,9 @@ class NARModuleModel:
         pl, d = self._plan, self._d
         s = _stream()
         B, T, N = pl.B, pl.T, pl.N
-        BT, NC, Rc, Rall, RV, pmax = pl.BT, pl.NC, pl.Rc, pl.Rall, pl.RV, pl.pmax
+        pos, BT, BTf, NC, pmax = pl.pos, pl.P, pl.BT, pl.NC, pl.pmax          # see forward(): BT = valid positions
+        Rc = BT * NC; Rall = BT + Rc; RV = 2 * BT + pmax + 1
+        neg_ids, neg_slot = pl.cur_neg_ids, pl.cur_neg_slot
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
         cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         p, g = rt.p, rt.g
@@ -562,7 +617,7 @@ class NARModuleModel:
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
         check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
                                          float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3),
-                                         self.novelty_reg_factor, ptr(pl.neg_ids), ptr(self._dev_state['pop_norm']),
+                                         self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']),
                                          ptr(pl.logits), ptr(pl.nov_aux), s),
               "cham_score_softmax_bwd")
         e_dS3 = mark()
@@ -578,7 +633,7 @@ class NARModuleModel:
             rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
         rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
         e_dS1 = mark()
-        Z2c, dZ2c = pl.Z2[BT:], pl.dZ2[BT:]
+        Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
         with side(e_dS1):
             rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
             rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
@@ -592,9 +647,14 @@ class NARModuleModel:
             rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
             rt.colsum(pl.dpred, C, BT, C, g('bf2'))
             rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
-            rt.gemm(pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
+            rt.gemm(pl.rnn_c if pos is not None else pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
             rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
-            rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
+            if pos is not None:          # d rnn_out back into the [B, T] layout (zero at padded steps)
+                rt.gemm(pl.dFC1, p('Wf1'), pl.drnn_c, BT, Hp, 512, 512, 512, Hp, transB=1)
+                pl.drnn.zero_()
+                check(lib.cham_rows_scatter(ptr(pl.drnn_c), ptr(pos), BT, Hp, ptr(pl.drnn), ss), "cham_rows_scatter")
+            else:
+                rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
             for l in range(last, -1, -1):
                 if L.rnn_stepwise:
                     pl.carry.zero_()
@@ -612,17 +672,21 @@ class NARModuleModel:
                     check(lib.cham_rnn_bwd(cell, ptr(pl.drnn), ptr(pl.WhT), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
                                            ptr(pl.Cc[l]), ptr(pl.R[l]), ptr(pl.dxproj), ss), "cham_rnn_bwd")
                 if l == 0:   # -> gradient w.r.t. the CAR tanh pre-activation of the clicked-input rows (main lane waits for it)
-                    rt.gemm(pl.dxproj, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
+                    dxp = pl.dxproj
+                    if pos is not None:
+                        dxp = pl.dxproj_c
+                        check(lib.cham_rows_gather(ptr(pl.dxproj), ptr(pos), BT, NGH, ptr(dxp), ss), "cham_rows_gather")
+                    rt.gemm(dxp, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
                     e_dZ2in = mark()
+                    rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
-                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BT, Hp, NGH, NGH, NGH, Hp, transB=1)
-                x, ldx, K = (pl.Z2, C, C) if l == 0 else (pl.rnn_out[l - 1], Hp, Hp)
-                rt.gemm(x, pl.dxproj, g('rnn%d/Wx' % l), K, NGH, BT, ldx, NGH, NGH, transA=1, splits=0)
+                    rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
+                    rt.gemm(pl.rnn_out[l - 1], pl.dxproj, g('rnn%d/Wx' % l), Hp, NGH, BTf, Hp, NGH, NGH, transA=1, splits=0)
                 # recurrent weights: their forward product runs in the fp32 time-step kernel -> fp32 wgrad in every mode
-                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BT, Hp, NGH, 2 * Hp, transA=1, splits=0, force_f32=True)
+                rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BTf, Hp, NGH, 2 * Hp, transA=1, splits=0, force_f32=True)
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
-                    rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BT, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
-                rt.colsum(pl.dxproj, NGH, BT, NGH, g('rnn%d/b' % l))
+                    rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BTf, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
+                rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn%d/b' % l))
             # CAR layer-2 weight gradient over ALL rows (needs dZ2 of the clicked rows from just above)
             rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
             rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
@@ -631,16 +695,16 @@ class NARModuleModel:
         # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
         if rt.dgrad_nn:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
-            rt.gemm(pl.dZ2[BT:], pl.W2T, pl.dZ1[BT:], Rc, C, C, C, C, C, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+            rt.gemm(pl.dZ2[BT:Rall], pl.W2T, pl.dZ1[BT:Rall], Rc, C, C, C, C, C, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
         else:
-            rt.gemm(pl.dZ2[BT:], p('W2'), pl.dZ1[BT:], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:], ldr=C, dact=ACT_LEAKY)
+            rt.gemm(pl.dZ2[BT:Rall], p('W2'), pl.dZ1[BT:Rall], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
         if on:
             main_wait(e_dZ2in)
         if rt.dgrad_nn:
             rt.gemm(pl.dZ2, pl.W2T, pl.dZ1, BT, C, C, C, C, C, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
         else:
             rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
-        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(pl.neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
+        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
                                    rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
         e_dUV = mark()
         with side(e_dUV):
@@ -726,9 +790,21 @@ class NARModuleModel:
             ev = self._eval = dict(pred_ids=torch.zeros(pl.B, pl.T, pl.NC, dtype=torch.int64, device=dev),
                                    pred_probs=torch.zeros(pl.B, pl.T, pl.NC, dtype=torch.float32, device=dev),
                                    label_rank=torch.zeros(pl.B, pl.T, dtype=torch.int32, device=dev))
-        check(rt.lib.cham_rank_items(ptr(pl.probs), ptr(d['label_next']), ptr(pl.neg_ids), ptr(pl.mask), pl.BT, pl.N,
-                                     ptr(ev['pred_ids']), ptr(ev['pred_probs']), ptr(ev['label_rank']), _stream()),
-              "cham_rank_items")
+        if pl.pos is None:
+            check(rt.lib.cham_rank_items(ptr(pl.probs), ptr(d['label_next']), ptr(pl.neg_ids), ptr(pl.mask), pl.BT, pl.N,
+                                         ptr(ev['pred_ids']), ptr(ev['pred_probs']), ptr(ev['label_rank']), _stream()),
+                  "cham_rank_items")
+        else:       # rank the valid positions, then back into the [B, T, 1+N] layout (padded positions: ids 0, probs 0, rank -1)
+            P, NC = pl.P, pl.NC
+            c = ev.get('compact')
+            if c is None or c[0].shape[0] < P:
+                c = ev['compact'] = (torch.zeros(pl.BT, NC, dtype=torch.int64, device=dev), torch.zeros(pl.BT, NC, dtype=torch.float32, device=dev),
+                                     torch.zeros(pl.BT, dtype=torch.int32, device=dev))
+            check(rt.lib.cham_rank_items(ptr(pl.probs), ptr(d['ln_rows']), ptr(pl.cur_neg_ids), ptr(pl.mask), P, pl.N,
+                                         ptr(c[0]), ptr(c[1]), ptr(c[2]), _stream()), "cham_rank_items")
+            ev['pred_ids'].zero_(); ev['pred_probs'].zero_(); ev['label_rank'].fill_(-1)
+            for src, dst, words in ((c[0], ev['pred_ids'], 2 * NC), (c[1], ev['pred_probs'], NC), (c[2], ev['label_rank'], 1)):
+                check(rt.lib.cham_rows_scatter(ptr(src), ptr(pl.pos), P, words, ptr(dst), _stream()), "cham_rows_scatter")
         self._eval_iter += 1
         return self.total_loss
 
@@ -740,8 +816,8 @@ class NARModuleModel:
     def outputs_numpy(self):
         pl = self._plan
         torch.cuda.synchronize()
-        return dict(loss=pl.loss.cpu().numpy(), logits=pl.logits.view(pl.B, pl.T, pl.NC).cpu().numpy(),
-                    probs=pl.probs.view(pl.B, pl.T, pl.NC).cpu().numpy(), neg_items=pl.neg_ids.cpu().numpy(),
+        return dict(loss=pl.loss.cpu().numpy(), logits=pl.full_rows(pl.logits).view(pl.B, pl.T, pl.NC).cpu().numpy(),
+                    probs=pl.full_rows(pl.probs).view(pl.B, pl.T, pl.NC).cpu().numpy(), neg_items=pl.neg_ids.cpu().numpy(),
                     neg_slot=pl.neg_slot.cpu().numpy(), pool=pl.pool.cpu().numpy(), meta=pl.meta.cpu().numpy())
 
 

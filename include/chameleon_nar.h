@@ -113,6 +113,10 @@ int cham_ugrnn_point_bwd(const float* dout, const float* carry, const int32_t* s
 /* scheduling hook: recurrent workgroups request this much LDS so that no other workgroup shares their CU */
 void cham_rnn_set_exclusive_lds(size_t bytes);
 int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);
+/* valid-position compaction (the mask of nar_model.py:231 applied as a row selection instead of a multiply): rows are
+ * `words` 32-bit words wide; gather: dst[i] = src[pos[i]], scatter: dst[pos[i]] = src[i] (other rows of dst untouched) */
+int cham_rows_gather(const void* src, const int32_t* pos, long n_rows, int words, void* dst, void* stream);
+int cham_rows_scatter(const void* src, const int32_t* pos, long n_rows, int words, void* dst, void* stream);
 
 /* --- K5 scoring tail + sampled softmax + masked NLL: nar_model.py:478-517, 639-667 */
 int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream);

@@ -49,20 +49,21 @@ def _compare_step(model, orc, f, l, st, check_grads=True):
 def _kink_flips(model, orc, mask):
     """Number of leaky-ReLU outputs whose SIGN differs between the HIP path and the oracle (gradient-carrying rows)."""
     pl, taps = model._plan, orc.debug_taps
-    B, T, NC, BT = pl.B, pl.T, pl.NC, pl.BT
+    B, T, NC, BT, P = pl.B, pl.T, pl.NC, pl.BT, pl.P       # P = rows actually computed (valid positions); full_rows -> [B*T] layout
     n = 0
     for name, hip in (('S1', pl.S1), ('S2', pl.S2), ('S3', pl.S3)):
         pos, neg = taps[name]
         ref = torch.cat([pos.unsqueeze(2), neg], 2).numpy()
-        h = hip.cpu().numpy().reshape(ref.shape)
+        h = pl.full_rows(hip, NC).cpu().numpy().reshape(ref.shape)
         n += int(((h > 0) != (ref > 0))[mask].sum())
     zin, zpos, zneg = taps['Z1']
-    Z1 = pl.Z1.cpu().numpy()
     C = zin.shape[-1]
-    n += int(((Z1[:BT].reshape(B, T, C) > 0) != (zin.numpy() > 0))[mask].sum())
+    Zin = pl.full_rows(pl.Z1[:P]).cpu().numpy()
+    Zc = pl.full_rows(pl.Z1[P:P + P * NC], NC).cpu().numpy()
+    n += int(((Zin.reshape(B, T, C) > 0) != (zin.numpy() > 0))[mask].sum())
     zc = torch.cat([zpos.unsqueeze(2), zneg], 2).numpy()
-    n += int(((Z1[BT:].reshape(B, T, NC, C) > 0) != (zc > 0))[mask].sum())
-    n += int(((pl.FC1.cpu().numpy().reshape(B, T, -1) > 0) != (taps['FC1'][0].numpy() > 0))[mask].sum())
+    n += int(((Zc.reshape(B, T, NC, C) > 0) != (zc > 0))[mask].sum())
+    n += int(((pl.full_rows(pl.FC1).cpu().numpy().reshape(B, T, -1) > 0) != (taps['FC1'][0].numpy() > 0))[mask].sum())
     return n
 
 
@@ -186,6 +187,58 @@ def test_microbatched_step_equals_whole_batch_step(gpu):
     # first Adam step: dw = lr * g / (|g| + eps') is ill-conditioned where |g| ~ eps: compare the moments tightly, weights loosely
     assert float((m1.rt.m - m2.rt.m).abs().max()) < 2e-5 * float(m1.rt.m.abs().max()) + 1e-9
     assert float((m1.rt.flat - m2.rt.flat).abs().max()) < 2.1 * p['lr']
+
+
+@pytest.mark.parametrize("cell,layers", [("ugrnn", 1), ("gru", 2)])
+def test_valid_position_compaction_equals_padded_masked_path(gpu, cell, layers):
+    """Row-wise stages on the non-padded positions only (default) == computing every padded position and masking it
+    (CHAM_COMPACT=0, the reference's formulation): same negatives, logits at valid positions, loss, gradients, Adam step."""
+    p = H.tiny_params(C=128, H=96, neg=9, batch_size=40, rnn_cell=cell, rnn_num_layers=layers)
+    batches = synthetic.make_batches(4, 40, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:2])
+    mc, _ = H.make_pair(p, seed=5)
+    mp, _ = H.make_pair(p, seed=5)
+    mp.rt.compact = False
+    for f, l in batches[2:4]:
+        outs = []
+        for m in (mc, mp):
+            m.feed_state(st.get_articles_recent_pop_norm(), st.get_recent_clicks_buffer())
+            d = m.upload_batch(f, l)
+            m.forward(d); m.backward()
+            torch.cuda.synchronize()
+            outs.append((m.outputs_numpy(), m.rt.grads.clone(), d))
+        (oc, gc, dc), (op, gp, dp_) = outs
+        assert dc['pos'] is not None and dp_['pos'] is None and dc['P'] < dp_['P']
+        mask = np.arange(f['item_clicked'].shape[1])[None, :] < (np.asarray(f['session_size']).reshape(-1, 1) - 1)
+        assert np.array_equal(oc['neg_items'], op['neg_items'])
+        assert np.abs(oc['logits'] - op['logits'])[mask].max() < 1e-5
+        assert np.abs(oc['loss'] - op['loss']).max() < 1e-5
+        assert float((gc - gp).abs().max()) < 2e-5 * float(gp.abs().max()) + 1e-7
+        for m in (mc, mp):
+            m.apply_gradients()
+        H.update_state(st, f, l)
+        assert float((mc.rt.m - mp.rt.m).abs().max()) < 2e-5 * float(mp.rt.m.abs().max()) + 1e-9
+        assert float((mc.rt.flat - mp.rt.flat).abs().max()) < 2.1 * p['lr']
+        # Adam's first steps amplify roundoff where the true gradient is 0 (match4/bias: softmax shift invariance), which would
+        # shift every logit of the next batch: restart both models from the same weights / slots
+        for name in ('flat', 'm', 'v'):
+            getattr(mp.rt, name).copy_(getattr(mc.rt, name))
+
+
+@pytest.mark.parametrize("n_sessions", [1, 3])
+def test_step_parity_handful_of_sessions(gpu, n_sessions):
+    """The short last batch of an hourly file (datasets.py:136: no drop_remainder): a few sessions, a few valid positions -
+    every wgrad reduction is shorter than one split-K chunk."""
+    from chameleon_recsys_amd.nar import parallel
+    p = H.tiny_params()
+    batches = synthetic.make_batches(4, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    f, l = parallel.slice_batch(*batches[3], 5, 5 + n_sessions)
+    T = int(np.asarray(f['session_size']).max()) - 1          # padded_batch pads to the longest session OF THE BATCH
+    f = {k: (v[:, :T] if np.asarray(v).ndim == 2 else v) for k, v in f.items()}
+    l = {k: (v[:, :T] if k == 'label_next_item' else v) for k, v in l.items()}
+    _compare_step(model, orc, f, l, st)
 
 
 def _mode_parity(p, grad_tol, loss_of, check_fwd, flip_sensitive=True):
