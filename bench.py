@@ -242,7 +242,7 @@ def main():
             model.feed_state(state, state)
             model.train_step(rdev[k])
             state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
-        for i in range(max(3, args.warmup)):
+        for i in range(max(n_distinct, args.warmup)):        # every distinct padded length T allocates its StepPlan once
             ragged_step(i)
         barrier()
         t0 = time.perf_counter()

@@ -40,7 +40,7 @@ def _run(dp_world, rank, batches, p):
         losses.append(dp.global_loss().cpu().numpy())
         st.update_from_device_batch(d['aci'], d['g_event_ts'])
     torch.cuda.synchronize()
-    return np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy()
+    return np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy(), getattr(dp, 'emb_sharded', model.rt.layout.emb_end)
 
 
 def _worker(rank, world, port, out_dir, mode):
@@ -49,12 +49,12 @@ def _worker(rank, world, port, out_dir, mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p = _params()
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
-    losses, flat, m = _run(world, rank, batches, p)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=losses, flat=flat, m=m)
+    losses, flat, m, E = _run(world, rank, batches, p)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=losses, flat=flat, m=m, E=E)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "hybrid"])
 def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
@@ -65,12 +65,16 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     if mode == "sharded":       # Adam slots live on the rank that owns the parameter slice
         assert not r0['m'][n:].any() and not r1['m'][:n].any()
         m_dp = np.concatenate([r0['m'][:n], r1['m'][n:]])
+    elif mode == "hybrid":      # embedding-table slots on the owning rank, dense slots replicated
+        E = int(r0['E']); h = E // 2
+        assert E > 0 and not r0['m'][h:E].any() and not r1['m'][:h].any() and np.array_equal(r0['m'][E:], r1['m'][E:])
+        m_dp = np.concatenate([r0['m'][:h], r1['m'][h:E], r0['m'][E:]])
     else:
         assert np.array_equal(r0['m'], r1['m'])
         m_dp = r0['m']
     p = _params()
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
-    losses, flat, m = _run(1, 0, batches, p)
+    losses, flat, m, _ = _run(1, 0, batches, p)
     assert np.abs(losses - r0['losses']).max() < 2e-5, (losses, r0['losses'])
     assert np.abs(m - m_dp).max() < 1e-4 * np.abs(m).max()
     assert np.abs(flat - r0['flat']).max() < 2.1 * p['lr'] * STEPS

@@ -95,3 +95,72 @@ def test_two_rank_gradients_equal_full_batch(tmp_path):
     scale = np.abs(flat).max()
     assert np.abs(got['flat'] - flat).max() < 2e-5 * scale + 1e-7
     assert abs(got['loss'][1] - float(out['xe_loss'])) < 1e-5 and abs(got['loss'][0] - float(out['total_loss'])) < 1e-5
+
+
+# ---- optimizer-step exchange modes (allreduce | sharded | hybrid): same parameters on every rank as the single-process step --
+_N_TOTAL, _N_EMB = 4096, 1500            # flat parameter count, embedding-table region [0, _N_EMB) (not a multiple of world*64)
+
+
+def _toy_adam(flat, m, lr=0.1):
+    def adam(a, b, grads, g_off):         # elementwise update on the parameter range [a, b): what cham_adam_tf does per element
+        g = grads[g_off:g_off + (b - a)]
+        m[a:b] = 0.9 * m[a:b] + 0.1 * g
+        flat[a:b] -= lr * m[a:b] / (g.abs() + 1.0)
+    return adam
+
+
+def _mode_worker(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g0 = torch.Generator().manual_seed(0)
+
+    class _Layout:
+        emb_end = _N_EMB
+
+    class _RT:
+        flat = torch.randn(_N_TOTAL, generator=g0) if rank == 0 else torch.zeros(_N_TOTAL)     # broadcast must replicate rank 0
+        layout = _Layout()
+        dp_rank = dp_world = dp_allreduce = dp_sharded = None
+
+    class _Model:
+        rt = _RT()
+    dp = parallel.DataParallelNAR(_Model(), mode=mode)
+    rt = _Model.rt
+    m = torch.zeros(_N_TOTAL)
+    adam = _toy_adam(rt.flat, m)
+    for step in range(3):
+        grads = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(100 + 10 * step + rank))
+        if rt.dp_sharded is not None:
+            rt.dp_sharded(grads, rt.flat, adam)
+        else:
+            rt.dp_allreduce(grads)
+            adam(0, _N_TOTAL, grads, 0)
+    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), flat=rt.flat.numpy(), m=m.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "hybrid"])
+def test_exchange_modes_match_single_process_step(tmp_path, mode):
+    world = 2
+    mp.spawn(_mode_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    flat = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(0))
+    m = torch.zeros(_N_TOTAL)
+    adam = _toy_adam(flat, m)
+    for step in range(3):
+        g = sum(torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(100 + 10 * step + r)) for r in range(world))
+        adam(0, _N_TOTAL, g, 0)
+    got = [np.load(str(tmp_path / ("%s_rank%d.npz" % (mode, r)))) for r in range(world)]
+    for r in range(world):
+        assert np.allclose(got[r]['flat'], flat.numpy(), atol=1e-6), (mode, r)      # every rank ends with the full updated parameters
+    owned = np.zeros(_N_TOTAL)
+    for r in range(world):
+        owned += (got[r]['m'] != 0)
+        assert np.allclose(got[r]['m'][got[r]['m'] != 0], m.numpy()[got[r]['m'] != 0], atol=1e-6)
+    if mode == "allreduce":
+        assert (owned == world).all()
+    elif mode == "sharded":
+        assert (owned == 1).all()                                                   # every optimizer slot lives on exactly one rank
+    else:
+        E = (_N_EMB // (world * 64)) * (world * 64)
+        assert (owned[:E] == 1).all() and (owned[E:] == world).all()                # tables sharded, dense replicated
