@@ -24,6 +24,11 @@ G1 = dict(n_items=46000, ace_dim=250, seq_len=20, batch=256, neg=50, neg_from_bu
           C=1024, H=255)
 TINY = dict(n_items=1000, ace_dim=64, seq_len=8, batch=64, neg=10, neg_from_buffer=100, buffer=2000, for_norm=200,
             C=1024, H=255)
+# BASELINE.json configs[3]: Adressa-shape (13k articles, seq_len 30, 2-layer GRU hidden 256, 100 negatives); hyper-parameters of
+# the reference's Adressa script
+ADRESSA = dict(n_items=13000, ace_dim=250, seq_len=30, batch=256, neg=100, neg_from_buffer=5000, buffer=20000, for_norm=5000,
+               C=1024, H=256, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2, lr=3e-4,
+               reg_weight_decay=1e-4)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 
 
@@ -114,7 +119,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="g1", choices=["g1", "tiny"])
+    ap.add_argument("--config", default="g1", choices=["g1", "tiny", "adressa"],
+                    help="g1 = BASELINE.json configs[1] (the headline); adressa = configs[3] (2-layer GRU, 100 negatives); tiny = configs[0]")
     ap.add_argument("--length-dist", default="full", choices=["full", "g1"],
                     help="full: every session has seq_len clicks (no padded rows); g1: G1-like ragged lengths")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -143,12 +149,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = G1 if args.config == "g1" else TINY
+    cfg = {"g1": G1, "tiny": TINY, "adressa": ADRESSA}[args.config]
     Bl = cfg['batch']                 # per-GPU batch (weak scaling)
     Bg = Bl * world
     params = synthetic.default_params(cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'], batch_size=Bg, neg=cfg['neg'],
                                       neg_from_buffer=cfg['neg_from_buffer'], buffer_size=cfg['buffer'],
-                                      for_norm=cfg['for_norm'], C=cfg['C'], H=cfg['H'], seed=args.seed)
+                                      for_norm=cfg['for_norm'], C=cfg['C'], H=cfg['H'], seed=args.seed,
+                                      **{k: cfg[k] for k in ('dataset', 'rnn_cell', 'rnn_num_layers', 'softmax_temperature', 'lr',
+                                                             'reg_weight_decay') if k in cfg})
     params['gemm_dtype'] = args.dtype
     n_distinct = 8
     batches = synthetic.make_batches(n_distinct, Bg, cfg['seq_len'], cfg['n_items'], params['session_features_config'],
@@ -263,16 +271,17 @@ def main():
     if rank == 0:
         L = rt.layout
         T = cfg['seq_len'] - 1
-        dense_fwd = dense_step_flops(Bl, T, cfg['neg'], L.F, cfg['C'], cfg['H'])
+        dense_fwd = dense_step_flops(Bl, T, cfg['neg'], L.F, cfg['C'], cfg['H'], cfg.get('rnn_num_layers', 1))
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "NAR training sessions/sec", "value": round(Bg * args.steps / dt, 2), "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "G1-shape synthetic (BASELINE.json configs[1])" if args.config == "g1" else "G1-tiny synthetic",
+            "config": {"workload": {"g1": "G1-shape synthetic (BASELINE.json configs[1])", "tiny": "G1-tiny synthetic (configs[0])",
+                                    "adressa": "Adressa-shape synthetic (BASELINE.json configs[3])"}[args.config],
                        "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
-                       "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": "ugrnn",
+                       "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": DOM_SYMBOL + " = fp32 MFMA GEMM, NN, bias+tanh (CAR layer 2 forward), all launches of a step",

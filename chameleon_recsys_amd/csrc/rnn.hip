@@ -15,7 +15,61 @@
 // profiles/r01_notes.md).
 #include "common.h"
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// branch-free gate non-linearities on v_exp_f32 / v_rcp_f32 (~1e-6 relative; libdevice expf / tanhf /
+// IEEE division cost ~100 VALU instructions per element with divergent range branches - the recurrence is latency-bound)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// acc[j] += A[32 x K] * W[K x (32-column tile j)], j < NA, on v_mfma_f32_32x32x2_f32.
+//   a : this lane's A stream in LDS, already offset to (row = lane & 31, k parity = lane >> 5): element of k-pair p is a[2 p]
+//   w : this lane's W stream in global memory (L2-resident), already offset to (k parity, first column + lane & 31):
+//       element of k-pair p, tile j is w[2 p ldw + off[j]]
+// W comes from L2 with ~1 us latency and the compiler does not software-pipeline a rolled loop (it waits for every load of
+// an unrolled body before the first MFMA: the latency was exposed 16x per time step, 42 us/step measured against a 14 us
+// MFMA floor).  Here the loads of k-block i+1 are issued before the MFMAs of block i (two register blocks, ping-pong).
+template <int K, int NA, int KB>
+__device__ __forceinline__ void mm_stream(floatx16 (&acc)[NA], const float* __restrict__ a, const float* __restrict__ w,
+                                          const size_t ldw, const int (&off)[NA]) {
+    static_assert(K % (4 * KB) == 0, "K must be an even number of k-blocks");
+    constexpr int NB = K / (2 * KB);
+    float w0[KB][NA], w1[KB][NA];           // ping-pong register blocks: one is consumed while the other is in flight
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) w0[i][j] = w[(size_t)(2 * i) * ldw + off[j]];
+#pragma unroll 1
+    for (int blk = 0; blk < NB; blk += 2) {
+        const float* wn = w + (size_t)(2 * (blk + 1) * KB) * ldw;
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) w1[i][j] = wn[(size_t)(2 * i) * ldw + off[j]];
+        __builtin_amdgcn_sched_barrier(0);      // keep the block's loads ahead of the MFMAs (the scheduler sinks them to their use)
+        const float* ab = a + 2 * blk * KB;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float av = ab[2 * i];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[i][j], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // block blk + 2 (the last iteration re-reads the final block: no branch around a memory op, result unused)
+        const float* wnn = w + (size_t)(2 * (blk + 2 < NB ? blk + 2 : NB - 1) * KB) * ldw;
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) w0[i][j] = wnn[(size_t)(2 * i) * ldw + off[j]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float av = ab[2 * (KB + i)];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w1[i][j], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// row of accumulator element e for this lane (32x32 MFMA C/D layout)
+#define ACC_ROW(e, kl) (((e) & 3) + 8 * ((e) >> 2) + 4 * (kl))
 
 // NT = 32-wide hidden tiles per wave (Hp = 128*NT)
 template <int NT, int NTW>
@@ -31,41 +85,50 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_fwd(const float* __res
     for (int i = threadIdx.x; i < 32 * LDH; i += blockDim.x) hL[i] = 0.f;
     __syncthreads();
     const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
+    constexpr int KB = NT <= 2 ? 8 : 4;      // W prefetch depth (registers: 2 KB NA)
+    constexpr bool PF = NT <= 2;             // 12 / 16-wave workgroups have 168 / 128 VGPRs per lane: no room for the x prefetch
+    int sl[16];                              // session lengths of the 16 rows this lane's accumulators cover
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const int b = b0 + ACC_ROW(e, kl); sl[e] = b < B ? seq_len[b] : 0; }
+    int off[2 * NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { off[j] = j * 32; off[NTW + j] = Hp + j * 32; }
     for (int t = 0; t < T; ++t) {
-        floatx16 ag[NTW], ac[NTW];
+        // x_t W_x + b of this step: issued before the recurrent product so that their latency hides behind it
+        float xg[NTW][16], xc[NTW][16];
+        if (PF) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { ag[j][e] = 0.f; ac[j][e] = 0.f; }
-        const float* hrow = hL + fl * LDH + kl;
-        const float* wg = Wh + (size_t)kl * H2 + hid0 + fl;
-#pragma unroll 8
-        for (int k = 0; k < Hp; k += 2) {
-            const float a = hrow[k];
-            const float* w = wg + (size_t)k * H2;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                ag[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ag[j], 0, 0, 0);
-                ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], ac[j], 0, 0, 0);
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const int b = b0 + ACC_ROW(e, kl);
+                    const size_t o = ((size_t)(b < B ? b : 0) * T + t) * H2 + hid0 + j * 32 + fl;
+                    xg[j][e] = xproj[o]; xc[j][e] = xproj[o + Hp];
+                }
         }
+        floatx16 acc[2 * NTW];               // gate tiles, then candidate tiles
+#pragma unroll
+        for (int j = 0; j < 2 * NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        mm_stream<Hp, 2 * NTW, KB>(acc, hL + fl * LDH + kl, Wh + (size_t)kl * H2 + hid0 + fl, H2, off);
         __syncthreads();                                   // every wave finished reading h_{t-1}
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int row = ACC_ROW(e, kl);
                 const int b = b0 + row;
                 if (b >= B) continue;
                 const size_t bt = (size_t)b * T + t;
-                const float zg = ag[j][e] + xproj[bt * H2 + hid];
-                const float zc = ac[j][e] + xproj[bt * H2 + Hp + hid];
+                const float zg = acc[j][e] + (PF ? xg[j][e] : xproj[bt * H2 + hid]);
+                const float zc = acc[NTW + j][e] + (PF ? xc[j][e] : xproj[bt * H2 + Hp + hid]);
                 const float g = sigmoidf_(zg + 1.0f);      // forget_bias = 1.0
-                const float c = tanhf(zc);
+                const float c = cham_tanhf(zc);
                 const float ho = hL[row * LDH + hid];
                 const float hn = g * ho + (1.f - g) * c;
-                const bool valid = t < seq_len[b];
+                const bool valid = t < sl[e];
                 out[bt * Hp + hid] = valid ? hn : 0.f;
                 hprev[bt * Hp + hid] = ho;
                 G[bt * Hp + hid] = g;
@@ -90,11 +153,32 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_bwd(const float* __res
     const int b0 = blockIdx.x * 32;
     const int fl = lane & 31, kl = lane >> 5;
     const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
+    constexpr int KB = NT <= 2 ? 8 : 4;
+    constexpr bool PF = NT <= 2;                             // prefetch step t-1's saved activations behind step t's product
+    int sl[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const int b = b0 + ACC_ROW(e, kl); sl[e] = b < B ? seq_len[b] : 0; }
+    int off[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) off[j] = j * 32;
     floatx16 carry[NTW];                                     // dL/dh_t flowing to step t (accumulator layout)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) carry[j][e] = 0.f;
+    float pd[NTW][16], pg[NTW][16], pc[NTW][16], ph[NTW][16];    // dout, g, c, h_prev of the step being processed
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int b = b0 + ACC_ROW(e, kl);
+                const bool on = t >= 0 && t < sl[e];
+                const size_t o = ((size_t)(on ? b : 0) * T + (on ? t : 0)) * Hp + hid0 + j * 32 + fl;
+                pd[j][e] = dout[o]; pg[j][e] = G[o]; pc[j][e] = Cc[o]; ph[j][e] = hprev[o];
+            }
+    };
+    if (PF) fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         floatx16 direct[NTW];
 #pragma unroll
@@ -102,13 +186,13 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_bwd(const float* __res
             const int hid = hid0 + j * 32 + fl;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int row = ACC_ROW(e, kl);
                 const int b = b0 + row;
                 float dzg = 0.f, dzc = 0.f, dd = 0.f;
-                if (b < B && t < seq_len[b]) {
+                if (t < (PF ? sl[e] : (b < B ? seq_len[b] : 0))) {
                     const size_t o = ((size_t)b * T + t) * Hp + hid;
-                    const float dh = dout[o] + carry[j][e];
-                    const float g = G[o], c = Cc[o], hp = hprev[o];
+                    const float dh = (PF ? pd[j][e] : dout[o]) + carry[j][e];
+                    const float g = PF ? pg[j][e] : G[o], c = PF ? pc[j][e] : Cc[o], hp = PF ? ph[j][e] : hprev[o];
                     dzg = dh * (hp - c) * g * (1.f - g);
                     dzc = dh * (1.f - g) * (1.f - c * c);
                     dd = dh * g;
@@ -124,28 +208,19 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_ugrnn_bwd(const float* __res
             }
         }
         __syncthreads();
+        if (PF) fetch(t - 1);
         floatx16 acc[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        const float* zrow = dzL + fl * LDZ + kl;
-        const float* wt = WhT + (size_t)kl * Hp + hid0 + fl;
-#pragma unroll 8
-        for (int k = 0; k < H2; k += 2) {
-            const float a = zrow[k];
-            const float* w = wt + (size_t)k * Hp;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
-        }
+        mm_stream<H2, NTW, KB>(acc, dzL + fl * LDZ + kl, WhT + (size_t)kl * Hp + hid0 + fl, Hp, off);
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * kl;
-                const int b = b0 + row;
-                const bool valid = (b < B) && (t < seq_len[b]);
-                carry[j][e] = valid ? (direct[j][e] + acc[j][e]) : carry[j][e];
+                const int b = b0 + ACC_ROW(e, kl);
+                carry[j][e] = (t < (PF ? sl[e] : (b < B ? seq_len[b] : 0))) ? (direct[j][e] + acc[j][e]) : carry[j][e];
             }
         __syncthreads();                                   // dzL is rewritten by the next step
     }
@@ -175,26 +250,32 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_fwd(const float* __restr
     for (int i = threadIdx.x; i < 64 * LDH; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
+    constexpr int KB = NT <= 2 ? 8 : 4;
+    constexpr bool PF = NT <= 2;
+    int off1[NTW], off2[2 * NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { off1[j] = j * 32; off2[j] = j * 32; off2[NTW + j] = Hp + j * 32; }
     for (int t = 0; t < T; ++t) {
-        floatx16 ar[NTW], au[NTW];
+        // x_t W_x + b of this step: issued before the recurrent products so that their latency hides behind them
+        float xr[NTW][16], xu[NTW][16], xc[NTW][16];
+        if (PF) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { ar[j][e] = 0.f; au[j][e] = 0.f; }
-        {
-            const float* hrow = hL + fl * LDH + kl;
-            const float* wg = Wgh + (size_t)kl * H2 + hid0 + fl;
-#pragma unroll 8
-            for (int k = 0; k < Hp; k += 2) {
-                const float a = hrow[k];
-                const float* w = wg + (size_t)k * H2;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    ar[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ar[j], 0, 0, 0);
-                    au[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[Hp + j * 32], au[j], 0, 0, 0);
+                for (int e = 0; e < 16; ++e) {
+                    const int b = b0 + ACC_ROW(e, kl);
+                    const size_t o = ((size_t)(b < B ? b : 0) * T + t) * H3 + hid0 + j * 32 + fl;
+                    xr[j][e] = xproj[o]; xu[j][e] = xproj[o + Hp]; xc[j][e] = xproj[o + H2];
                 }
-            }
         }
+        floatx16 aru[2 * NTW];               // reset-gate tiles, then update-gate tiles
+#pragma unroll
+        for (int j = 0; j < 2 * NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) aru[j][e] = 0.f;
+        mm_stream<Hp, 2 * NTW, KB>(aru, hL + fl * LDH + kl, Wgh + (size_t)kl * H2 + hid0 + fl, H2, off2);
+        floatx16 (&ar)[NTW] = *reinterpret_cast<floatx16 (*)[NTW]>(&aru[0]);
+        floatx16 (&au)[NTW] = *reinterpret_cast<floatx16 (*)[NTW]>(&aru[NTW]);
         // gates; r*h -> LDS (each wave writes its own hidden columns of rhL; hL is only read here)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -206,8 +287,8 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_fwd(const float* __restr
                 float r = 0.f, u = 0.f;
                 if (b < B) {
                     const size_t bt = (size_t)b * T + t;
-                    r = sigmoidf_(ar[j][e] + xproj[bt * H3 + hid]);
-                    u = sigmoidf_(au[j][e] + xproj[bt * H3 + Hp + hid]);
+                    r = sigmoidf_(ar[j][e] + (PF ? xr[j][e] : xproj[bt * H3 + hid]));
+                    u = sigmoidf_(au[j][e] + (PF ? xu[j][e] : xproj[bt * H3 + Hp + hid]));
                 }
                 ar[j][e] = r; au[j][e] = u;
                 rhL[row * LDH + hid] = r * hL[row * LDH + hid];
@@ -219,17 +300,7 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_fwd(const float* __restr
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) ac[j][e] = 0.f;
-        {
-            const float* rrow = rhL + fl * LDH + kl;
-            const float* wc = Wch + (size_t)kl * Hp + hid0 + fl;
-#pragma unroll 8
-            for (int k = 0; k < Hp; k += 2) {
-                const float a = rrow[k];
-                const float* w = wc + (size_t)k * Hp;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) ac[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], ac[j], 0, 0, 0);
-            }
-        }
+        mm_stream<Hp, NTW, KB>(ac, rhL + fl * LDH + kl, Wch + (size_t)kl * Hp + hid0 + fl, Hp, off1);
         __syncthreads();                                   // all reads of hL / rhL of this step are done
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -240,7 +311,7 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_fwd(const float* __restr
                 const int b = b0 + row;
                 if (b >= B) continue;
                 const size_t bt = (size_t)b * T + t;
-                const float c = tanhf(ac[j][e] + xproj[bt * H3 + H2 + hid]);
+                const float c = cham_tanhf(ac[j][e] + (PF ? xc[j][e] : xproj[bt * H3 + H2 + hid]));
                 const float ho = hL[row * LDH + hid];
                 const float r = ar[j][e], u = au[j][e];
                 const float hn = u * ho + (1.f - u) * c;
@@ -272,6 +343,10 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_bwd(const float* __restr
     const int hid0 = wave * (32 * NTW);      // 4 * NT / NTW waves, NTW 32-wide hidden tiles each
     const float* WghT = WhT;
     const float* WchT = WhT + (size_t)H2 * Hp;
+    constexpr int KB = NT <= 2 ? 8 : 4;
+    int off1[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) off1[j] = j * 32;
     floatx16 carry[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -307,17 +382,7 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_bwd(const float* __restr
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        {
-            const float* zrow = dcL + fl * LDC + kl;
-            const float* wt = WchT + (size_t)kl * Hp + hid0 + fl;
-#pragma unroll 8
-            for (int k = 0; k < Hp; k += 2) {
-                const float a = zrow[k];
-                const float* w = wt + (size_t)k * Hp;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
-            }
-        }
+        mm_stream<Hp, NTW, KB>(acc, dcL + fl * LDC + kl, WchT + (size_t)kl * Hp + hid0 + fl, Hp, off1);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int hid = hid0 + j * 32 + fl;
@@ -347,17 +412,7 @@ __global__ __launch_bounds__(256 * NT / NTW) void k_gru_bwd(const float* __restr
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        {
-            const float* zrow = dzL + fl * LDZ + kl;
-            const float* wt = WghT + (size_t)kl * Hp + hid0 + fl;
-#pragma unroll 8
-            for (int k = 0; k < H2; k += 2) {
-                const float a = zrow[k];
-                const float* w = wt + (size_t)k * Hp;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j * 32], acc[j], 0, 0, 0);
-            }
-        }
+        mm_stream<H2, NTW, KB>(acc, dzL + fl * LDZ + kl, WghT + (size_t)kl * Hp + hid0 + fl, Hp, off1);
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -544,7 +599,7 @@ __global__ __launch_bounds__(256) void k_ugrnn_point_fwd(const float* __restrict
     const int b = i / Hp, hid = i % Hp;
     const size_t bt = (size_t)b * T + t, o = bt * Hp + hid;
     const float g = sigmoidf_(zh[(size_t)b * 2 * Hp + hid] + xproj[bt * 2 * Hp + hid] + 1.0f);
-    const float c = tanhf(zh[(size_t)b * 2 * Hp + Hp + hid] + xproj[bt * 2 * Hp + Hp + hid]);
+    const float c = cham_tanhf(zh[(size_t)b * 2 * Hp + Hp + hid] + xproj[bt * 2 * Hp + Hp + hid]);
     const float ho = h[i], hn = g * ho + (1.f - g) * c;
     const bool valid = t < seq_len[b];
     out[o] = valid ? hn : 0.f; hprev[o] = ho; G[o] = g; Cc[o] = c;
