@@ -99,19 +99,26 @@ def hitrate_parity(seed):
         train.feed_state(pop, buf); train.train_step(train.upload_batch(f, l))
         orc.train_step(f, l, buf, pop)
         st.update_items_state(*batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']))
-    m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "cpu_oracle")}
+    # third column: the oracle EVALUATING THE HIP-TRAINED WEIGHTS - separates the eval path (must agree to the last hit) from the
+    # divergence of two fp32 training runs (30 Adam steps at lr 1e-3 amplify last-bit differences; the per-step bounds are in
+    # tests/test_step_gpu.py::test_training_curve_matches_oracle)
+    orc_hw = NAROracle(p, weights=rt.logical_weights())
+    m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "cpu_oracle", "cpu_oracle_on_hip_weights")}
     for i, (f, l) in enumerate(batches[30:]):
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         ev.feed_state(pop, buf); ev.evaluate_step(ev.upload_batch(f, l))
         ids = ev.predicted_item_ids.eval()
-        ref = orc.forward(f, l, buf, pop, mode='eval', step=NARModuleModel.eval_step_key(orc.global_step, i))
-        for k, pred in (("hip", ids), ("cpu_oracle", ref['predicted_item_ids'].numpy())):
+        key = NARModuleModel.eval_step_key(orc.global_step, i)
+        ref = orc.forward(f, l, buf, pop, mode='eval', step=key)
+        ref_hw = orc_hw.forward(f, l, buf, pop, mode='eval', step=key)
+        for k, pred in (("hip", ids), ("cpu_oracle", ref['predicted_item_ids'].numpy()),
+                        ("cpu_oracle_on_hip_weights", ref_hw['predicted_item_ids'].numpy())):
             m[k][0].add(pred, l['label_next_item']); m[k][1].add(pred, l['label_next_item'])
         st.update_items_state(*batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']))
     return {"hitrate_at_5": {k: round(v[0].result(), 5) for k, v in m.items()},
             "mrr_at_5": {k: round(float(v[1].result()), 5) for k, v in m.items()},
-            "protocol": "G1-tiny synthetic, 30 training steps + 4 eval batches x 64 sessions, 20 eval negatives, same weights / inputs / "
-                        "negatives on both sides"}
+            "protocol": "G1-tiny synthetic, 30 training steps (lr 1e-3) + 4 eval batches x 64 sessions, 20 eval negatives; same initial "
+                        "weights / inputs / negatives on both sides; cpu_oracle_on_hip_weights = the oracle evaluating the HIP-trained weights"}
 
 
 def main():
@@ -127,6 +134,8 @@ def main():
                     help="f32: exact fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16-rounded GEMM operands, fp32 accumulate/"
                          "storage/softmax/loss/Adam (BASELINE configs[2] arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ragged-leg", action="store_true",
+                    help="skip the secondary G1-like-session-lengths leg (profiling runs: keeps per-symbol averages to the headline leg)")
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
@@ -240,7 +249,7 @@ def main():
     # variant (no padded positions: the most work a session can carry); with ragged sessions the step runs its row-wise
     # stages on the valid positions only (nar_model.upload_batch), so sessions/s rises with the padding fraction.
     ragged = None
-    if args.length_dist == "full" and args.state == "device":
+    if args.length_dist == "full" and args.state == "device" and not args.no_ragged_leg:
         rb = synthetic.make_batches(n_distinct, Bg, cfg['seq_len'], cfg['n_items'], params['session_features_config'],
                                     seed=args.seed + 1, length_dist="g1", sessions_per_hour=Bg * 2)
         rdev = [dp.upload(f, l) for f, l in rb]
