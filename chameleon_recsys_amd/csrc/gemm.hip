@@ -31,6 +31,7 @@
 //   * epilogue (compile-time specialised): bias + {none, leaky_relu(0.2), tanh}; or multiply by act'(saved output)
 //     for dgrad; optional accumulate.  Split-K (grid.y) writes raw partials, reduced in fixed order (deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define OOB_OFF 0x80000000u          // > every window size below: loads return 0, stores are dropped
@@ -727,8 +728,16 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
         // small to fill 256 CUs
         // measured on MI355X at the CAR shapes (profiles/r01_gemm_variants.md): NN 256x128 126-130 TFLOP/s; NT (dgrad) and
         // TN (wgrad, long K) prefer the 256x256 tile (123 / 133 TFLOP/s)
+        // the largest tile whose grid still gives every one of the 256 CUs a workgroup (a 4 864-row GEMM on 256x256 tiles is 76
+        // workgroups: 70 % of the chip idle)
+        auto grid = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.splits; };
+        static const bool by_area = getenv("CHAM_GEMM_TILE_BY_AREA") != nullptr;      // A/B switch: the rule of builds a-h
         int v = ((long)p.M * p.N >= (1L << 20)) ? 2 : 0;
         if (v == 2 && (!AK || BKC) && p.K >= 512 && p.M >= 1024 && p.N >= 512) v = 4;
+        if (!by_area) {       // ... demoted while the grid does not cover the chip
+            if (v == 4 && grid(256, 256) < 256) v = 2;
+            if (v == 2 && grid(256, 128) < 256) v = 0;
+        }
         if (g_variant >= 0) v = g_variant;
         switch (v) {      // (other tile shapes were measured and dropped: profiles/r01_notes.md items 3 and 9)
             case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
@@ -743,7 +752,8 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
 template <bool AK, bool BKC>
 static int launch_by_shape_bf16(GemmParams& p, hipStream_t st) {
     if (p.N > 64) {
-        if ((long)p.M * p.N >= (1L << 20)) return launch_cfg<256, 128, 4, 2, 32, AK, BKC, true>(p, st);
+        if ((long)p.M * p.N >= (1L << 20) && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splits >= 256)
+            return launch_cfg<256, 128, 4, 2, 32, AK, BKC, true>(p, st);
         return launch_cfg<128, 128, 2, 2, 32, AK, BKC, true>(p, st);
     }
     if (p.N > 32) return launch_cfg<256, 64, 4, 1, 32, AK, BKC, true>(p, st);
