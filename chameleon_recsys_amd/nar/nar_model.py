@@ -677,7 +677,13 @@ class NARModuleModel:
                         dxp = pl.dxproj_c
                         check(lib.cham_rows_gather(ptr(pl.dxproj), ptr(pos), BT, NGH, ptr(dxp), ss), "cham_rows_gather")
                     rt.gemm(dxp, p('rnn0/Wx'), pl.dZ2, BT, C, NGH, NGH, NGH, C, transB=1, dref=pl.Z2, ldr=C, dact=ACT_TANH)
-                    e_dZ2in = mark()
+                    # CAR layer-2 dgrad of the clicked rows right here (0.1 ms; behind the W2 wgrad it would starve: that kernel's
+                    # 256 workgroups fill every CU's register file for 4 ms) - the main lane's PreCAR backward waits for it ...
+                    rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+                    e_dZ1in = mark()
+                    # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
+                    rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
+                    rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
@@ -687,9 +693,6 @@ class NARModuleModel:
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
                     rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BTf, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
                 rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn%d/b' % l))
-            # CAR layer-2 weight gradient over ALL rows (needs dZ2 of the clicked rows from just above)
-            rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
-            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
         # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only).  W2 is transposed once (4 MB) so
         # that the 520-GFLOP dgrad runs in the NN layout (B tile staged with ds_write_b128 instead of 4 x ds_write_b32:
         # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
@@ -699,18 +702,13 @@ class NARModuleModel:
         else:
             rt.gemm(pl.dZ2[BT:Rall], p('W2'), pl.dZ1[BT:Rall], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
         if on:
-            main_wait(e_dZ2in)
-        if rt.dgrad_nn:
-            rt.gemm(pl.dZ2, pl.W2T, pl.dZ1, BT, C, C, C, C, C, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
-        else:
-            rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
+            main_wait(e_dZ1in)
         check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
                                    rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
-        e_dUV = mark()
-        with side(e_dUV):
-            rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
-            rt.colsum(pl.dU, C, BT, C, g('b1'))
-            rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+        # PreCAR weight gradients stay on this lane (the side lane is busy with the W2 wgrad until the end of the step)
+        rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+        rt.colsum(pl.dU, C, BT, C, g('b1'))
+        rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
         rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
         rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
         # scale/center + embedding tables
