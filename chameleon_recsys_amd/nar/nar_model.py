@@ -127,6 +127,7 @@ class NARRuntime:
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
         import os
         self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "-1")))
+        self.aux_stream = torch.cuda.Stream(device=dev, priority=-1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
         # Measured on MI355X (profiles/r01_notes.md): with a HIGH-PRIORITY side stream the 8 recurrent workgroups get
@@ -137,6 +138,7 @@ class NARRuntime:
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
         self.compact = os.environ.get("CHAM_COMPACT", "1") == "1"
+        self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -620,26 +622,42 @@ class NARModuleModel:
                                          self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']),
                                          ptr(pl.logits), ptr(pl.nov_aux), s),
               "cham_score_softmax_bwd")
-        e_dS3 = mark()
-        with side(e_start, e_dS3):
-            rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
-            rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
-            rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
-            rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
+        # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
+        # matrix work that then runs beside the HBM-bound k_mulpred_bwd instead of beside the MFMA-bound CAR dgrad - and the small
+        # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it
         rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
-        e_dS2 = mark()
-        with side(e_dS2):
-            rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
-            rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
         rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
         e_dS1 = mark()
         Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
-        with side(e_dS1):
+        with side(e_start, e_dS1):
             rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
             rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
+            rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
+            rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
+            rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
+            rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
+            rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
+            rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
         rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
-        check(lib.cham_mulpred_bwd(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s), "cham_mulpred_bwd")
-        e_dZ2c = mark()                  # dZ2c final + dpred
+        # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
+        # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
+        # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
+        half = BT // 2 if (on and rt.split_mulpred and BT >= 256) else BT
+
+        def mulpred(g0, g1):
+            check(lib.cham_mulpred_bwd(ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N,
+                                       ptr(pl.dpred[g0:g1]), _stream()), "cham_mulpred_bwd")
+        mulpred(0, half)
+        e_halfB = None
+        if half < BT:
+            e_halfA = mark()
+            rt.aux_stream.wait_event(e_halfA)
+            with torch.cuda.stream(rt.aux_stream):
+                mulpred(half, BT)
+                e_halfB = mark()
+            e_dZ2c = e_halfB
+        else:
+            e_dZ2c = mark()              # dZ2c final + dpred
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
         with side(e_dZ2c):
@@ -698,9 +716,15 @@ class NARModuleModel:
         # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
         if rt.dgrad_nn:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
-            rt.gemm(pl.dZ2[BT:Rall], pl.W2T, pl.dZ1[BT:Rall], Rc, C, C, C, C, C, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
-        else:
-            rt.gemm(pl.dZ2[BT:Rall], p('W2'), pl.dZ1[BT:Rall], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
+        for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
+            if r1 <= r0:
+                continue
+            if ev is not None:
+                main_wait(ev)
+            if rt.dgrad_nn:
+                rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
+            else:
+                rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
         if on:
             main_wait(e_dZ1in)
         check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
