@@ -104,7 +104,12 @@ class DeviceClickedItemsState:
     """The same state kept in HBM: recent-clicks ring buffer (ids, timestamps), recent popularity histogram,
     ``articles_recent_pop_norm`` (float32, what the graph is fed) and global popularity, updated by the HIP kernels of
     csrc/state.hip straight from the batch tensors the step already has on the device - no host round trip per step.
-    Same public methods as ClickedItemsState (the getters download); bit-identical results (tests/test_state_gpu.py)."""
+    Same public methods as ClickedItemsState (the getters download); bit-identical results (tests/test_state_gpu.py).
+
+    The update only depends on the batch's ids / timestamps, not on the training step, so it runs on its own stream as soon as
+    the step has finished READING the state (NARModuleModel calls note_consumed() after its last state read; the next
+    feed_state waits for `updated_event`): ~0.25 ms of small kernels leave the critical path.  CHAM_STATE_ASYNC=0 keeps the
+    update on the caller's stream."""
     is_device = True
 
     def __init__(self, recent_clicks_buffer_hours, recent_clicks_buffer_max_size, recent_clicks_for_normalization, num_items,
@@ -119,6 +124,9 @@ class DeviceClickedItemsState:
         self.recent_clicks_for_normalization = recent_clicks_for_normalization
         self.num_items = num_items
         self._ws = None
+        import os
+        self.stream = torch.cuda.Stream(device=self.device) if os.environ.get("CHAM_STATE_ASYNC", "1") == "1" else None
+        self.updated_event, self.consumed_event, self._consumed_key = None, None, None
         self.reset_state()
 
     def reset_state(self):
@@ -132,6 +140,26 @@ class DeviceClickedItemsState:
         self.n_valid = t.zeros(1, dtype=t.int32, device=dev)
         self.n_updates = 0
         self.current_step = 0
+        self._after_host_side_change()
+
+    # ---- stream ordering
+    def _after_host_side_change(self):
+        """State tensors were (re)created on the caller's stream: later updates on the state stream must come after that."""
+        if self.stream is not None:
+            self.stream.wait_stream(self.torch.cuda.current_stream())
+            self.consumed_event = None
+
+    def sync_to_current(self):
+        """Every reader of the state tensors on another stream calls this first."""
+        if self.updated_event is not None:
+            self.torch.cuda.current_stream().wait_event(self.updated_event)
+
+    def note_consumed(self, aci):
+        """Called by the step after its last read of the state; `aci` identifies the batch whose update may now start."""
+        if self.stream is not None:
+            ev = self.torch.cuda.Event()
+            ev.record()
+            self.consumed_event, self._consumed_key = ev, aci.data_ptr()
 
     # ---- updates
     def update_from_device_batch(self, aci, event_ts):
@@ -142,11 +170,23 @@ class DeviceClickedItemsState:
         need = self.lib.cham_state_workspace_bytes(B, self.recent_clicks_buffer_max_size)
         if self._ws is None or self._ws.numel() < need:
             self._ws = t.empty(need, dtype=t.uint8, device=self.device)
-        check(self.lib.cham_state_update(ptr(aci), ptr(event_ts), B, T1 - 1, float(self.recent_clicks_buffer_hours),
-                                         ptr(self.buf_ids), ptr(self.buf_ts), self.recent_clicks_buffer_max_size,
-                                         ptr(self.recent_pop), ptr(self.pop_norm), ptr(self.articles_pop), self.num_items,
-                                         self.recent_clicks_for_normalization, ptr(self.n_valid), ptr(self._ws), self._ws.numel(),
-                                         t.cuda.current_stream().cuda_stream), "cham_state_update")
+        st = t.cuda.current_stream()
+        if self.stream is not None:
+            if self.consumed_event is not None and self._consumed_key == aci.data_ptr():
+                self.stream.wait_event(self.consumed_event)        # the step that uploaded this batch is done reading the state
+            else:
+                self.stream.wait_stream(st)                        # unknown producer of the inputs: fully ordered
+            self.consumed_event = None
+            st = self.stream
+        with t.cuda.stream(st):
+            check(self.lib.cham_state_update(ptr(aci), ptr(event_ts), B, T1 - 1, float(self.recent_clicks_buffer_hours),
+                                             ptr(self.buf_ids), ptr(self.buf_ts), self.recent_clicks_buffer_max_size,
+                                             ptr(self.recent_pop), ptr(self.pop_norm), ptr(self.articles_pop), self.num_items,
+                                             self.recent_clicks_for_normalization, ptr(self.n_valid), ptr(self._ws), self._ws.numel(),
+                                             st.cuda_stream), "cham_state_update")
+            if self.stream is not None:
+                self.updated_event = t.cuda.Event()
+                self.updated_event.record()
         self.n_updates += 1
 
     def update_items_state(self, batch_clicked_items, batch_clicked_timestamps):
@@ -159,19 +199,24 @@ class DeviceClickedItemsState:
 
     # ---- the reference's getters (download)
     def get_recent_clicks_buffer(self):
+        self.sync_to_current()
         return self.buf_ids.cpu().numpy()
 
     def get_articles_recent_pop_norm(self):
+        self.sync_to_current()
         return self.pop_norm.cpu().numpy()
 
     def get_articles_recent_pop(self):
+        self.sync_to_current()
         return self.recent_pop.cpu().numpy().astype(np.int64)
 
     def get_articles_pop(self):
+        self.sync_to_current()
         return self.articles_pop.cpu().numpy()
 
     @property
     def pop_recent_clicks_buffer(self):
+        self.sync_to_current()
         return np.stack([self.buf_ids.cpu().numpy(), self.buf_ts.cpu().numpy()], axis=1)
 
     def increment_current_step(self):
@@ -182,9 +227,12 @@ class DeviceClickedItemsState:
 
     # ---- snapshot around evaluation (clicked_items_state.py:49-79: buffer + global pop; pop_norm is NOT restored)
     def save_state_checkpoint(self):
+        self.sync_to_current()
         self._chkp = (self.articles_pop.clone(), self.buf_ids.clone(), self.buf_ts.clone(), self.n_valid.clone(),
                       self.n_updates, self.current_step)
 
     def restore_state_checkpoint(self):
+        self.sync_to_current()          # the update still in flight writes the tensors that are being replaced
         self.articles_pop, self.buf_ids, self.buf_ts, self.n_valid, self.n_updates, self.current_step = self._chkp
         del self._chkp
+        self._after_host_side_change()

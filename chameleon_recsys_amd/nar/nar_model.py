@@ -400,6 +400,7 @@ class NARModuleModel:
     # ------------------------------------------------------------------ host -> device
     def feed_device_state(self, state):
         """Device-resident state (clicked_items_state.DeviceClickedItemsState): nothing is uploaded."""
+        state.sync_to_current()           # the previous batch's update runs on the state's own stream
         self.articles_recent_pop_norm = state
         self.pop_recent_items_buffer = state
         self._dev_state = dict(buffer=state.buf_ids, pop_norm=state.pop_norm, last=state.buf_ids,
@@ -572,6 +573,8 @@ class NARModuleModel:
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
         self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
+        if not self.is_training and st.get('device'):
+            self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in an EVAL step
         return pl
 
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
@@ -622,6 +625,8 @@ class NARModuleModel:
                                          self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']),
                                          ptr(pl.logits), ptr(pl.nov_aux), s),
               "cham_score_softmax_bwd")
+        if self._dev_state.get('device'):
+            self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
         # matrix work that then runs beside the HBM-bound k_mulpred_bwd instead of beside the MFMA-bound CAR dgrad - and the small
         # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it

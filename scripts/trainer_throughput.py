@@ -23,13 +23,14 @@ def main():
     ap.add_argument("--hours", type=int, default=4)
     ap.add_argument("--sessions-per-hour", type=int, default=5120)
     ap.add_argument("--state", default="device", choices=["device", "host"])
+    ap.add_argument("--length-dist", default="full", choices=["full", "g1"], help="session lengths of the generated files")
     a = ap.parse_args()
     import torch
     from chameleon_recsys_amd.nar import datasets, nar_trainer_gcom as T, synthetic
     from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, DeviceClickedItemsState
     d = tempfile.mkdtemp(prefix="cham_g1_")
     t0 = time.time()
-    files, csv, pkl = synthetic.write_dataset(d, a.hours + 1, a.sessions_per_hour, 46000, 250, seq_len=20, seed=42, length_dist='full')
+    files, csv, pkl = synthetic.write_dataset(d, a.hours + 1, a.sessions_per_hour, 46000, 250, seq_len=20, seed=42, length_dist=a.length_dist)
     gen_s = time.time() - t0
     argv = ['--batch_size', '256', '--truncate_session_length', '20', '--learning_rate', '1e-4', '--reg_l2', '1e-5',
             '--softmax_temperature', '0.1', '--recent_clicks_buffer_max_size', '20000', '--recent_clicks_for_normalization', '2000',
@@ -61,7 +62,7 @@ def main():
     n = sum(len(f['session_id']) for f, _ in datasets.SessionDataset(files[1:a.hours + 1], scfg, batch_size=256, truncate_sequence_length=20))
     dt_in = time.time() - t2
     print(json.dumps(dict(workload="G1-shape synthetic via the Estimator boundary (TFRecord files -> input_fn -> model_fn)",
-                          clicked_items_state=a.state, steps=steps, sessions=steps * 256, seconds=round(dt, 3),
+                          clicked_items_state=a.state, session_lengths=a.length_dist, steps=steps, sessions=steps * 256, seconds=round(dt, 3),
                           sessions_per_s=round(steps * 256 / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
                           includes="GZIP+TFRecord+protobuf decode, H2D copies of every batch, hooks, checkpoint at the end",
                           input_pipeline_alone_sessions_per_s=round(n / dt_in, 1), dataset_generation_s=round(gen_s, 1))), flush=True)
