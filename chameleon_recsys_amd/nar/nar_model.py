@@ -10,6 +10,7 @@ PyTorch is only used for device memory, streams and (data-parallel) torch.distri
 runs in the hand-written HIP kernels.  There is no CPU fallback.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -632,8 +633,10 @@ class NARModuleModel:
         # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it
         rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
         rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
-        e_dS1 = mark()
         Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
+        e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
+        #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
+        rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         with side(e_start, e_dS1):
             rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
             rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
@@ -643,7 +646,6 @@ class NARModuleModel:
             rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
             rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
             rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
-        rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
         # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
         # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
