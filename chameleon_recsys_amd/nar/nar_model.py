@@ -139,6 +139,11 @@ class NARRuntime:
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
         self.compact = os.environ.get("CHAM_COMPACT", "1") == "1"
+        # backward tail schedule (profiles/r01_notes.md item 18): the PreCAR backward on the (high-priority) side lane beside the W2
+        # wgrad on the main lane, the wgrad split finer than the chip needs so that its workgroups retire in rounds
+        # - measured neutral (16.95-17.13 ms both ways; 64 splits 17.6 ms): experiment switch, default off
+        self.tail_on_side = os.environ.get("CHAM_TAIL_ON_SIDE", "0") == "1"
+        self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
@@ -245,6 +250,8 @@ class StepPlan:
         need = rt.lib.cham_combine_bwd_workspace_bytes(L.C, B * T, N, 20 * N)
         if need > rt.gemm_ws.numel() * 4:
             rt.gemm_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        if need > rt.gemm_ws_side.numel() * 4:
+            rt.gemm_ws_side = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         self.ws_bytes = rt.lib.cham_neg_sample_workspace_bytes(Bg * (T + 1), int(rt.params['recent_clicks_buffer_max_size']), n_buf)
         self.sampler_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         # features
@@ -596,6 +603,7 @@ class NARModuleModel:
         cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         p, g = rt.p, rt.g
         main_stream, on = torch.cuda.current_stream(), rt.overlap
+        swap = on and rt.tail_on_side
 
         def mark():                      # event on the current stream
             if not on:
@@ -706,9 +714,10 @@ class NARModuleModel:
                     # 256 workgroups fill every CU's register file for 4 ms) - the main lane's PreCAR backward waits for it ...
                     rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
                     e_dZ1in = mark()
-                    # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
-                    rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
-                    rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+                    if not swap:
+                        # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
+                        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
+                        rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
@@ -732,22 +741,37 @@ class NARModuleModel:
                 rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
             else:
                 rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
-        if on:
-            main_wait(e_dZ1in)
-        check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(rt.gemm_ws),
-                                   rt.gemm_ws.numel() * 4, s), "cham_combine_bwd")
-        # PreCAR weight gradients stay on this lane (the side lane is busy with the W2 wgrad until the end of the step)
-        rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
-        rt.colsum(pl.dU, C, BT, C, g('b1'))
-        rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
-        rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
-        rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
-        # scale/center + embedding tables
-        check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(rt.ctx_desc), ptr(p('gamma_ctx')), 0, ptr(d['cat']),
-                                   None, None, 0, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), ptr(rt.grads), s), "cham_feature_bwd")
-        check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(rt.item_desc), ptr(p('gamma_item')), 1, None,
-                                   ptr(pl.ids_all), ptr(rt.meta_cat), rt.n_items, ptr(g('gamma_item')), ptr(g('beta_item')),
-                                   ptr(rt.grads), s), "cham_feature_bwd")
+        def precar_backward(ws):
+            """PreCAR combine scatter, W1 weight gradients, feature / embedding backward (on whatever lane is current)."""
+            st = _stream()
+            check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
+                  "cham_combine_bwd")
+            rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+            rt.colsum(pl.dU, C, BT, C, g('b1'))
+            rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+            rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
+            rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
+            # scale/center + embedding tables
+            check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(rt.ctx_desc), ptr(p('gamma_ctx')), 0, ptr(d['cat']),
+                                       None, None, 0, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), ptr(rt.grads), st), "cham_feature_bwd")
+            check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(rt.item_desc), ptr(p('gamma_item')), 1, None,
+                                       ptr(pl.ids_all), ptr(rt.meta_cat), rt.n_items, ptr(g('gamma_item')), ptr(g('beta_item')),
+                                       ptr(rt.grads), st), "cham_feature_bwd")
+
+        if swap:
+            # the lanes trade places for the last phase: the W2 wgrad (4 ms of matrix work, nothing but Adam waits for it) on this
+            # normal-priority lane, split so finely that its workgroups retire in rounds; the PreCAR backward on the high-priority
+            # side lane, whose kernels are dispatched first whenever a round of wgrad workgroups frees the CUs' register files
+            e_dgrad = mark()
+            with side(e_dgrad):
+                precar_backward(rt.gemm_ws_side)
+            main_wait(e_dZ1in)       # (= clicked-row dZ2 ready)
+            rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=rt.w2_splits)
+            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+        else:
+            if on:
+                main_wait(e_dZ1in)
+            precar_backward(rt.gemm_ws)      # beside the W2 wgrad of the side lane
         rt.join()
 
     def apply_gradients(self):
