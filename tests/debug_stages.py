@@ -1,4 +1,5 @@
-"""Diagnostic (not a test): per-stage max errors HIP vs oracle on the tiny config.  python -m tests.debug_stages"""
+"""Diagnostic (not a test): per-stage max errors HIP vs oracle on the tiny config (padded [B, T] layout: valid-position
+compaction switched off).  python -m tests.debug_stages"""
 import numpy as np
 import torch
 
@@ -11,6 +12,7 @@ def main(empty=False):
     batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
     st = H.warm_state(p, [] if empty else batches[:3])
     model, orc = H.make_pair(p)
+    model.rt.compact = False          # the per-stage comparisons below index the plan buffers in the padded [B, T] layout
     f, l = batches[0] if empty else batches[3]
     buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
     model.feed_state(pop, buf)
@@ -65,6 +67,7 @@ def selfcheck(empty=False):
     batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
     st = H.warm_state(p, [] if empty else batches[:3])
     model, orc = H.make_pair(p)
+    model.rt.compact = False          # the per-stage comparisons below index the plan buffers in the padded [B, T] layout
     f, l = batches[0] if empty else batches[3]
     buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
     model.feed_state(pop, buf)
@@ -163,6 +166,7 @@ def taps(empty=False):
     batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
     st = H.warm_state(p, [] if empty else batches[:3])
     model, orc = H.make_pair(p)
+    model.rt.compact = False          # the per-stage comparisons below index the plan buffers in the padded [B, T] layout
     f, l = batches[0] if empty else batches[3]
     buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
     model.feed_state(pop, buf)
