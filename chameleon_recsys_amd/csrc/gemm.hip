@@ -54,6 +54,7 @@ struct GemmParams {
     int kchunk; int splits; float* partial;
     int nbm, nbn;
     float* aux; int aux_slots;      // EPI 7: per-(row tile, position group) column sums [nbm][aux_slots][N]
+    int xcd_split;                  // split-K workgroup placement: one K-split per XCD (see the kernels' tile mapping)
 };
 
 // One operand tile [BF x BK].  Offsets are tile-window-local bytes, computed once; per K tile only the k-validity
@@ -382,12 +383,23 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
 
     // ---- XCD-aware, bijective tile mapping (all scalar) --------------------------------------------
     const int nwg = p.nbm * p.nbn;
-    const int id = blockIdx.x;
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
-    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    int tile_m, tile_n, split;
+    if (p.xcd_split) {
+        // split-K with a small output (wgrad): ALL tiles of one K-split on the same XCD, so that each K-panel of A and B is
+        // fetched from HBM once and shared through that XCD's L2 (tile-major placement re-read every panel on ~3 XCDs: the W2
+        // wgrad fetched 6.3 GB for 2.07 GB of operands).  Workgroups are dealt to the 8 XCDs round-robin in dispatch order.
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+        split = (lin & 7) + 8 * (slot / nwg);
+        const int t = slot % nwg;
+        tile_m = t / p.nbn; tile_n = t % p.nbn;
+    } else {
+        const int id = blockIdx.x;
+        const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
+        const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
+        tile_m = swz / p.nbn; tile_n = swz % p.nbn;
+        split = blockIdx.y;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -664,12 +676,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmParams p) {
     __bf16* Bs = As + 2 * ASZ;                         // [2][BN][LDK]
 
     const int nwg = p.nbm * p.nbn;
-    const int id = blockIdx.x;
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
-    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    int tile_m, tile_n, split;
+    if (p.xcd_split) {
+        // split-K with a small output (wgrad): ALL tiles of one K-split on the same XCD, so that each K-panel of A and B is
+        // fetched from HBM once and shared through that XCD's L2 (tile-major placement re-read every panel on ~3 XCDs: the W2
+        // wgrad fetched 6.3 GB for 2.07 GB of operands).  Workgroups are dealt to the 8 XCDs round-robin in dispatch order.
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+        split = (lin & 7) + 8 * (slot / nwg);
+        const int t = slot % nwg;
+        tile_m = t / p.nbn; tile_n = t % p.nbn;
+    } else {
+        const int id = blockIdx.x;
+        const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
+        const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
+        tile_m = swz / p.nbn; tile_n = swz % p.nbn;
+        split = blockIdx.y;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -818,6 +841,8 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     p.nbn = (p.N + BN - 1) / BN;
     int rc;
     if (p.splits > 1) {
+        static const bool tile_major = getenv("CHAM_GEMM_SPLIT_TILE_MAJOR") != nullptr;      // A/B switch: the placement of builds a-i
+        p.xcd_split = (p.splits % 8 == 0 && !tile_major) ? 1 : 0;
         rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6, BF16>(p, st);
         if (rc != CHAM_OK) return rc;
         const size_t n = (size_t)p.M * p.N;
@@ -865,7 +890,7 @@ extern "C" int cham_gemm_mulpred_bwd_f32(const float* A, int lda, const float* B
     p.bias = nullptr; p.act = 0; p.dref = Z; p.ldr = ldz; p.dact = 0;
     p.rs = pred; p.ldrs = ldp; p.rs_div = NC; p.accumulate = 0; p.partial = nullptr;
     p.kchunk = ((K + 31) / 32) * 32; p.splits = 1;
-    p.aux = workspace; p.aux_slots = 256 / NC + 2;
+    p.aux = workspace; p.aux_slots = 256 / NC + 2; p.xcd_split = 0;
     p.nbm = (M + 255) / 256; p.nbn = N / 128;
     hipStream_t st = (hipStream_t)stream;
     using LA = TileLoader<256, 16, true, 512>;
@@ -976,7 +1001,7 @@ static int gemm_dispatch(int precision, const float* A, int lda, int transA, con
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.act = act; p.dref = dref; p.ldr = ldr; p.dact = dact;
     p.rs = rowscale; p.ldrs = ldrs; p.rs_div = rs_div > 0 ? rs_div : 1;
-    p.accumulate = accumulate; p.partial = workspace; p.aux = nullptr; p.aux_slots = 0;
+    p.accumulate = accumulate; p.partial = workspace; p.aux = nullptr; p.aux_slots = 0; p.xcd_split = 0;
     int splits = 1;
     if (splits_hint != 1 && workspace) {
         // long-reduction / small-output shapes (wgrad): fill >= ~1024 workgroups

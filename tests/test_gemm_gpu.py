@@ -76,6 +76,8 @@ def test_tn_wgrad_splitk(gpu, M, N, K):
     assert _run(gpu, M, N, K, transA=1) < 1e-4
     assert _run(gpu, M, N, K, transA=1, splits=0) < 1e-4
     assert _run(gpu, M, N, K, transA=1, splits=7) < 1e-4
+    assert _run(gpu, M, N, K, transA=1, splits=8) < 1e-4          # multiples of 8: one-K-split-per-XCD placement
+    assert _run(gpu, M, N, K, transA=1, splits=16) < 1e-4
 
 
 def test_rowscale(gpu):
