@@ -516,6 +516,7 @@ class NARModuleModel:
                                   rt.tf_random_seed, step, d['row_begin'], B, N, self.negative_sample_from_buffer,
                                   ptr(pl.neg_ids), ptr(pl.neg_slot), ptr(pl.pool), ptr(pl.canon), ptr(pl.meta),
                                   ptr(pl.sampler_ws), pl.ws_bytes, s), "cham_neg_sample")
+        rt.dp_touched = (d['aci'], pl.pool)       # item rows this step can touch on ANY rank (parallel.py, mode "sparse")
         neg_ids, neg_slot = pl.neg_ids, pl.neg_slot
         if pos is not None:
             neg_ids, neg_slot = pl.neg_ids_c, pl.neg_slot_c

@@ -39,7 +39,13 @@ class DataParallelNAR:
     mode "hybrid" (SURVEY.md 8e, C1 + C2): all-reduce of the dense (CAR / RNN / FC / scorer) gradients with the full dense
     Adam on every rank, and for the trainable EMBEDDING TABLES reduce-scatter of their gradient region to the owning rank,
     owner-side Adam, all-gather of the updated table slices.  (The tables' gradient is dense - the L2 term touches every
-    row, nar_model.py:740/917 - so the exchange is a dense reduce-scatter of the region, not a row-id list.)"""
+    row, nar_model.py:740/917 - so the exchange is a dense reduce-scatter of the region, not a row-id list.)
+    mode "sparse" (large catalogs, BASELINE config 5): the trainable ITEM table's data gradient only touches the rows of the
+    global batch's clicked ids + the candidate pool + the pad item - a list every rank derives identically from the replicated
+    integers, so no index exchange is needed: every rank packs those rows (duplicates allowed) into a compact [L, dim] buffer,
+    ONE all-reduce of that buffer replaces the all-reduce of the whole [n_items, dim] table (5 M x 378 floats = 7.5 GB ->
+    ~86 k rows = 130 MB), and the summed rows are written back; the L2 term of the other rows is local (added inside the Adam
+    kernel).  Everything else in the flat buffer is all-reduced densely."""
 
     def __init__(self, model, process_group=None, mode=None):
         import os
@@ -48,8 +54,8 @@ class DataParallelNAR:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.mode = mode or os.environ.get("CHAM_DP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "sharded", "hybrid"):
-            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded' or 'hybrid'")
+        if self.mode not in ("allreduce", "sharded", "hybrid", "sparse"):
+            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'hybrid' or 'sparse'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
         if self.world > 1:
@@ -64,6 +70,11 @@ class DataParallelNAR:
                 self.emb_sharded = (rt.layout.emb_end // (self.world * 64)) * (self.world * 64)
                 rt.dp_sharded = self._hybrid_step
                 self._grad_slice = torch.empty(max(1, self.emb_sharded // self.world), dtype=rt.flat.dtype, device=rt.flat.device)
+            elif self.mode == "sparse" and 'items_embedding' in rt.layout.entries:
+                e = rt.layout.entries['items_embedding']
+                self._item = (e.offset, e.shape[0], e.shape[1])
+                self._compact = None
+                rt.dp_allreduce = self._sparse_allreduce
             else:
                 rt.dp_allreduce = self._allreduce
             # identical initial weights on every rank
@@ -71,6 +82,25 @@ class DataParallelNAR:
 
     def _allreduce(self, flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _sparse_allreduce(self, flat_grads):
+        from .._lib import check, ptr
+        rt = self.model.rt
+        off, n, dim = self._item
+        aci, pool = rt.dp_touched          # GLOBAL batch ids [Bg, T+1] and the candidate pool of this step (device int64)
+        ids = torch.cat([aci.reshape(-1), pool.reshape(-1), pool.new_zeros(1)]).to(torch.int32)
+        L = ids.numel()
+        if self._compact is None or self._compact.shape[0] < L:
+            self._compact = torch.empty(L, dim, dtype=flat_grads.dtype, device=flat_grads.device)
+        buf, table = self._compact[:L], flat_grads[off:off + n * dim]
+        st = torch.cuda.current_stream().cuda_stream
+        check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(buf), st), "cham_rows_gather")
+        if off > 0:
+            dist.all_reduce(flat_grads[:off], op=dist.ReduceOp.SUM, group=self.pg)
+        dist.all_reduce(flat_grads[off + n * dim:], op=dist.ReduceOp.SUM, group=self.pg)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        # duplicate ids carry identical sums: concurrent writes of the same value
+        check(rt.lib.cham_rows_scatter(ptr(buf), ptr(ids), L, dim, ptr(table), st), "cham_rows_scatter")
 
     def _sharded_step(self, flat_grads, flat_params, adam):
         n = flat_params.numel() // self.world
