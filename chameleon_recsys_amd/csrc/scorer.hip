@@ -43,6 +43,36 @@ __global__ __launch_bounds__(256) void k_combine_fwd(const float* __restrict__ U
     }
 }
 
+// The candidate rows of one position share U[bt]: one workgroup per position keeps its U row in registers and streams the 1+N
+// candidate rows (4 independent V-row loads in flight) - the row-per-workgroup form above pays a dependent slot -> V -> store
+// chain and a workgroup launch per 4 KB written.
+__global__ __launch_bounds__(256) void k_combine_fwd_cand(const float* __restrict__ U, const float* __restrict__ V, int C,
+                                                          int BT, int N, int pmax, const int* __restrict__ neg_slot,
+                                                          float* __restrict__ Z1) {
+    const int bt = blockIdx.x, NC = N + 1;
+    const float4* pu = reinterpret_cast<const float4*>(U + (size_t)bt * C);
+    float4* po = reinterpret_cast<float4*>(Z1 + ((size_t)BT + (size_t)bt * NC) * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 a = pu[k];
+        for (int c0 = 0; c0 < NC; c0 += 4) {
+            float4 b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i < NC ? c0 + i : NC - 1;
+                b[i] = reinterpret_cast<const float4*>(V + (size_t)cand_vrow(bt, c, BT, N, pmax, neg_slot) * C)[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i >= NC) break;
+                float4 o;
+                o.x = act_fwd(a.x + b[i].x, ACT_LEAKY); o.y = act_fwd(a.y + b[i].y, ACT_LEAKY);
+                o.z = act_fwd(a.z + b[i].z, ACT_LEAKY); o.w = act_fwd(a.w + b[i].w, ACT_LEAKY);
+                po[(size_t)(c0 + i) * (C / 4) + k] = o;
+            }
+        }
+    }
+}
+
 // dU[bt] = dpre[input bt] + sum_c dpre[cand (bt,c)];  dV_in[bt] = dpre[input bt];  dV_pos[bt] = dpre[cand (bt,0)]
 __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__ dpre, int C, int BT, int N,
                                                        float* __restrict__ dU, float* __restrict__ dV) {
@@ -314,8 +344,11 @@ extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, i
     if (!U || !V || !neg_slot || !Z1 || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
     const long rows = (long)BT + (long)BT * (N + 1);
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > rows) return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)row_count), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
-                       Z1, (int)row_begin);
+    if (row_begin == BT && row_count == (long)BT * (N + 1))         // all candidate rows: one workgroup per position
+        hipLaunchKernelGGL(k_combine_fwd_cand, dim3((unsigned)BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot, Z1);
+    else
+        hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)row_count), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax,
+                           neg_slot, Z1, (int)row_begin);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
