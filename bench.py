@@ -191,6 +191,7 @@ def main():
             model.feed_state(state, state)                                                              # hook.before_run
             model.train_step(dev_batches[k])
             state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])        # hook.after_run
+            model.presample(dev_batches[(k + 1) % n_distinct])        # next batch's negatives behind the state update
         else:
             model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())
             model.train_step(dev_batches[k])
@@ -261,6 +262,7 @@ def main():
             model.feed_state(state, state)
             model.train_step(rdev[k])
             state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
+            model.presample(rdev[(k + 1) % n_distinct])
         for i in range(max(n_distinct, args.warmup)):        # every distinct padded length T allocates its StepPlan once
             ragged_step(i)
         barrier()

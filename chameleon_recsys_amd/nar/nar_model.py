@@ -146,6 +146,7 @@ class NARRuntime:
         self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
         # fused scorer-dgrad + mulpred epilogue (cham_gemm_mulpred_bwd_f32): correct and deterministic but slower than the two-pass
         # form so far (1.2-1.5 ms vs 0.27 + 0.60 ms; profiles/r01_notes.md item 19) - experiment switch, default off
+        self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.fuse_mulpred = os.environ.get("CHAM_FUSE_MULPRED", "0") == "1"
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
@@ -263,11 +264,12 @@ class StepPlan:
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         i64 = lambda *s: torch.zeros(*s, dtype=torch.int64, device=dev)
         # sampler
-        self.neg_ids = i64(B, T, N)
-        self.neg_slot = torch.zeros(B, T, N, dtype=torch.int32, device=dev)
-        self.pool = i64(pmax)
-        self.canon = torch.zeros(pmax, dtype=torch.int32, device=dev)
-        self.meta = torch.zeros(4, dtype=torch.int32, device=dev)
+        # two sets of sampler outputs: the next step's negatives can be drawn (NARModuleModel.presample) while this step's
+        # backward still reads its own
+        self._samp = [dict(neg_ids=i64(B, T, N), neg_slot=torch.zeros(B, T, N, dtype=torch.int32, device=dev), pool=i64(pmax),
+                           canon=torch.zeros(pmax, dtype=torch.int32, device=dev), meta=torch.zeros(4, dtype=torch.int32, device=dev))
+                      for _ in range(2)]
+        self.use_sampler_set(0)
         need = rt.lib.cham_combine_bwd_workspace_bytes(L.C, B * T, N, 20 * N)
         if need > rt.gemm_ws.numel() * 4:
             rt.gemm_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
@@ -327,6 +329,11 @@ class StepPlan:
         self.neg_slot_c = torch.zeros(BT, N, dtype=torch.int32, device=dev)
         self.Z2f, self.rnn_c, self.drnn_c, self.dxproj_c = f32(BT, C), f32(BT, Hp), f32(BT, Hp), f32(BT, NG * Hp)
         self.pos, self.P = None, BT
+
+    def use_sampler_set(self, k):
+        self._samp_cur = k
+        for name, t in self._samp[k].items():
+            setattr(self, name, t)
 
     def full_rows(self, x, group=1):
         """Debug / test helper: rows of the current step (one group of ``group`` rows per valid position) -> the [B*T*group, ...]
@@ -490,7 +497,36 @@ class NARModuleModel:
         else:
             d.update(P=B * T, pos=None, ic_rows=d['item_clicked'].view(-1), ln_rows=d['label_next'].view(-1),
                      ets_rows=d['event_ts'].view(-1), mask=t(mrows.astype(np.uint8)), cat=t(cat), num=t(num))
+        d['uploaded'] = torch.cuda.Event()
+        d['uploaded'].record()            # consumers on other streams (presample) wait for exactly the copies above
         return d
+
+    def _neg_sample(self, pl, d, step, k, stream):
+        """K0 negative sampling (nar_model.py:265-276) of batch d with key `step` into the plan's sampler-output set k."""
+        rt, st, o = self.rt, self._dev_state, pl._samp[k]
+        check(rt.lib.cham_neg_sample(ptr(d['aci']), d['Bg'], d['T'] + 1, ptr(st['buffer']), st['buffer'].numel(),
+                                     rt.tf_random_seed, step, d['row_begin'], d['B'], self.negative_samples,
+                                     self.negative_sample_from_buffer, ptr(o['neg_ids']), ptr(o['neg_slot']), ptr(o['pool']),
+                                     ptr(o['canon']), ptr(o['meta']), ptr(pl.sampler_ws), pl.ws_bytes, stream), "cham_neg_sample")
+
+    def presample(self, d):
+        """Draw the negatives of the NEXT training step now.  Sampling depends on the recent-clicks state and the batch's ids,
+        not on the weights, so it can run on the device state's stream right behind the state update of the current batch,
+        while the current step's backward is still executing (0.3 ms of latency-bound kernels off the head of every step).
+        ``d`` = the uploaded next batch; forward() picks the result up when the batch and the sampler key match."""
+        rt, state = self.rt, self.articles_recent_pop_norm
+        if not (rt.presample and self.is_training and getattr(state, 'is_device', False) and state.stream is not None
+                and self._dev_state is not None and self._dev_state.get('device')):
+            return False
+        pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
+        k, step = 1 - pl._samp_cur, rt.global_step
+        state.stream.wait_event(d['uploaded'])
+        with torch.cuda.stream(state.stream):      # in order behind the state update it must see
+            self._neg_sample(pl, d, step, k, state.stream.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record()
+        d['_presampled'] = (pl, k, step, ev)
+        return True
 
     # ------------------------------------------------------------------ forward
     def forward(self, d, step=None):
@@ -511,11 +547,13 @@ class NARModuleModel:
         if step is None:
             step = rt.global_step if self.is_training else self.eval_step_key(rt.global_step, self._eval_iter)
         p = rt.p
-        # K0 negative sampling (nar_model.py:265-276)
-        check(lib.cham_neg_sample(ptr(d['aci']), d['Bg'], T + 1, ptr(st['buffer']), st['buffer'].numel(),
-                                  rt.tf_random_seed, step, d['row_begin'], B, N, self.negative_sample_from_buffer,
-                                  ptr(pl.neg_ids), ptr(pl.neg_slot), ptr(pl.pool), ptr(pl.canon), ptr(pl.meta),
-                                  ptr(pl.sampler_ws), pl.ws_bytes, s), "cham_neg_sample")
+        # K0 negative sampling (nar_model.py:265-276) - unless presample() already drew this batch's negatives for this key
+        ps = d.pop('_presampled', None)
+        if ps is not None and ps[0] is pl and ps[2] == step and st.get('device'):
+            pl.use_sampler_set(ps[1])
+            torch.cuda.current_stream().wait_event(ps[3])
+        else:
+            self._neg_sample(pl, d, step, pl._samp_cur, s)
         rt.dp_touched = (d['aci'], pl.pool)       # item rows this step can touch on ANY rank (parallel.py, mode "sparse")
         neg_ids, neg_slot = pl.neg_ids, pl.neg_slot
         if pos is not None:
