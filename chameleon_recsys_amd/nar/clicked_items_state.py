@@ -178,6 +178,7 @@ class DeviceClickedItemsState:
                 self.stream.wait_stream(st)                        # unknown producer of the inputs: fully ordered
             self.consumed_event = None
             st = self.stream
+            aci.record_stream(st); event_ts.record_stream(st)     # (caching allocator: these are read on the state stream)
         with t.cuda.stream(st):
             check(self.lib.cham_state_update(ptr(aci), ptr(event_ts), B, T1 - 1, float(self.recent_clicks_buffer_hours),
                                              ptr(self.buf_ids), ptr(self.buf_ts), self.recent_clicks_buffer_max_size,

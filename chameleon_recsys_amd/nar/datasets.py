@@ -57,20 +57,38 @@ class SessionDataset:
         self.features, self.labels = BatchDict(), BatchDict()
         self.features.dataset = self.labels.dataset = self
         self.batch_size = batch_size
+        self._peeked = None          # (features, labels) of the batch after the current one, decoded ahead by peek()
 
     # ---- iteration
     def advance(self):
         """Loads the next batch into ``self.features`` / ``self.labels``; returns False at the end of the data."""
-        if self.h is None:
+        nxt, self._peeked = (self._peeked if self._peeked is not None else self._load()), None
+        if nxt is None:
             return False
+        for k, v in nxt[0].items():
+            self.features[k] = v
+        for k, v in nxt[1].items():
+            self.labels[k] = v
+        return True
+
+    def peek(self):
+        """The batch the next advance() will install, decoded now (the same array objects), or None at the end of the data.
+        Lets the training loop upload it and draw its negatives while the current step is still running."""
+        if self._peeked is None:
+            self._peeked = self._load()
+        return self._peeked
+
+    def _load(self):
+        if self.h is None:
+            return None
         B, T = ctypes.c_int(0), ctypes.c_int(0)
         rc = self.lib.cham_sessions_next(self.h, ctypes.byref(B), ctypes.byref(T))
         if rc == _tfrecord.EOF:
             self.close()
-            return False
+            return None
         check(rc, "cham_sessions_next")
         B, T = B.value, T.value
-        f, l = self.features, self.labels
+        f, l = {}, {}
         for i, (n, dt) in enumerate(zip(self.ctx_names, self.ctx_dtypes)):
             if dt == _tfrecord.DT_BYTES:
                 tot = check(self.lib.cham_sessions_ctx_bytes(self.h, i, None, None), "cham_sessions_ctx_bytes")
@@ -89,7 +107,7 @@ class SessionDataset:
         nxt, last = np.empty((B, T), np.int64), np.empty((B, 1), np.int64)
         check(self.lib.cham_sessions_labels(self.h, nxt.ctypes.data, last.ctypes.data), "cham_sessions_labels")
         l['label_next_item'], l['label_last_item'] = nxt, last
-        return True
+        return f, l
 
     def get_next(self):
         if not self.advance():

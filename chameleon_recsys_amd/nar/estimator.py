@@ -183,6 +183,8 @@ class Estimator:
                 break
             self._run_hooks_step(all_hooks, ctx, spec.train_op)
             n += 1
+            if hasattr(model, 'stage_next'):
+                model.stage_next(ds)          # next batch: H2D copies + negative sampling behind this step (nar_model.presample)
             if log_every and n - last_log >= log_every:
                 torch.cuda.synchronize()
                 dt = time.time() - t0

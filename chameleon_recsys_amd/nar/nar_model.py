@@ -147,6 +147,7 @@ class NARRuntime:
         # fused scorer-dgrad + mulpred epilogue (cham_gemm_mulpred_bwd_f32): correct and deterministic but slower than the two-pass
         # form so far (1.2-1.5 ms vs 0.27 + 0.60 ms; profiles/r01_notes.md item 19) - experiment switch, default off
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
+        self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
         self.fuse_mulpred = os.environ.get("CHAM_FUSE_MULPRED", "0") == "1"
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
@@ -477,7 +478,18 @@ class NARModuleModel:
             else np.zeros((1, B * T), np.int64)
         num = np.stack([np.asarray(features[n], np.float32).reshape(-1) for n in L.ctx_num_names]) if L.ctx_num_names \
             else np.zeros((1, B * T), np.float32)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        # H2D copies on their own stream: queued behind the running step's kernels on the compute stream, a copy from pageable
+        # host memory blocks the host until that step has finished (one implicit synchronisation per step)
+        main, up = torch.cuda.current_stream(), self.rt.upload_stream
+
+        def t(a):
+            x = torch.from_numpy(np.ascontiguousarray(a))
+            if up is None:
+                return x.to(dev, non_blocking=True)
+            with torch.cuda.stream(up):
+                x = x.to(dev, non_blocking=True)
+            x.record_stream(main)             # allocated on the upload stream, consumed on the compute stream
+            return x
         g_ets = ets if global_features is None else np.ascontiguousarray(gf['event_timestamp'], dtype=np.int64)
         label_next = np.ascontiguousarray(labels['label_next_item'], dtype=np.int64)
         # Valid-position compaction.  The reference computes every padded (session, time) position and multiplies it
@@ -498,7 +510,7 @@ class NARModuleModel:
             d.update(P=B * T, pos=None, ic_rows=d['item_clicked'].view(-1), ln_rows=d['label_next'].view(-1),
                      ets_rows=d['event_ts'].view(-1), mask=t(mrows.astype(np.uint8)), cat=t(cat), num=t(num))
         d['uploaded'] = torch.cuda.Event()
-        d['uploaded'].record()            # consumers on other streams (presample) wait for exactly the copies above
+        d['uploaded'].record(up if up is not None else main)      # consumers (forward, presample) wait for exactly the copies above
         return d
 
     def _neg_sample(self, pl, d, step, k, stream):
@@ -521,6 +533,7 @@ class NARModuleModel:
         pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
         k, step = 1 - pl._samp_cur, rt.global_step
         state.stream.wait_event(d['uploaded'])
+        d['aci'].record_stream(state.stream)
         with torch.cuda.stream(state.stream):      # in order behind the state update it must see
             self._neg_sample(pl, d, step, k, state.stream.cuda_stream)
             ev = torch.cuda.Event()
@@ -537,6 +550,7 @@ class NARModuleModel:
         B, T, N = d['B'], d['T'], self.negative_samples
         pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
         self._plan, self._d = pl, d
+        torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
         # BT = rows of the row-wise stages = the P valid positions (all B*T when nothing is padded); BTf = the [B, T] layout
         pos, BT, BTf, NC, pmax = d['pos'], d['P'], pl.BT, pl.NC, pl.pmax
@@ -885,9 +899,29 @@ class NARModuleModel:
         self.total_loss = rt.loss_acc
         return self.total_loss
 
+    def stage_next(self, dataset):
+        """Training-loop hook (estimator.Estimator.train): upload the batch AFTER the current one and draw its negatives now
+        (presample), so that neither the H2D copies nor the sampler sit at the head of the next step."""
+        self._staged = None
+        state = self.articles_recent_pop_norm
+        if not (self.rt.presample and self.is_training and getattr(state, 'is_device', False)):
+            return
+        nxt = dataset.peek()
+        if nxt is None:
+            return
+        d = self.upload_batch(nxt[0], nxt[1])
+        self.presample(d)
+        self._staged = (nxt[0]['item_clicked'], d)
+
     def train_step(self, device_batch=None):
         """One optimizer step on the current batch (the reference's ``session.run(model.train)``)."""
-        d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)
+        d = device_batch
+        if d is None:
+            staged, self._staged = getattr(self, '_staged', None), None
+            if staged is not None and staged[0] is self.inputs['item_clicked']:        # the very arrays stage_next() uploaded
+                d = staged[1]
+            else:
+                d = self.upload_batch(self.inputs, self.labels)
         self.forward(d)
         self.backward()
         self.apply_gradients()

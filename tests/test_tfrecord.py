@@ -175,6 +175,30 @@ def test_input_fn_matches_reference_transform(g1_files):
         ds.get_next()
 
 
+def test_peek_is_the_batch_the_next_advance_installs(g1_files):
+    """SessionDataset.peek(): one-batch look-ahead for the training loop (upload + negative sampling behind the running step) -
+    same array objects as the following advance(), no batch skipped or repeated, None at the end."""
+    cfg, files, sessions = g1_files
+    plain = [(dict(f), dict(l)) for f, l in datasets.SessionDataset(files, cfg, batch_size=32, truncate_sequence_length=20)]
+    features, labels = datasets.prepare_dataset_iterator(files, cfg, batch_size=32, truncate_session_length=20)
+    ds = features.dataset
+    i = 0
+    while ds.advance():
+        assert np.array_equal(features['item_clicked'], plain[i][0]['item_clicked'])
+        cur = features['item_clicked']
+        nxt = ds.peek() if i % 2 == 0 else None           # peek on every other step only
+        assert features['item_clicked'] is cur            # peeking does not re-bind the current batch
+        if nxt is not None:
+            assert ds.peek() is nxt                        # idempotent
+            assert np.array_equal(nxt[0]['item_clicked'], plain[i + 1][0]['item_clicked'])
+            assert np.array_equal(nxt[1]['label_next_item'], plain[i + 1][1]['label_next_item'])
+            staged = nxt[0]['item_clicked']
+            assert ds.advance() and features['item_clicked'] is staged
+            i += 1
+        i += 1
+    assert i == len(plain) and ds.peek() is None and not ds.advance()
+
+
 def test_corrupt_and_missing_inputs(g1_files, tmp_path):
     cfg, files, _ = g1_files
     raw = bytearray(gzip.open(files[0], "rb").read())
