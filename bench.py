@@ -153,10 +153,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    # CHAM_DIST_BACKEND=gloo: debugging aid - exercises this script's multi-rank path with several ranks on ONE GPU (RCCL refuses
+    # two ranks per device); the driver's runs use the default, RCCL with one rank per GPU
+    backend = os.environ.get("CHAM_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = {"g1": G1, "tiny": TINY, "adressa": ADRESSA}[args.config]
     Bl = cfg['batch']                 # per-GPU batch (weak scaling)
