@@ -154,6 +154,8 @@ class NARRuntime:
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._plans = {}
+        self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
+        self.plan_bytes_budget = 128 << 30        # of the 288 GB: activations of the cached shapes
         self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
         # data-parallel context (set by parallel.DataParallelNAR)
         self.dp_rank, self.dp_world, self.dp_allreduce, self.dp_sharded = 0, 1, None, None
@@ -186,12 +188,19 @@ class NARRuntime:
         self.global_step = int(sd['global_step'])
 
     def plan(self, B, T, N, n_buf, Bg=None):
+        """Buffers for one batch shape, cached: ragged hourly files produce a handful of padded lengths T.  Least-recently-used
+        plans are dropped one at a time (count / byte budget), never all at once."""
         key = (B, T, N, n_buf, Bg or B)
-        if key not in self._plans:
-            if len(self._plans) > 8:
-                self._plans.clear()
-            self._plans[key] = StepPlan(self, B, T, N, n_buf, Bg or B)
-        return self._plans[key]
+        pl = self._plans.pop(key, None)
+        if pl is None:
+            need = StepPlan.estimate_bytes(self.layout, B, T, N)
+            while self._plans and (len(self._plans) >= self.max_plans or
+                                   need + sum(p.nbytes for p in self._plans.values()) > self.plan_bytes_budget):
+                self._plans.pop(next(iter(self._plans)))          # oldest entry (dicts keep insertion order)
+            pl = StepPlan(self, B, T, N, n_buf, Bg or B)
+            pl.nbytes = need
+        self._plans[key] = pl                                      # (re)insert as most recently used
+        return pl
 
     # ---- thin kernel wrappers -------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
@@ -251,6 +260,12 @@ class NARRuntime:
 
 class StepPlan:
     """Device buffers for one (B, T, N) shape.  Row layouts: see csrc/scorer.hip."""
+
+    @staticmethod
+    def estimate_bytes(L, B, T, N):
+        """Dominant buffers only: Z1, Z2, dZ1, dZ2 over all CAR rows + the scorer activations over the candidate rows."""
+        rows = B * T * (N + 2)
+        return 4 * (4 * rows * L.C + 2 * rows * (128 + 64 + 32))
 
     def __init__(self, rt, B, T, N, n_buf, Bg):
         L, dev = rt.layout, rt.device
@@ -663,9 +678,9 @@ class NARModuleModel:
     def backward(self):
         """Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
         PreCAR combine -> features); SIDE (high priority) carries everything that only produces weight gradients - wgrad GEMMs,
-        bias column sums - plus the session-FC / recurrent chain, so the HBM-bound elementwise kernels of one lane run beside the
-        MFMA-bound GEMMs of the other.  Every cross-lane dependency is an explicit event; with overlap off the same program
-        order runs on one stream."""
+        bias column sums - plus the session-FC / recurrent chain and the clicked-row CAR dgrad, so the HBM-bound elementwise
+        kernels of one lane run beside the MFMA-bound GEMMs of the other (DESIGN.md "Step schedule").  Every cross-lane
+        dependency is an explicit event; with overlap off the same program order runs on one stream."""
         rt, lib, L = self.rt, self.rt.lib, self.rt.layout
         pl, d = self._plan, self._d
         s = _stream()
@@ -807,9 +822,9 @@ class NARModuleModel:
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
                     rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BTf, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
                 rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn%d/b' % l))
-        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only).  W2 is transposed once (4 MB) so
-        # that the 520-GFLOP dgrad runs in the NN layout (B tile staged with ds_write_b128 instead of 4 x ds_write_b32:
-        # 131 vs 124 TFLOP/s, profiles/r01_gemm_variants.md)
+        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only): the largest GEMM of the backward,
+        # NT layout on the 256x256 tile.  (CHAM_DGRAD_NN=1: transpose W2 once and run it in the NN layout - faster stand-alone,
+        # slower inside the step; profiles/r01_notes.md item 10)
         if rt.dgrad_nn:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
         for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
