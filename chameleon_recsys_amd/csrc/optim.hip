@@ -93,21 +93,31 @@ __global__ __launch_bounds__(256) void k_colsum_gen(const float* __restrict__ X,
         partial[(size_t)blockIdx.x * F + c] = acc;
     }
 }
-// 32 columns x 8 chunk-lanes per workgroup; lane l sums chunks l, l+8, ... then the 8 lanes are added in order
+// 16 columns x 16 chunk-lanes per workgroup; lane l sums chunks l, l+16, ... (4 independent loads in flight: the partials
+// come from L2 and a lane's loads are otherwise a dependent latency chain - 188 us for 1024 chunks with 8 lanes), then the 16
+// lanes are added in order.  Fixed order -> deterministic.
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nchunks, int F, float* __restrict__ out,
                                                       int accumulate) {
-    __shared__ float sm[8][33];
-    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float s = 0.f;
-    if (c < F)
-        for (int k = kl; k < nchunks; k += 8) s += partial[(size_t)k * F + c];
-    sm[kl][cl] = s;
+    __shared__ float sm[16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < F) {
+        int k = kl;
+        for (; k + 48 < nchunks; k += 64) {
+            s0 += partial[(size_t)k * F + c];
+            s1 += partial[(size_t)(k + 16) * F + c];
+            s2 += partial[(size_t)(k + 32) * F + c];
+            s3 += partial[(size_t)(k + 48) * F + c];
+        }
+        for (; k < nchunks; k += 16) s0 += partial[(size_t)k * F + c];
+    }
+    sm[kl][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (kl == 0 && c < F) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][cl];
+        for (int k = 0; k < 16; ++k) t += sm[k][cl];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -157,7 +167,7 @@ extern "C" int cham_colsum(const float* X, int ld, int R, int F, const float* w,
     const bool vec = (F % 4 == 0) && (F / 4 <= 256) && (256 % (F / 4) == 0) && (ld % 4 == 0);
     if (vec) hipLaunchKernelGGL(k_colsum_vec, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
     else hipLaunchKernelGGL(k_colsum_gen, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((F + 31) / 32), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
+    hipLaunchKernelGGL(k_colsum_final, dim3((F + 15) / 16), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
