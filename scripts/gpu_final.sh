@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats of the same bench command, PMC passes (separate runs) for HBM traffic of the dominant kernel.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-T=${TAG:-r01j}
+T=${TAG:-r01k}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
