@@ -1,0 +1,51 @@
+"""Host-side logic that needs no GPU: the StepPlan cache policy and the environment-switch defaults documented in DESIGN.md."""
+import re
+
+from chameleon_recsys_amd.nar import nar_model
+
+
+class _FakePlan:
+    def __init__(self, rt, B, T, N, n_buf, Bg):
+        self.key = (B, T, N, n_buf, Bg)
+
+
+def _runtime(max_plans, budget, monkeypatch):
+    rt = object.__new__(nar_model.NARRuntime)            # no device: only the cache fields plan() touches
+    rt._plans, rt.max_plans, rt.plan_bytes_budget = {}, max_plans, budget
+
+    class _L:
+        C = 1024
+    rt.layout = _L()
+    monkeypatch.setattr(nar_model, "StepPlan", type("StepPlan", (_FakePlan,), {
+        "estimate_bytes": staticmethod(nar_model.StepPlan.estimate_bytes)}))
+    return rt
+
+
+def test_plan_cache_evicts_least_recently_used_shape(monkeypatch):
+    rt = _runtime(3, 1 << 60, monkeypatch)
+    a, b, c = rt.plan(256, 10, 50, 3000), rt.plan(256, 11, 50, 3000), rt.plan(256, 12, 50, 3000)
+    assert rt.plan(256, 10, 50, 3000) is a                  # a becomes most recently used
+    d = rt.plan(256, 13, 50, 3000)                          # evicts b, not everything
+    assert [p.key[1] for p in rt._plans.values()] == [12, 10, 13]
+    assert rt.plan(256, 12, 50, 3000) is c and rt.plan(256, 13, 50, 3000) is d
+    assert rt.plan(256, 11, 50, 3000) is not b              # b was dropped and is rebuilt
+
+
+def test_plan_cache_respects_byte_budget(monkeypatch):
+    one = nar_model.StepPlan.estimate_bytes(type("L", (), {"C": 1024}), 256, 19, 50)
+    assert 4.0e9 < one < 6.0e9                              # G1 shape: ~4.4 GB of CAR / scorer activations
+    rt = _runtime(24, int(2.5 * one), monkeypatch)
+    for T in (19, 18, 17, 16):
+        rt.plan(256, T, 50, 3000)
+    assert 1 <= len(rt._plans) <= 2 and list(rt._plans.values())[-1].key[1] == 16
+
+
+def test_documented_switch_defaults_match_the_code():
+    src = open(nar_model.__file__).read()
+    doc = open(nar_model.__file__.rsplit("/chameleon_recsys_amd/", 1)[0] + "/DESIGN.md").read()
+    for name, default in re.findall(r'os\.environ\.get\("(CHAM_[A-Z0-9_]+)",\s*"([^"]*)"\)', src):
+        assert name in doc, "%s is not documented in DESIGN.md section 9" % name
+        row = [l for l in doc.splitlines() if l.startswith("| `") and name in l]
+        assert row, name
+        if name in ("CHAM_COMPACT", "CHAM_OVERLAP", "CHAM_PRESAMPLE", "CHAM_ASYNC_UPLOAD", "CHAM_SIDE_PRIORITY"):
+            assert "| %s |" % default in row[0], (name, default, row[0])
