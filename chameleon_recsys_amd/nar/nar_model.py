@@ -127,13 +127,14 @@ class NARRuntime:
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
         import os
-        self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "-1")))
+        self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
         self.aux_stream = torch.cuda.Stream(device=dev, priority=-1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
-        # Measured on MI355X (profiles/r01_notes.md): with a HIGH-PRIORITY side stream the 8 recurrent workgroups get
-        # CUs as soon as GEMM workgroups retire: 22.2 -> 20.7 ms per G1 step.  (With a default-priority stream they were
-        # starved behind the 7.7k-workgroup GEMM grid.)  CHAM_OVERLAP=0 turns it off.
+        # Side-lane priority, measured on MI355X (profiles/r01_notes.md items 2 and 25): the early builds needed a HIGH-priority
+        # side stream (their 4-wave recurrent workgroups starved behind the 7.7k-workgroup GEMM grid: 22.2 -> 20.7 ms); with the
+        # final schedule (8-wave pipelined recurrent kernels, presampled negatives, PreCAR backward beside the W2 wgrad) normal
+        # priority is 0.2-0.3 ms faster (16.74-16.94 vs 17.06-17.11 ms).  CHAM_OVERLAP=0 turns the lanes off.
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"
         self.dgrad_nn = os.environ.get("CHAM_DGRAD_NN", "0") == "1"      # experiment switch (profiles/r01_notes.md item 9)
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
@@ -677,7 +678,7 @@ class NARModuleModel:
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
     def backward(self):
         """Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
-        PreCAR combine -> features); SIDE (high priority) carries everything that only produces weight gradients - wgrad GEMMs,
+        PreCAR combine -> features); SIDE carries everything that only produces weight gradients - wgrad GEMMs,
         bias column sums - plus the session-FC / recurrent chain and the clicked-row CAR dgrad, so the HBM-bound elementwise
         kernels of one lane run beside the MFMA-bound GEMMs of the other (DESIGN.md "Step schedule").  Every cross-lane
         dependency is an explicit event; with overlap off the same program order runs on one stream."""
