@@ -869,6 +869,12 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 
 static int g_variant = -1;     // -1 = automatic
 extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
+// Launch counters per tile instance (tests assert that a shape really ran on the instance it is meant to cover):
+// [0] 128x128, [1] 256x128, [2] 256x256, [3] 256x64, [4] 256x32; +8 for the bf16 kernels.  Not thread-safe (test aid).
+static long long g_tile_launches[16];
+extern "C" void cham_gemm_launch_counts(long long* out16, int reset) {
+    for (int i = 0; i < 16; ++i) { if (out16) out16[i] = g_tile_launches[i]; if (reset) g_tile_launches[i] = 0; }
+}
 
 // C[M,N] = (A[M,K] B[N,K]^T) (.) pred[row / NC] (.) (1 - Z^2);  dpred[g] = (sum_{rows of g} (A B^T) (.) Z) (.) (1 - pred[g]^2)
 // = the scorer's first-layer dgrad + the backward of `cand (.) pred` + the CAR tanh derivative in one pass (see mulpred_epilogue).
@@ -930,23 +936,27 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
         }
         if (g_variant >= 0) v = g_variant;
         switch (v) {      // (other tile shapes were measured and dropped: profiles/r01_notes.md items 3 and 9)
-            case 2: return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
-            case 4: return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
-            default: return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
+            case 2: ++g_tile_launches[1]; return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
+            case 4: ++g_tile_launches[2]; return launch_cfg<256, 256, 4, 2, 16, AK, BKC>(p, st);
+            default: ++g_tile_launches[0]; return launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
         }
     }
-    if (p.N > 32) return launch_cfg<256, 64, 4, 1, 16, AK, BKC>(p, st);
+    if (p.N > 32) { ++g_tile_launches[3]; return launch_cfg<256, 64, 4, 1, 16, AK, BKC>(p, st); }
+    ++g_tile_launches[4];
     return launch_cfg<256, 32, 4, 1, 16, AK, BKC>(p, st);
 }
 
 template <bool AK, bool BKC>
 static int launch_by_shape_bf16(GemmParams& p, hipStream_t st) {
     if (p.N > 64) {
-        if ((long)p.M * p.N >= (1L << 20) && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splits >= 256)
-            return launch_cfg<256, 128, 4, 2, 32, AK, BKC, true>(p, st);
+        bool big = (long)p.M * p.N >= (1L << 20) && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splits >= 256;
+        if (g_variant >= 0) big = g_variant >= 2;
+        if (big) { ++g_tile_launches[8 + 1]; return launch_cfg<256, 128, 4, 2, 32, AK, BKC, true>(p, st); }
+        ++g_tile_launches[8 + 0];
         return launch_cfg<128, 128, 2, 2, 32, AK, BKC, true>(p, st);
     }
-    if (p.N > 32) return launch_cfg<256, 64, 4, 1, 32, AK, BKC, true>(p, st);
+    if (p.N > 32) { ++g_tile_launches[8 + 3]; return launch_cfg<256, 64, 4, 1, 32, AK, BKC, true>(p, st); }
+    ++g_tile_launches[8 + 4];
     return launch_cfg<256, 32, 4, 1, 32, AK, BKC, true>(p, st);
 }
 

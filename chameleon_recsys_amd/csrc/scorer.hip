@@ -93,43 +93,149 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__
     }
 }
 
-// dV[2BT + s] = sum over candidate rows that reference slot s (deterministic, no float atomics).
-// Negatives are popularity-sampled, so a few slots are referenced by almost every click: the reduction is
-// therefore split over (slot, row-chunk) workgroups.  Each workgroup scans its chunk of the (L2-resident) slot
-// table, compacts the matching rows IN ORDER into an LDS list (ballot + popcount prefix), then sums those rows
-// with 8 independent row loads in flight; a second kernel adds the per-chunk partials in chunk order.
-#define SLOT_CHUNK 16384
-#define SLOT_LIST 2048          // a click holds a slot at most once -> <= SLOT_CHUNK / N + 2 matches per chunk (N >= 8)
+// dV[2BT + s] = sum over the candidate rows that reference pool slot s - deterministic (rows are summed in ascending position
+// order, no float atomics) and without a size assumption (round-1 version: every (slot, row-chunk) workgroup scanned its 64-KB
+// chunk of the slot table - 1 GB of L2 reads per step, hot slots serialised, and a fixed-size match list that silently
+// truncated the zero-padding slot).
+//   1. k_slot_bitmap: one bit per (slot, position): a click holds a pool slot at most once (k_click_select keeps one key per
+//      canonical slot), so "which positions reference s" is a BT-bit set; integer atomicOr = order independent.
+//   2. k_slot_reduce: workgroup (s, position chunk) walks its bitmap words, lists the set positions in ascending order
+//      (popcount prefix), finds the slot's column inside each position's N entries and sums those dpre rows, 8 row loads in
+//      flight.  Cold slots (<= SLOT_HOT rows: almost all) are finished by chunk 0 alone straight into dV; hot slots
+//      (popularity-sampled negatives: a few slots sit in nearly every click) are split over position chunks -> partials,
+//      added in chunk order by k_slot_final.
+//   3. the zero-padding slot (s == pmax: a click holds it N - #candidates times) keeps the scan form, in chunks of SLOT_LIST
+//      entries so that its match list cannot overflow.
+#define SLOT_HOT 512            // rows a single workgroup sums; also the position-chunk size of hot slots (SLOT_HOT / 32 words)
+#define SLOT_LIST 2048
+__global__ __launch_bounds__(256) void k_slot_bitmap(const int* __restrict__ neg_slot, size_t n, int N, int pmax, int W,
+                                                     unsigned* __restrict__ bitmap /*[pmax][W], zeroed*/) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = neg_slot[i];
+    if (s < 0 || s >= pmax) return;
+    const unsigned p = (unsigned)(i / N);
+    atomicOr(bitmap + (size_t)s * W + (p >> 5), 1u << (p & 31));
+}
+
+__device__ __forceinline__ int block_sum_int(int v, int* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_slot_reduce(const float* __restrict__ dpre, int C, int BT, int N,
+                                                     const int* __restrict__ neg_slot, const unsigned* __restrict__ bitmap, int W,
+                                                     int nslots, float* __restrict__ partial /*[nchunk][nslots][C]*/,
+                                                     float* __restrict__ dV) {
+    __shared__ int list[SLOT_HOT];
+    __shared__ int red[4];
+    const int s = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned* bm = bitmap + (size_t)s * W;
+    int c = 0;
+    for (int w = tid; w < W; w += 256) c += __popc(bm[w]);
+    const int total = block_sum_int(c, red);
+    const bool hot = total > SLOT_HOT;
+    if (!hot && chunk != 0) return;
+    constexpr int PCW = SLOT_HOT / 32;
+    const int w0 = hot ? chunk * PCW : 0, w1 = hot ? min(W, w0 + PCW) : W;
+    // ordered list of the set positions in [w0, w1): 256 words per round
+    int base = 0;
+    for (int t0 = w0; t0 < w1; t0 += 256) {
+        const int w = t0 + tid;
+        unsigned bits = w < w1 ? bm[w] : 0u;
+        const int mycnt = __popc(bits);
+        int incl = mycnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63) red[wave] = incl;
+        __syncthreads();
+        int off = base + incl - mycnt;
+        for (int q = 0; q < wave; ++q) off += red[q];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (off < SLOT_HOT) list[off] = w * 32 + b;       // (cannot overflow: <= SLOT_HOT rows by construction)
+            ++off;
+        }
+        base += red[0] + red[1] + red[2] + red[3];
+    }
+    __syncthreads();
+    const int cnt = min(base, SLOT_HOT);
+    // position -> candidate row (relative to the first candidate row): find the slot's column among the position's N entries
+    for (int j = tid; j < cnt; j += 256) {
+        const int p = list[j];
+        const int* r = neg_slot + (size_t)p * N;
+        int n = 0;
+        for (int q = 0; q < N; ++q) n = (r[q] == s) ? q : n;
+        list[j] = p * (N + 1) + 1 + n;
+    }
+    __syncthreads();
+    float* out = hot ? partial + ((size_t)chunk * nslots + s) * C : dV + ((size_t)2 * BT + s) * C;
+    const float* cand = dpre + (size_t)BT * C;
+    for (int k = tid; k < C / 4; k += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4*>(cand + (size_t)list[t + u] * C)[k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+        for (; t < cnt; ++t) {
+            const float4 x = reinterpret_cast<const float4*>(cand + (size_t)list[t] * C)[k];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<float4*>(out)[k] = acc;
+    }
+}
+// hot slots only: dV[2BT + s] = sum of the position chunks' partials, in chunk order
+__global__ __launch_bounds__(256) void k_slot_final(const float* __restrict__ partial, int C, int nslots, int nchunk, int BT,
+                                                    const unsigned* __restrict__ bitmap, int W, float* __restrict__ dV) {
+    __shared__ int red[4];
+    const int s = blockIdx.x;
+    const unsigned* bm = bitmap + (size_t)s * W;
+    int c = 0;
+    for (int w = threadIdx.x; w < W; w += 256) c += __popc(bm[w]);
+    if (block_sum_int(c, red) <= SLOT_HOT) return;
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float4 x = reinterpret_cast<const float4*>(partial + ((size_t)ch * nslots + s) * C)[k];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<float4*>(dV + ((size_t)2 * BT + s) * C)[k] = acc;
+    }
+}
+
+// The zero-padding slot: rows of one chunk of the slot table that hold `slot`, compacted IN ORDER into an LDS list (ballot-free
+// per-thread bit masks + popcount prefix) and summed; chunk_len <= SLOT_LIST, so the list holds every match.
 __global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* __restrict__ dpre, int C, int BT, int N,
-                                                                   const int* __restrict__ neg_slot,
-                                                                   float* __restrict__ partial /*[nchunk][pmax+1][C]*/, int nslots,
-                                                                   int chunk_len /* multiple of 1024, <= SLOT_CHUNK */) {
+                                                                   const int* __restrict__ neg_slot, int slot,
+                                                                   float* __restrict__ partial /*[nchunk][C]*/,
+                                                                   int chunk_len /* multiple of 1024, <= SLOT_LIST */) {
     __shared__ int list[SLOT_LIST];
     __shared__ int wave_tot[4];
-    const int s = blockIdx.x, chunk = blockIdx.y;
+    const int s = slot, chunk = blockIdx.x;
     const size_t n = (size_t)BT * N;
     const size_t i0 = (size_t)chunk * chunk_len;
     const size_t i1 = i0 + chunk_len < n ? i0 + chunk_len : n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // each thread owns a contiguous segment of chunk_len/256 (<= 64) entries: count, block prefix, then fill in order
+    // each thread owns a contiguous segment of chunk_len/256 (<= 8) entries: count, block prefix, then fill in order
     const int SEG = chunk_len / 256;
     const size_t sb = i0 + (size_t)threadIdx.x * SEG;
-    unsigned long long mbits = 0ull;
-    if (sb < i1) {
-        const int4* pv = reinterpret_cast<const int4*>(neg_slot + sb);       // sb is a multiple of 64 entries
-        for (int q = 0; q < SEG / 4; ++q) {
-            if (sb + 4 * q + 3 < i1) {
-                const int4 v = pv[q];
-                mbits |= (unsigned long long)(v.x == s) << (4 * q) | (unsigned long long)(v.y == s) << (4 * q + 1) |
-                         (unsigned long long)(v.z == s) << (4 * q + 2) | (unsigned long long)(v.w == s) << (4 * q + 3);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (sb + 4 * q + e < i1 && neg_slot[sb + 4 * q + e] == s) mbits |= 1ull << (4 * q + e);
-            }
-        }
-    }
-    const int mycnt = __popcll(mbits);
-    // wave-level inclusive scan of counts
+    unsigned mbits = 0u;
+    for (int e = 0; e < SEG; ++e)
+        if (sb + e < i1 && neg_slot[sb + e] == s) mbits |= 1u << e;
+    const int mycnt = __popc(mbits);
     int incl = mycnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -140,15 +246,13 @@ __global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* 
     __syncthreads();
     int off = incl - mycnt;
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    const int total_s = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    const int cnt = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];        // <= chunk_len <= SLOT_LIST
     while (mbits) {
-        const int bit = __ffsll((long long)mbits) - 1;
+        const int bit = __ffs((int)mbits) - 1;
         mbits &= mbits - 1;
-        if (off < SLOT_LIST) list[off] = threadIdx.x * SEG + bit;
-        ++off;
+        list[off++] = threadIdx.x * SEG + bit;
     }
     __syncthreads();
-    const int cnt = total_s < SLOT_LIST ? total_s : SLOT_LIST;
     const int nk = C / 4;
     for (int k = threadIdx.x; k < nk; k += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -170,19 +274,18 @@ __global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* 
             const float4 x = reinterpret_cast<const float4*>(dpre + row * C)[k];
             acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
         }
-        reinterpret_cast<float4*>(partial + ((size_t)chunk * nslots + s) * C)[k] = acc;
+        reinterpret_cast<float4*>(partial + (size_t)chunk * C)[k] = acc;
     }
 }
-__global__ __launch_bounds__(256) void k_combine_bwd_slots_final(const float* __restrict__ partial, int C, int nslots, int nchunk,
-                                                                 int BT, float* __restrict__ dV) {
-    const int s = blockIdx.x;
+__global__ __launch_bounds__(256) void k_combine_bwd_pad_final(const float* __restrict__ partial, int C, int nchunk,
+                                                               float* __restrict__ dv_row) {
     for (int k = threadIdx.x; k < C / 4; k += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = 0; c < nchunk; ++c) {
-            const float4 x = reinterpret_cast<const float4*>(partial + ((size_t)c * nslots + s) * C)[k];
+            const float4 x = reinterpret_cast<const float4*>(partial + (size_t)c * C)[k];
             acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
         }
-        reinterpret_cast<float4*>(dV + ((size_t)2 * BT + s) * C)[k] = acc;
+        reinterpret_cast<float4*>(dv_row)[k] = acc;
     }
 }
 
@@ -353,31 +456,43 @@ extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, i
     return CHAM_OK;
 }
 
-static int slot_chunk_len(int N) {
-    long c = ((long)(SLOT_LIST - 2) * N / 1024) * 1024;      // matches per chunk <= chunk/N + 2 <= SLOT_LIST
-    if (c > SLOT_CHUNK) c = SLOT_CHUNK;
-    if (c < 1024) c = 1024;
-    return (int)c;
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct SlotWs { size_t bitmap_bytes, partial_bytes, pad_bytes; int W, nchunk, nchunk_pad; };
+static SlotWs slot_ws(int C, int BT, int N, int pmax) {
+    SlotWs w;
+    w.W = (BT + 31) / 32;
+    w.nchunk = (w.W + SLOT_HOT / 32 - 1) / (SLOT_HOT / 32);
+    w.nchunk_pad = (int)(((size_t)BT * N + SLOT_LIST - 1) / SLOT_LIST);
+    w.bitmap_bytes = al256((size_t)pmax * w.W * sizeof(unsigned));
+    w.partial_bytes = al256((size_t)w.nchunk * pmax * C * sizeof(float));
+    w.pad_bytes = al256((size_t)w.nchunk_pad * C * sizeof(float));
+    return w;
 }
 extern "C" size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax) {
-    const size_t n = (size_t)BT * N;
-    const size_t cl = (size_t)slot_chunk_len(N);
-    const size_t nchunk = (n + cl - 1) / cl;
-    return nchunk * (size_t)(pmax + 1) * C * sizeof(float);
+    if (C <= 0 || BT <= 0 || N <= 0 || pmax <= 0) return 0;
+    const SlotWs w = slot_ws(C, BT, N, pmax);
+    return w.bitmap_bytes + w.partial_bytes + w.pad_bytes;
 }
 
 extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot,
                                 float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
-    if (!dpre || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
-    if (workspace_bytes < cham_combine_bwd_workspace_bytes(C, BT, N, pmax)) return -CHAM_ERR_ARG;
+    if (!dpre || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0 || pmax <= 0) return -CHAM_ERR_ARG;
+    if (workspace_bytes < cham_combine_bwd_workspace_bytes(C, BT, N, pmax) || ((uintptr_t)workspace & 15)) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const SlotWs w = slot_ws(C, BT, N, pmax);
+    unsigned* bitmap = reinterpret_cast<unsigned*>(workspace);
+    float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes);
+    float* pad_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes + w.partial_bytes);
     const size_t n = (size_t)BT * N;
-    const int cl = slot_chunk_len(N);
-    const int nchunk = (int)((n + cl - 1) / cl);
     hipLaunchKernelGGL(k_combine_bwd_u, dim3(BT), dim3(256), 0, st, dpre, C, BT, N, dU, dV);
-    hipLaunchKernelGGL(k_combine_bwd_slots_partial, dim3(pmax + 1, nchunk), dim3(256), 0, st, dpre, C, BT, N, neg_slot, workspace,
-                       pmax + 1, cl);
-    hipLaunchKernelGGL(k_combine_bwd_slots_final, dim3(pmax + 1), dim3(256), 0, st, workspace, C, pmax + 1, nchunk, BT, dV);
+    if (hipMemsetAsync(bitmap, 0, (size_t)pmax * w.W * sizeof(unsigned), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_slot_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, neg_slot, n, N, pmax, w.W, bitmap);
+    hipLaunchKernelGGL(k_slot_reduce, dim3(pmax, w.nchunk), dim3(256), 0, st, dpre, C, BT, N, neg_slot, bitmap, w.W, pmax, partial, dV);
+    hipLaunchKernelGGL(k_slot_final, dim3(pmax), dim3(256), 0, st, partial, C, pmax, w.nchunk, BT, bitmap, w.W, dV);
+    hipLaunchKernelGGL(k_combine_bwd_slots_partial, dim3(w.nchunk_pad), dim3(256), 0, st, dpre, C, BT, N, neg_slot, pmax,
+                       pad_partial, SLOT_LIST);
+    hipLaunchKernelGGL(k_combine_bwd_pad_final, dim3(1), dim3(256), 0, st, pad_partial, C, w.nchunk_pad,
+                       dV + ((size_t)2 * BT + pmax) * C);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -82,6 +82,9 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
 
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
+/* test aid: launches per tile instance since the last reset - out16[0..4] = fp32 128x128, 256x128, 256x256, 256x64, 256x32;
+ * out16[8..12] = the same tiles of the bf16 kernels.  Parity tests assert that a shape ran on the instance it is meant to cover. */
+void cham_gemm_launch_counts(long long* out16, int reset);
 
 /* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward.
  * rows [row_begin, row_begin+row_count) of the BT + BT*(1+N) CAR rows (the BT clicked-input rows come first: they are

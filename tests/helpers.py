@@ -56,3 +56,65 @@ def make_pair(p, seed=3):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+# ---- post-Adam checks that can fail ----------------------------------------------------------------------------------------
+# One TF-Adam step moves a weight by ~lr whatever |g| is (dw = lr_t * m / (sqrt(v) + eps)): where the true gradient is ~0 the sign
+# of roundoff decides the direction and two correct evaluations differ by up to 2*lr - a bound of that size cannot fail.  The
+# checks below compare the weights only where the first moment is above the noise floor (|m| > floor * max|m| of the tensor);
+# there a relative gradient error e moves the step by ~e * lr, so 0.05 * lr per step is loose for a correct path and 40x
+# tighter than the step itself (a wrong sign, slot or row shows up as >= lr).
+def _significant(m_ref, floor, global_max=0.0):
+    """|m| above floor x the tensor's max - and above 1e-4 x the largest first moment of the whole model (a tensor whose true
+    gradient is identically zero, e.g. match4/bias under the softmax's shift invariance, holds only roundoff)."""
+    a = np.abs(np.asarray(m_ref, np.float64))
+    return a > max(floor * max(float(a.max()), 1e-30), 1e-4 * global_max)
+
+
+def assert_adam_state_close(model, orc, lr, n_steps=1, m_tol=5e-3, w_tol=0.2, floor=1e-2):
+    """HIP runtime vs oracle after n_steps optimizer steps: first moments (all entries), weights (entries with significant m)."""
+    L = model.rt.layout
+    m_hip = L.unpack(model.rt.m.cpu().numpy())
+    w_hip = model.rt.logical_weights()
+    checked, worst_m, worst_w = 0, 0.0, 0.0
+    gmax = max(float(v.abs().max()) for v in orc.m.values())
+    for k, v in orc.m.items():
+        mr = v.numpy()
+        scale = max(1e-8, float(np.abs(mr).max()))
+        em = float(np.abs(m_hip[k] - mr).max())
+        worst_m = max(worst_m, em / scale)
+        assert em < m_tol * scale + 2e-6, "Adam m of %s: %g of max" % (k, em / scale)
+        sig = _significant(mr, floor, gmax)
+        if sig.any():
+            dw = float(np.abs(w_hip[k] - orc.w[k].detach().numpy())[sig].max())
+            worst_w = max(worst_w, dw / (lr * n_steps))
+            assert dw < w_tol * lr * n_steps, "weights of %s: |dw| %g vs lr %g" % (k, dw, lr)
+            checked += int(sig.sum())
+    assert checked > 0
+    print("adam state: worst m err %.2e of max, worst |dw| %.3f lr*steps over %d significant entries" % (worst_m, worst_w, checked))
+    return worst_w
+
+
+def assert_flat_close(layout, flat_a, m_a, flat_b, m_b, lr, n_steps=1, m_tol=2e-5, w_tol=0.2, floor=1e-2):
+    """Two flat (weights, Adam m) images that should have taken the same optimizer step(s) (micro-batching, compaction, host vs
+    device state, data-parallel modes ...): first moments everywhere, weights where the first moment is significant."""
+    to_np = lambda x: x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
+    flat_a, m_a, flat_b, m_b = (to_np(x).astype(np.float64) for x in (flat_a, m_a, flat_b, m_b))
+    assert float(np.abs(m_a - m_b).max()) < m_tol * float(np.abs(m_b).max()) + 1e-9, \
+        "Adam m differs by %g of max" % (float(np.abs(m_a - m_b).max()) / float(np.abs(m_b).max()))
+    checked, worst = 0, 0.0
+    gmax = float(np.abs(m_b).max())
+    for name, e in layout.entries.items():
+        sl = slice(e.offset, e.offset + e.size)
+        sig = _significant(m_b[sl], floor, gmax)
+        if sig.any():
+            dw = float(np.abs(flat_a[sl] - flat_b[sl])[sig].max())
+            worst = max(worst, dw / (lr * n_steps))
+            assert dw < w_tol * lr * n_steps, "weights of %s: |dw| %g vs lr %g" % (name, dw, lr)
+            checked += int(sig.sum())
+    assert checked > 0
+    return worst
+
+
+def assert_runtimes_close(rt_a, rt_b, lr, n_steps=1, **kw):
+    return assert_flat_close(rt_a.layout, rt_a.flat, rt_a.m, rt_b.flat, rt_b.m, lr, n_steps, **kw)

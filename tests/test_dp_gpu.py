@@ -78,5 +78,5 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     assert np.abs(losses - r0['losses']).max() < 2e-5, (losses, r0['losses'])
     # two SINGLE-process runs already differ by up to ~1.4e-4 of max|m| after three steps (float atomics in the embedding scatter ->
     # last-bit gradient differences -> Adam's first steps flip the sign of near-zero updates -> slightly different later gradients)
-    assert np.abs(m - m_dp).max() < 1e-3 * np.abs(m).max()
-    assert np.abs(flat - r0['flat']).max() < 2.1 * p['lr'] * STEPS
+    from chameleon_recsys_amd.nar.nar_model import NARRuntime
+    H.assert_flat_close(NARRuntime(p).layout, r0['flat'], m_dp, flat, m, p['lr'], n_steps=STEPS, m_tol=1e-3)

@@ -1,0 +1,190 @@
+"""HIP path vs the CPU oracle AT THE BENCHMARKED SHAPES (BASELINE.json configs[1] / [3]): 46k articles, 250-d ACE, seq_len 20,
+50 negatives, C = 1024, H = 255 (and the Adressa shape: 13k articles, seq_len 30, 100 negatives, 2-layer GRU 256), with batches of
+72 / 32 sessions - small enough for the dense oracle (seconds per step), large enough that every GEMM of the step is dispatched to
+the SAME tile instance the full 256-session batch uses: 72 x 19 x 51 = 69 768 candidate rows (273 row tiles of 256 - the tile
+choice needs a grid of >= 256 workgroups) x 1024 select the 256x128 NN, 256x256 NT (CAR dgrad), 256x256 TN split-K (W2 wgrad) and
+256x128 row-scale (scorer layer 1) kernels (asserted through cham_gemm_launch_counts).  nar_model.py:374-405, 447-500 of the reference.
+
+Tolerances: negatives bit-exact; logits / probabilities / loss 1e-3 (north_star).  Gradients: at 63 M PreCAR outputs a handful of
+leaky-ReLU pre-activations lie within an fp32 ulp of zero and take the other branch in two correct evaluations (the count is
+printed), so the per-tensor check is the relative L2 error (< 1e-3; a flipped element moves it by ~1e-5) plus a max-error bound
+(3e-4 of the tensor's max without flips, 2e-2 with)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from chameleon_recsys_amd.nar import synthetic
+from tests import helpers as H
+from tests.test_step_gpu import _kink_flips
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+def tile_counts(lib, reset=False):
+    out = (ctypes.c_longlong * 16)()
+    lib.cham_gemm_launch_counts(out, int(reset))
+    return list(out)
+
+
+def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-3, grad_max=3e-4, grad_max_flips=2e-2):
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    model.feed_state(pop, buf)
+    model.forward(model.upload_batch(f, l))
+    out = model.outputs_numpy()
+    for v in orc.w.values():
+        v.grad = None
+    orc.debug_taps = {}
+    ref = orc.forward(f, l, buf, pop, 'train')
+    assert np.array_equal(out['neg_items'], ref['neg_items'].numpy()), "negative samples must be bit exact"
+    mask = ref['mask'].numpy()
+    e_logit = float(np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max())
+    e_prob = float(np.abs(out['probs'] - ref['probs'].detach().numpy())[mask].max())
+    assert e_logit < logit_tol and e_prob < logit_tol, (e_logit, e_prob)
+    assert abs(out['loss'][1] - float(ref['xe_loss'])) < logit_tol
+    assert abs(out['loss'][2] - float(ref['reg_loss'])) < 1e-5
+    flips = _kink_flips(model, orc, mask)
+    ref['xe_loss'].backward()
+    orc.debug_taps = None
+    model.backward()
+    torch.cuda.synchronize()
+    g = model.rt.logical_grads()
+    worst = {}
+    gmax = max(float(v.grad.abs().max()) for v in orc.w.values() if v.grad is not None)
+    for k, v in orc.w.items():
+        rg = v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)
+        d = g[k].astype(np.float64) - rg
+        if float(np.abs(rg).max()) < 1e-5 * gmax:
+            # the true gradient of this tensor is identically zero (match4/bias: the softmax is shift invariant) - both sides hold
+            # roundoff; only its absolute size can be checked
+            assert float(np.abs(d).max()) < 1e-5 * gmax + 1e-7, "grad %s (zero gradient): |err| %g" % (k, float(np.abs(d).max()))
+            continue
+        scale = max(1e-6, float(np.abs(rg).max()))
+        nrm = float(np.sqrt((rg * rg).sum()))
+        l2 = float(np.sqrt((d * d).sum())) / max(nrm, 1e-12) if nrm > 1e-9 else float(np.abs(d).max())
+        mx = float(np.abs(d).max()) / scale
+        worst[k] = (l2, mx)
+        assert l2 < grad_l2, "grad %s: relative L2 error %g (max err %g of max, %d kink flips)" % (k, l2, mx, flips)
+        assert mx < (grad_max if flips == 0 else grad_max_flips) + 2e-5 / scale, \
+            "grad %s: max err %g of max |g| = %g (%d kink flips)" % (k, mx, scale, flips)
+    print("kink flips %d, logits err %.2e, worst grad L2 %.2e / max %.2e" % (
+        flips, e_logit, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
+    return flips
+
+
+def _g1_params(B, **over):
+    return synthetic.default_params(46000, 250, seq_len=20, batch_size=B, neg=50, neg_from_buffer=3000, buffer_size=20000,
+                                    for_norm=2000, C=1024, H=255, **over)
+
+
+@pytest.mark.parametrize("length_dist", ["full", "g1"])
+def test_step_parity_g1_shape(gpu, length_dist):
+    """BASELINE configs[1] shape, 72 sessions: forward + full backward vs the dense oracle, on the big-tile GEMM instances."""
+    B = 72
+    p = _g1_params(B)
+    batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=7)
+    lib = model.rt.lib
+    tile_counts(lib, reset=True)
+    compare_step_large(model, orc, *batches[3], st)
+    c = tile_counts(lib)
+    if length_dist == "full":
+        # CAR forward NN + scorer layer 1 (row scale) + scorer layer-1 dgrad on 256x128, CAR dgrad NT + W2 wgrad TN split-K on
+        # 256x256: the instances the bench's step runs on
+        assert c[1] >= 3 and c[2] >= 2, "expected the 256x128 and 256x256 instances to run: %r" % (c,)
+    else:
+        assert c[1] >= 1, c
+
+
+def test_training_curve_g1_shape(gpu):
+    """Three optimizer steps at the G1 shape with the state evolving: losses within 1e-3, Adam first moments agree, weights agree
+    where the gradient is above the noise floor (|dw| of one Adam step is ~lr whatever |g| is, so entries with g ~ 0 say nothing)."""
+    B = 64
+    p = _g1_params(B)            # shipped lr 1e-4
+    batches = synthetic.make_batches(5, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B)
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=9)
+    for i, (f, l) in enumerate(batches[2:5]):
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        model.feed_state(pop, buf)
+        loss = model.train_step(model.upload_batch(f, l)).cpu().numpy()
+        ref = orc.train_step(f, l, buf, pop)
+        assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy())
+        assert abs(loss[0] - float(ref['total_loss'])) < LOGIT_TOL, (i, loss, float(ref['total_loss']))
+        H.update_state(st, f, l)
+    # (Adam moves a weight whose gradient is roundoff by +-lr per step in either direction: after three steps the two runs' weights
+    # differ by ~lr on such entries and the gradients of small tensors by a fraction of a percent)
+    H.assert_adam_state_close(model, orc, p['lr'], n_steps=3, m_tol=2e-2, w_tol=0.1)
+
+
+def test_step_parity_adressa_shape(gpu):
+    """BASELINE configs[3] shape (13k articles, seq_len 30, 100 negatives, 2-layer GRU 256, Adressa feature schema), 32 sessions."""
+    B = 32
+    p = synthetic.default_params(13000, 250, seq_len=30, batch_size=B, neg=100, neg_from_buffer=5000, buffer_size=20000, for_norm=5000,
+                                 C=1024, H=256, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2,
+                                 reg_weight_decay=1e-4, lr=3e-4)
+    batches = synthetic.make_batches(4, B, 30, 13000, p['session_features_config'], length_dist='full', seed=3, sessions_per_hour=4 * B)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=2)
+    lib = model.rt.lib
+    tile_counts(lib, reset=True)
+    compare_step_large(model, orc, *batches[3], st)
+    c = tile_counts(lib)
+    assert c[1] >= 3 and c[2] >= 2, c
+
+
+def test_step_parity_g1_shape_bf16(gpu):
+    """BASELINE configs[2] arithmetic at the G1 shape: forward against the oracle that emulates the bf16 operand rounding
+    (logits 4e-3: bf16 products are exact in fp32, only the accumulation order differs, but a value that lands on the other side of
+    a bf16 rounding boundary moves by 2^-8 relative), loss 1e-3, and within 3e-2 of the fp32 oracle; gradients as accurate against
+    the FP32 oracle as the emulation is (see tests/test_step_gpu.py::test_step_parity_bf16_compute_mode)."""
+    from oracle.nar_oracle import NAROracle
+    B = 72
+    p = _g1_params(B, gemm_dtype='bf16')
+    batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist='full', sessions_per_hour=4 * B)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=7)
+    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
+    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    orc32 = NAROracle(p32, weights=orc.weights_numpy())
+    f, l = batches[3]
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    model.feed_state(pop, buf)
+    lib = model.rt.lib
+    tile_counts(lib, reset=True)
+    model.forward(model.upload_batch(f, l))
+    out = model.outputs_numpy()
+    grads = {}
+    for name, o in (("bf16", orc), ("f32", orc32)):
+        for v in o.w.values():
+            v.grad = None
+        ref = o.forward(f, l, buf, pop, 'train')
+        if name == "bf16":
+            mask = ref['mask'].numpy()
+            assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
+            e = float(np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max())
+            assert e < 4e-3, e
+            assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
+        else:
+            assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 3e-2
+        ref['xe_loss'].backward()
+        grads[name] = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros_like(v.detach().numpy())) for k, v in o.w.items()}
+        del ref
+    model.backward()
+    torch.cuda.synchronize()
+    c = tile_counts(lib)
+    assert c[8 + 1] >= 3, "expected the 256x128 bf16 instance to run: %r" % (c,)
+    g = model.rt.logical_grads()
+    gmax = max(float(np.abs(v).max()) for v in grads["f32"].values())
+    for k in g:
+        r32 = grads["f32"][k].astype(np.float64)
+        if float(np.abs(r32).max()) < 1e-5 * gmax:            # identically-zero gradient (match4/bias): roundoff on both sides
+            assert float(np.abs(g[k] - r32).max()) < 1e-4 * gmax, k
+            continue
+        nrm = max(1e-12, float(np.sqrt((r32 * r32).sum())))
+        e_hip = float(np.sqrt(((g[k] - r32) ** 2).sum())) / nrm
+        e_emu = float(np.sqrt(((grads["bf16"][k] - r32) ** 2).sum())) / nrm
+        assert e_hip < 3.0 * e_emu + 2e-2, (k, e_hip, e_emu)

@@ -1,4 +1,6 @@
-"""fp32 MFMA GEMM (csrc/gemm.hip) against a float64 reference, every transpose mode / epilogue / tile config."""
+"""fp32 and bf16 MFMA GEMM (csrc/gemm.hip) against a float64 reference: every transpose mode and epilogue at small ragged
+shapes (128x128 / 256x64 / 256x32 tiles), and - at the end of the file - the benchmarked step's own shapes on the 256x128 / 256x256
+tiles (automatic choice and forced through cham_gemm_set_variant)."""
 import numpy as np
 import pytest
 import torch
@@ -167,3 +169,147 @@ def test_fused_mulpred_backward_gemm(gpu, G, NC, N, K):
                                          ptr(ws), 16, None) == -22                                  # workspace too small
     assert lib.cham_gemm_mulpred_bwd_f32(ptr(dA), K, ptr(dB), K, ptr(C), N, 3 * G, N, K, ptr(dZ), N, ptr(dP), N, 3, ptr(dp), N,
                                          ptr(ws), ws.numel() * 4, None) == -22                      # NC < 4
+
+
+# ---- the instances the benchmarked step actually runs on ---------------------------------------------------------
+# launch_by_shape sends a GEMM to the 256x128 tile when M*N >= 2^20 and the grid has >= 256 workgroups, to 256x256 when
+# additionally (NT or TN) K >= 512, M >= 1024, N >= 512.  The cases below are the G1-shape step's GEMMs at 72 sessions (69 768
+# candidate rows x 1024) - each checked against float64 on the instance picked automatically AND with the tile forced through
+# cham_gemm_set_variant (2 = 256x128, 4 = 256x256, 0 = 128x128), fp32 and bf16, with the launch counters proving which ran.
+def _counts(lib, reset=False):
+    import ctypes
+    out = (ctypes.c_longlong * 16)()
+    lib.cham_gemm_launch_counts(out, int(reset))
+    return list(out)
+
+
+class _BigCase:
+    """One GEMM problem + its float64 references (fp32 operands / bf16-rounded operands), shared by all tile variants."""
+
+    def __init__(self, gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.M, self.N, self.K, self.tA, self.tB, self.act, self.dact, self.rs_div = M, N, K, transA, transB, act, dact, (rowscale or 1)
+        self.A = torch.randn((K, M) if transA else (M, K), generator=g)
+        self.B = torch.randn((N, K) if transB else (K, N), generator=g)
+        self.bias = torch.randn(N, generator=g) if bias else None
+        self.ref_t = torch.tanh(torch.randn(M, N, generator=g)) if dref else None
+        self.rs = torch.randn((self.A.shape[0] + self.rs_div - 1) // self.rs_div, self.A.shape[1], generator=g) if rowscale else None
+        self.dev = {k: (v.to(gpu) if v is not None else None) for k, v in
+                    dict(A=self.A, B=self.B, bias=self.bias, ref=self.ref_t, rs=self.rs).items()}
+        self.gpu = gpu
+        self._refs = {}
+
+    def reference(self, bf16):
+        if bf16 in self._refs:
+            return self._refs[bf16]
+        Ae = self.A.double()
+        if self.rs is not None:
+            Ae = Ae * self.rs.double()[torch.arange(self.A.shape[0]) // self.rs_div]
+        Be = self.B.double()
+        if bf16:
+            Ae, Be = Ae.float().bfloat16().double(), self.B.bfloat16().double()
+        R = (Ae.t() if self.tA else Ae) @ (Be.t() if self.tB else Be)
+        if self.bias is not None:
+            R = R + self.bias.double()
+        if self.act == 1:
+            R = torch.where(R > 0, R, 0.2 * R)
+        elif self.act == 2:
+            R = torch.tanh(R)
+        if self.ref_t is not None:
+            y = self.ref_t.double()
+            R = R * (torch.where(y > 0, 1.0, 0.2) if self.dact == 1 else (1 - y * y))
+        self._refs[bf16] = R
+        return R
+
+    def run(self, lib, variant, bf16=False, splits=1):
+        from chameleon_recsys_amd._lib import check, ptr
+        d = self.dev
+        C = torch.full((self.M, self.N), float('nan'), device=self.gpu)
+        ws = torch.empty(32 << 20, dtype=torch.float32, device=self.gpu) if splits != 1 else None
+        lib.cham_gemm_set_variant(variant)
+        try:
+            rc = (lib.cham_gemm_bf16 if bf16 else lib.cham_gemm_f32)(
+                ptr(d['A']), self.A.shape[1], self.tA, ptr(d['B']), self.B.shape[1], self.tB, ptr(C), self.N, self.M, self.N, self.K,
+                ptr(d['bias']), self.act, ptr(d['ref']), self.N, self.dact, ptr(d['rs']), self.A.shape[1], self.rs_div, 0, ptr(ws),
+                (32 << 20) * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream)
+        finally:
+            lib.cham_gemm_set_variant(-1)
+        check(rc, "gemm")
+        torch.cuda.synchronize()
+        R = self.reference(bf16)
+        return float((C.cpu().double() - R).abs().max()) / max(1.0, float(R.abs().max()))
+
+
+ROWS = 72 * 19 * 51          # candidate rows of a 72-session G1-shape batch: 273 row tiles of 256 (>= 256: the N = 128 scorer GEMM stays on 256x128)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_big_tiles_nn_car_forward(gpu, bf16):
+    """CAR layer 2 forward: [69 768, 1024] x [1024, 1024], bias + tanh (nar_model.py:384-403)."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    case = _BigCase(gpu, ROWS, 1024, 1024, bias=True, act=2, seed=1)
+    _counts(lib, reset=True)
+    # tolerance: the pre-activations are N(0, 32^2) sums of 1024 products; fp32 accumulation along k rounds at the running sum's
+    # magnitude (ulp(32) = 3.8e-6, x sqrt(1024) steps), and the maximum is taken over 71 M outputs - measured 1.0e-4; a wrong
+    # fragment / tile mapping is an O(1) error
+    tol = 3e-4
+    assert case.run(lib, -1, bf16) < tol
+    c = _counts(lib)
+    assert c[8 * bf16 + 1] == 1, "the automatic choice for this shape is the 256x128 tile: %r" % (c,)
+    assert case.run(lib, 0, bf16) < tol            # 128x128 (the instance the small tests cover) agrees on the same data
+    if not bf16:
+        assert case.run(lib, 4, bf16) < tol        # 256x256
+        assert _counts(lib)[2] == 1
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_big_tiles_nt_car_dgrad(gpu, bf16):
+    """CAR layer 2 dgrad: dZ2 [69 768, 1024] x W2^T, x leaky'(Z1) (backward of nar_model.py:375-403)."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    case = _BigCase(gpu, ROWS, 1024, 1024, transB=1, dref=True, dact=1, seed=2)
+    _counts(lib, reset=True)
+    assert case.run(lib, -1, bf16) < 5e-5
+    c = _counts(lib)
+    assert (c[8 + 1] == 1) if bf16 else (c[2] == 1), "automatic choice: 256x256 (fp32) / 256x128 (bf16): %r" % (c,)
+    assert case.run(lib, 2, bf16) < 5e-5
+    assert case.run(lib, 0, bf16) < 5e-5
+    case_t = _BigCase(gpu, ROWS, 1024, 128, transB=1, dref=True, dact=2, seed=3)       # scorer layer-1 dgrad (K = 128) x tanh'
+    assert case_t.run(lib, -1, bf16) < 5e-5
+    assert case_t.run(lib, 4, bf16) < 5e-5
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_big_tiles_tn_w2_wgrad_splitk(gpu, bf16):
+    """W2 weight gradient: Z1^T [1024, 62 016] x dZ2 [69 768, 1024], split-K; multiples of 8 splits take the one-K-split-per-XCD
+    placement."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    case = _BigCase(gpu, 1024, 1024, ROWS, transA=1, seed=4)
+    _counts(lib, reset=True)
+    for splits in (0, 8, 16, 12):
+        assert case.run(lib, -1, bf16, splits=splits) < 1e-4, splits
+    c = _counts(lib)      # fp32: 16 tiles of 256x256 x {16, 16} splits cover the chip, x {8, 12} do not -> demoted to 256x128
+    assert (c[8 + 1] == 4) if bf16 else (c[2] == 2 and c[1] == 2), c
+    for variant in (2, 0):
+        assert case.run(lib, variant, bf16, splits=16) < 1e-4, variant
+        assert case.run(lib, variant, bf16, splits=0) < 1e-4, variant
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_big_tiles_rowscale_scorer_layer1(gpu, bf16):
+    """Scorer layer 1 with the `cand (.) pred` product fused as a row-broadcast scale of A (nar_model.py:478-495), forward NN
+    [69 768, 1024] x [1024, 128] + bias + leaky and its weight gradient (TN, split-K)."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    fwd = _BigCase(gpu, ROWS, 128, 1024, bias=True, act=1, rowscale=51, seed=5)
+    _counts(lib, reset=True)
+    assert fwd.run(lib, -1, bf16) < 5e-5
+    c = _counts(lib)
+    assert c[8 * bf16 + 1] == 1, c
+    assert fwd.run(lib, 0, bf16) < 5e-5
+    wg = _BigCase(gpu, 1024, 128, ROWS, transA=1, rowscale=51, seed=6)
+    for splits in (0, 16):
+        assert wg.run(lib, -1, bf16, splits=splits) < 1e-4
+        assert wg.run(lib, 2, bf16, splits=splits) < 1e-4

@@ -107,13 +107,8 @@ def test_training_curve_matches_oracle(gpu):
         assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy())
         assert abs(loss[0] - float(ref['total_loss'])) < LOGIT_TOL, (i, loss, float(ref['total_loss']))
         H.update_state(st, f, l)
-    m_hip = model.rt.layout.unpack(model.rt.m.cpu().numpy())
-    for k, v in orc.m.items():
-        scale = max(1e-8, float(v.abs().max()))
-        assert float(np.abs(m_hip[k] - v.numpy()).max()) < 5e-3 * scale + 2e-6, k   # match4/bias: true gradient is 0
-    w_hip = model.rt.logical_weights()
-    for k, v in orc.w.items():
-        assert float(np.abs(w_hip[k] - v.detach().numpy()).max()) < 2.5 * p['lr'] * len(batches), k
+    # first moments everywhere (match4/bias: true gradient is 0), weights where the first moment is above the noise floor
+    H.assert_adam_state_close(model, orc, p['lr'], n_steps=len(batches), w_tol=0.2)
 
 
 def test_row_shards_sum_to_full_batch(gpu):
@@ -185,8 +180,7 @@ def test_microbatched_step_equals_whole_batch_step(gpu):
     assert np.abs(a - b).max() < 1e-5, (a, b)
     assert m1.rt.global_step == m2.rt.global_step == 1
     # first Adam step: dw = lr * g / (|g| + eps') is ill-conditioned where |g| ~ eps: compare the moments tightly, weights loosely
-    assert float((m1.rt.m - m2.rt.m).abs().max()) < 2e-5 * float(m1.rt.m.abs().max()) + 1e-9
-    assert float((m1.rt.flat - m2.rt.flat).abs().max()) < 2.1 * p['lr']
+    H.assert_runtimes_close(m1.rt, m2.rt, p['lr'])
 
 
 @pytest.mark.parametrize("cell,layers", [("ugrnn", 1), ("gru", 2)])
@@ -217,8 +211,7 @@ def test_valid_position_compaction_equals_padded_masked_path(gpu, cell, layers):
         for m in (mc, mp):
             m.apply_gradients()
         H.update_state(st, f, l)
-        assert float((mc.rt.m - mp.rt.m).abs().max()) < 2e-5 * float(mp.rt.m.abs().max()) + 1e-9
-        assert float((mc.rt.flat - mp.rt.flat).abs().max()) < 2.1 * p['lr']
+        H.assert_runtimes_close(mc.rt, mp.rt, p['lr'])
         # Adam's first steps amplify roundoff where the true gradient is 0 (match4/bias: softmax shift invariance), which would
         # shift every logit of the next batch: restart both models from the same weights / slots
         for name in ('flat', 'm', 'v'):
