@@ -30,6 +30,7 @@ ADRESSA = dict(n_items=13000, ace_dim=250, seq_len=30, batch=256, neg=100, neg_f
                C=1024, H=256, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2, lr=3e-4,
                reg_weight_decay=1e-4)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 
 
 def dense_step_flops(B, T, N, F, C, H, L=1):
@@ -45,8 +46,9 @@ def dense_step_flops(B, T, N, F, C, H, L=1):
     return fwd
 
 
-def cpu_baseline(params, cfg, length_dist, seed):
-    """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of the same workload."""
+def cpu_baseline(params, cfg, length_dist, seed, n_steps=20):
+    """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of the same workload: n_steps timed
+    optimizer steps of 64-session batches (same shape), with the per-stage breakdown SURVEY 8d asks for."""
     import torch
     from chameleon_recsys_amd.nar import synthetic
     from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
@@ -55,21 +57,109 @@ def cpu_baseline(params, cfg, length_dist, seed):
     torch.set_num_threads(cores)
     Bs = 64                                    # sample: 64-session batches of the same shape
     p = dict(params); p['batch_size'] = Bs
-    batches = synthetic.make_batches(8, Bs, cfg['seq_len'], cfg['n_items'], p['session_features_config'], seed=seed,
+    batches = synthetic.make_batches(n_steps + 1, Bs, cfg['seq_len'], cfg['n_items'], p['session_features_config'], seed=seed,
                                      length_dist=length_dist, sessions_per_hour=Bs * 4)
     orc = NAROracle(p, seed=seed)
     st = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
     times = []
     for i, (f, l) in enumerate(batches):
+        if i == 1:
+            orc.timers = {}                    # first step = warm-up
         t0 = time.perf_counter()
         orc.train_step(f, l, st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm())
-        ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
-        st.update_items_state(ids, ts)
+        with orc._stage('state_update'):
+            ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
+            st.update_items_state(ids, ts)
         times.append(time.perf_counter() - t0)
-    dt = sum(times[1:])                        # first step = warm-up
-    return dict(value=round(Bs * (len(times) - 1) / dt, 3), unit="sessions/s", cores=cores, kind="port",
+    dt, n = sum(times[1:]), len(times) - 1
+    return dict(value=round(Bs * n / dt, 3), unit="sessions/s", cores=cores, kind="port",
                 sample="%d timed optimizer steps of 64-session batches (same shape, 1 warm-up step), restated CPU oracle "
-                       "(PyTorch-CPU fp32, TF 1.12 unavailable), %d threads" % (len(times) - 1, cores))
+                       "(PyTorch-CPU fp32, TF 1.12 unavailable), %d threads" % (n, cores),
+                ms_per_step=round(dt / n * 1e3, 1),
+                stage_ms_per_step={k: round(v / n * 1e3, 1) for k, v in orc.timers.items()})
+
+
+def gemm_symbol(r):
+    """The C++ kernel symbol a profiled GEMM launch ran on, rebuilt from the library's own record of the launch (tile instance,
+    epilogue variant) - the names `rocprofv3 --stats` lists."""
+    bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
+    tf = lambda b: "true" if b else "false"
+    ak, bkc, epi = not r['transA'], bool(r['transB']), r['epi']
+    rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
+    if r['bf16']:
+        return "void gemm_bf16_kernel<%d, %d, %d, %d, 32, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
+    return "void gemm_f32_kernel<%d, %d, %d, %d, 16, %s, %s, %d, true, 0, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
+
+
+EPI_NAMES = {0: "plain", 1: "bias+leaky", 2: "bias+tanh", 3: "x leaky'", 4: "x tanh'", 5: "bias", 6: "split-K partials (+ reduce kernel)"}
+
+
+def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, state="device"):
+    """SURVEY 8d's metric: sessions/sec through the drop-in boundary - GZIP TFRecord session files -> input_fn
+    (datasets.prepare_dataset_iterator: C++ codec + prefetch) -> Estimator.train -> nar_module_model_fn -> hooks, host buffers
+    handed over every step (H2D copies included), >= 50 warm-up steps excluded, steady state over >= 200 steps (the checkpoint
+    Estimator.train writes when it returns is outside the clock)."""
+    import shutil
+    import tempfile
+    import torch
+    from chameleon_recsys_amd.nar import datasets, nar_trainer_gcom as T, synthetic
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, DeviceClickedItemsState
+    from chameleon_recsys_amd.nar.estimator import SessionRunHook
+    B = cfg['batch']
+    d = tempfile.mkdtemp(prefix="cham_bench_")
+    try:
+        t0 = time.time()
+        per_file = 50 * B
+        n_files = -(-(warm_steps + timed_steps) * B // per_file)
+        files, csv, pkl = synthetic.write_dataset(d, n_files, per_file, cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'],
+                                                  seed=seed, length_dist=length_dist)
+        gen_s = time.time() - t0
+        argv = ['--batch_size', str(B), '--truncate_session_length', str(cfg['seq_len']), '--learning_rate', '1e-4', '--reg_l2', '1e-5',
+                '--softmax_temperature', '0.1', '--recent_clicks_buffer_max_size', str(cfg['buffer']),
+                '--recent_clicks_for_normalization', str(cfg['for_norm']), '--eval_metrics_top_n', '5',
+                '--CAR_embedding_size', str(cfg['C']), '--rnn_units', str(cfg['H']),
+                '--train_total_negative_samples', str(cfg['neg']), '--train_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
+                '--eval_total_negative_samples', str(cfg['neg']), '--eval_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
+                '--content_embedding_scale_factor', '6.0', '--disable_eval_benchmarks', '--model_dir', os.path.join(d, 'model'),
+                '--clicked_items_state', state]
+        T.FLAGS = T.define_flags().parse_args(argv)
+        meta_df, ace = T.load_acr_module_resources(csv, pkl)
+        ace = T.l2_normalize_rows(ace) * np.float32(6.0)
+        acfg = T.get_articles_features_config(n_items=ace.shape[0])
+        meta = T.process_articles_metadata(meta_df, acfg)
+        scfg = T.get_session_features_config()
+        T.eval_sessions_metrics_log = []
+        T.clicked_items_state = (DeviceClickedItemsState if state == "device" else ClickedItemsState)(1.0, cfg['buffer'], cfg['for_norm'], ace.shape[0])
+        est = T.build_estimator(os.path.join(d, 'model'), ace, meta, acfg, scfg)
+        est.config.log_step_count_steps = 0
+        est.config.save_checkpoints_secs = 0
+
+        class Clock(SessionRunHook):
+            n, t0, t1, n1 = 0, None, None, 0
+
+            def after_run(self, ctx, values):
+                self.n += 1
+                if self.n == warm_steps:
+                    torch.cuda.synchronize(); self.t0 = time.perf_counter()
+
+            def end(self, session=None):
+                torch.cuda.synchronize(); self.t1, self.n1 = time.perf_counter(), self.n
+        clock = Clock()
+        est.train(lambda: datasets.prepare_dataset_iterator(files, scfg, batch_size=B, truncate_session_length=cfg['seq_len']),
+                  hooks=[clock])
+        steps = clock.n1 - warm_steps
+        dt = clock.t1 - clock.t0
+        # the input pipeline alone (decode + batch, no model)
+        t2 = time.perf_counter()
+        n_in = sum(len(f['session_id']) for f, _ in datasets.SessionDataset(files, scfg, batch_size=B, truncate_sequence_length=cfg['seq_len']))
+        dt_in = time.perf_counter() - t2
+        return dict(value=round(steps * B / dt, 1), unit="sessions/s", ms_per_step=round(dt / steps * 1e3, 3), steps=steps, warmup=warm_steps,
+                    session_lengths=length_dist, clicked_items_state=state,
+                    path="GZIP TFRecord files -> prepare_dataset_iterator (C++ decode) -> Estimator.train -> model_fn + hooks; host "
+                         "batches handed over every step (H2D included)",
+                    input_pipeline_alone_sessions_per_s=round(n_in / dt_in, 1), dataset_generation_s=round(gen_s, 1))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def hitrate_parity(seed):
@@ -134,6 +224,11 @@ def main():
                     help="f32: exact fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16-rounded GEMM operands, fp32 accumulate/"
                          "storage/softmax/loss/Adam (BASELINE configs[2] arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary-leg", action="store_true",
+                    help="skip the through-the-Estimator-boundary leg (TFRecord files -> input_fn -> Estimator.train, 50 + 200 steps)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 256 sessions per GPU per step (global batch 256 x N); strong: global batch 256 sharded over the N GPUs "
+                         "(SURVEY 8e / BASELINE configs[2]: 32 rows per GPU at N = 8)")
     ap.add_argument("--no-ragged-leg", action="store_true",
                     help="skip the secondary G1-like-session-lengths leg (profiling runs: keeps per-symbol averages to the headline leg)")
     ap.add_argument("--state", default="device", choices=["device", "host"],
@@ -167,8 +262,13 @@ def main():
             dist.init_process_group(backend)
 
     cfg = {"g1": G1, "tiny": TINY, "adressa": ADRESSA}[args.config]
-    Bl = cfg['batch']                 # per-GPU batch (weak scaling)
-    Bg = Bl * world
+    if args.scaling == "strong":
+        if cfg['batch'] % world:
+            raise SystemExit("--scaling strong: global batch %d is not divisible by %d ranks" % (cfg['batch'], world))
+        Bg, Bl = cfg['batch'], cfg['batch'] // world
+    else:
+        Bl = cfg['batch']             # per-GPU batch (weak scaling)
+        Bg = Bl * world
     params = synthetic.default_params(cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'], batch_size=Bg, neg=cfg['neg'],
                                       neg_from_buffer=cfg['neg_from_buffer'], buffer_size=cfg['buffer'],
                                       for_norm=cfg['for_norm'], C=cfg['C'], H=cfg['H'], seed=args.seed,
@@ -231,27 +331,44 @@ def main():
         one_step(args.warmup + args.steps + i)
     torch.cuda.synchronize()
     prof, rt.profile = rt.profile, None
-    # dominant kernel SYMBOL = gemm_f32_kernel<256,128,4,2,16,true,false,2,true,0,false>: NN layout, bias + tanh epilogue - the CAR layer-2
-    # forward over the B*T*(1+N) candidate rows (the small NN bias+tanh GEMMs - CAR layer 2 on the clicked rows, session FC2 -
-    # run on the 128x128 instance, a different symbol).  Aggregated over all of its launches exactly like `rocprofv3 --stats`
-    # aggregates per kernel symbol, so avg_launch_ms is comparable with the committed kernel_stats.
-    def agg(sel):
-        rows = [r for r in prof if sel(r)]
-        ms = sum(r['ev'][0].elapsed_time(r['ev'][1]) for r in rows)
-        fl = sum(2.0 * r['M'] * r['N'] * r['K'] for r in rows)
-        return len(rows), ms, fl
-    # launches that gemm.hip's launch_by_shape sends to the 256x128 NN bias+tanh instance (grid of at least 256 workgroups)
-    dom = lambda r: (r['N'] > 64 and r['M'] * r['N'] >= (1 << 20) and -(-r['M'] // 256) * -(-r['N'] // 128) >= 256
-                     and not r['transA'] and not r['transB'] and r['act'] == 2)
-    n_nn, ms_nn, fl_nn = agg(dom)
-    n_all, ms_all, fl_all = agg(lambda r: True)
+    # Per kernel SYMBOL (rebuilt from the library's record of each launch: tile instance + epilogue variant), aggregated over all of
+    # its launches exactly like `rocprofv3 --stats` aggregates, so avg_launch_ms is comparable with the committed kernel_stats.  The
+    # roofline object describes the symbol with the LARGEST total time; the top three are listed beside it.
+    by_sym = {}
+    for r in prof:
+        if r['tile'] < 0:
+            continue
+        e = by_sym.setdefault(gemm_symbol(r), dict(n=0, ms=0.0, flop=0.0, bytes=0.0, r=r))
+        e['n'] += 1
+        e['ms'] += r['ev'][0].elapsed_time(r['ev'][1])
+        e['flop'] += 2.0 * r['M'] * r['N'] * r['K']
+        # operands + output, each touched once (fp32 storage): A + B + bias + C (+ the saved activation a dgrad epilogue reads)
+        e['bytes'] += 4.0 * (r['M'] * r['K'] + r['K'] * r['N'] + r['M'] * r['N'] * (2 if r['dref'] else 1) + (r['N'] if r['bias'] else 0))
+    ranked = sorted(by_sym.items(), key=lambda kv: -kv[1]['ms'])
+    ms_all = sum(e['ms'] for e in by_sym.values())
+    fl_all = sum(e['flop'] for e in by_sym.values())
+
+    def describe(sym, e):
+        r = e['r']
+        mode = "NN" if not r['transA'] and not r['transB'] else ("NT (dgrad)" if r['transB'] else "TN (wgrad)")
+        return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
+            sym, "bf16" if r['bf16'] else "fp32", mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
+            r['M'], r['N'], r['K'])
+
+    def gemm_entry(sym, e):
+        tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
+        gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
+        return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
+                "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_fp32_mfma_peak": round(tf_s / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4)}
+    DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
+    n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
-    DOM_SYMBOL = "void gemm_f32_kernel<256, 128, 4, 2, 16, true, false, 2, true, 0, false>(GemmParams)"
     traffic, traffic_src = None, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if fn.endswith("_pmc_traffic.json"):     # PMC passes cannot be collected inside the timed bench: committed separately
             rec = json.load(open(os.path.join(ROOT, "profiles", fn))).get(DOM_SYMBOL)
-            if rec and args.config == "g1" and world == 1:
+            if rec and args.config == "g1" and world == 1 and args.scaling == "weak":
                 traffic, traffic_src = rec["traffic_bytes_per_launch"], "profiles/" + fn
             break
 
@@ -297,7 +414,7 @@ def main():
         out = {
             "metric": "NAR training sessions/sec", "value": round(Bg * args.steps / dt, 2), "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": {"g1": "G1-shape synthetic (BASELINE.json configs[1])", "tiny": "G1-tiny synthetic (configs[0])",
                                     "adressa": "Adressa-shape synthetic (BASELINE.json configs[3])"}[args.config],
                        "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
@@ -305,26 +422,29 @@ def main():
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
                        "final_loss": [round(float(x), 5) for x in loss]},
-            "roofline": {"bound": "mfma", "kernel": DOM_SYMBOL + " = fp32 MFMA GEMM, NN, bias+tanh (CAR layer 2 forward), all launches of a step",
+            "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "launches_per_step": n_nn // nprof, "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),
+                         "launches_per_step": round(n_nn / nprof, 2), "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),
                          "algorithmic_gflop_per_launch": round(fl_nn / max(1, n_nn) / 1e9, 3),
-                         # operands + output of the launch(es), each touched once: A [M,K] + W [K,N] + bias + out [M,N], fp32
-                         "algorithmic_bytes_per_launch": round(sum((r['M'] * r['K'] + r['K'] * r['N'] + r['N'] + r['M'] * r['N']) * 4.0
-                                                                   for r in prof if dom(r)) / max(1, n_nn)),
+                         "algorithmic_bytes_per_launch": round(dom['bytes'] / max(1, n_nn)),
+                         "top_gemms": [gemm_entry(sym, e) for sym, e in ranked[:3]],
                          "all_gemm_ms_per_step": round(ms_all / nprof, 3),
                          "all_gemm_tflops": round(fl_all / (ms_all * 1e-3) / 1e12, 2) if ms_all > 0 else 0.0,
                          "step_reference_dense_tflops": round(3 * dense_fwd / (ms_step * 1e-3) / 1e12, 2)},
         }
-        if args.dtype == "bf16":     # operands move as fp32, the matrix cores run 16x faster: the same launches are HBM/L2-bound
-            algo_bytes = out["roofline"]["algorithmic_bytes_per_launch"] or 0
-            gbs = algo_bytes / (ms_nn / max(1, n_nn) * 1e-3) / 1e9 if ms_nn > 0 else 0.0
-            out["roofline"].update(bound="hbm", kernel="gemm_bf16_kernel<256,128,4,2,32,true,false,2,false> = bf16-MFMA GEMM, NN, bias+tanh "
-                                   "(CAR layer 2 forward), all launches of a step", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
-                                   frac=round(gbs / 8000.0, 4), traffic=None, traffic_source=None)
+        if args.dtype == "bf16":     # the matrix cores run 16x faster than in fp32: the same launches are bound by moving their operands
+            gbs = dom['bytes'] / (ms_nn * 1e-3) / 1e9 if ms_nn > 0 else 0.0
+            out["roofline"].update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBPS, 4),
+                                   traffic=None, traffic_source=None)
         if ragged is not None:
             out["g1_like_session_lengths"] = ragged
+        if world == 1 and not args.no_boundary_leg and args.config == "g1" and args.dtype == "f32":
+            # SURVEY 8d's metric proper (input pipeline + H2D + hooks inside the clock), same workload as the headline and its
+            # G1-like-session-lengths variant
+            out["through_boundary"] = through_boundary(cfg, args.length_dist, seed=args.seed, state=args.state)
+            if ragged is not None:
+                out["through_boundary_g1_like_session_lengths"] = through_boundary(cfg, "g1", seed=args.seed, state=args.state)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

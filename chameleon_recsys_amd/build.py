@@ -45,7 +45,18 @@ def build_host(force=False, verbose=True):
     return HOST_LIB
 
 
+def _src_stamp(src):
+    """Hash of one translation unit: the source, the shared header(s) it includes and the flags."""
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, x) for x in os.listdir(CSRC) if x.endswith(".h")):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode()); h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
+    """Compiles the sources whose hash changed (one hipcc process per file, in parallel) and links libchameleon_nar.so."""
     stamp_file = LIB + ".stamp"
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
@@ -57,17 +68,22 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
+        st, sf = _src_stamp(s), o + ".stamp"
+        if not force and os.path.exists(o) and os.path.exists(sf) and open(sf).read() == st:
+            continue
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
+        procs.append((s, sf, st, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, sf, st, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % s)
         if verbose and out.strip():
             print(out.decode())
+        with open(sf, "w") as fh:
+            fh.write(st)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -159,25 +159,134 @@ __global__ __launch_bounds__(256) void k_scale_bwd_cols(const float* __restrict_
     sb = block_sum(sb, red);
     if (threadIdx.x == 0) { dgamma[c] = sg; dbeta[c] = sb; }
 }
-// ... and the embedding scatter-add (the IndexedSlices of tf.nn.embedding_lookup, nar_model.py:741, 918).
-// src_kind 0: per-row categorical values cat[feat][r];  1: item rows, meta_cat[feat][ids[r]] / ids[r].
-__global__ __launch_bounds__(256) void k_emb_scatter_add(const float* __restrict__ dxs, int R, int F,
-                                                         const int64_t* __restrict__ desc, const float* __restrict__ gamma,
-                                                         int src_kind, const int64_t* __restrict__ cat, const int64_t* __restrict__ ids,
-                                                         const int64_t* __restrict__ meta_cat, int n_items,
-                                                         float* __restrict__ grads) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)R * F) return;
-    const int r = (int)(i / F), c = (int)(i % F);
-    const int64_t* d = desc + (size_t)c * DESC_W;
-    const int kind = (int)d[0], feat = (int)d[1], sub = (int)d[2], dim = (int)d[3];
-    if (kind != COL_EMB && kind != COL_ITEMEMB) return;
-    const float g = dxs[i] * gamma[c];
-    if (g == 0.f) return;
-    int64_t row;
-    if (kind == COL_ITEMEMB) row = ids[r];
-    else row = src_kind == 0 ? cat[(size_t)feat * R + r] : meta_cat[(size_t)feat * n_items + ids[r]];
-    atomicAdd(grads + d[4] + row * dim + sub, g);
+// ... and the embedding-table gradients (the IndexedSlices of tf.nn.embedding_lookup, nar_model.py:741, 918): the rows of dxs that
+// looked up the same table row are SUMMED IN A FIXED ORDER - no float atomics, the step is bit-reproducible (round 1 scattered
+// with atomicAdd: duplicate ids within a batch made two runs differ in the last bit, and with them every later step).
+//
+// (a) small tables (context / article-metadata embeddings: 12 ... ~1000 rows): one workgroup per TABLE row scans the source rows'
+//     keys 64 at a time (ballot), 16 waves take interleaved 64-row stripes, matching rows are added in ascending order per wave,
+//     the 16 wave sums in wave order.
+__global__ __launch_bounds__(1024) void k_emb_grad_scan(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                        const float* __restrict__ gamma, const int64_t* __restrict__ keysrc,
+                                                        const int64_t* __restrict__ ids /* null: key = keysrc[r]; else keysrc[ids[r]] */,
+                                                        float* __restrict__ table_grad) {
+    __shared__ float part[16][64];
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int sub0 = 0; sub0 < dim; sub0 += 64) {
+        const int sub = sub0 + lane;
+        const bool cok = sub < dim;
+        float acc = 0.f;
+        for (int r0 = w * 64; r0 < R; r0 += 1024) {
+            const int r = r0 + lane;
+            int64_t key = -1;
+            if (r < R) key = ids ? keysrc[ids[r]] : keysrc[r];
+            unsigned long long m = __ballot(key == row);
+            while (m) {                                   // wave-uniform; 4 independent row loads in flight
+                int b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    b[u] = m ? __ffsll((long long)m) - 1 : -1;
+                    m &= m - 1;
+                }
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = (b[u] >= 0 && cok) ? dxs[(size_t)(r0 + b[u]) * F + c0 + sub] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += x[u];
+            }
+        }
+        part[w][lane] = acc;
+        __syncthreads();
+        if (w == 0 && cok) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += part[i][lane];
+            table_grad[(size_t)row * dim + sub] = t * gamma[c0 + sub];
+        }
+        __syncthreads();
+    }
+}
+
+// (b) the trainable item-embedding table (46 k ... 5 M rows, <= a few 10 k of them touched per step): the item rows are ranked by
+//     (id, row) - rank = number of smaller keys, counted against LDS tiles of the key list: O(R^2 / chip) integer compares, a few
+//     microseconds for R ~ 10^4 and independent of the gradients, so it runs in the forward pass - which makes equal ids
+//     contiguous in `perm`; one workgroup per segment adds its rows (4 waves take every 4th member, ascending; wave sums in
+//     wave order) and STORES the table row: distinct segments = distinct table rows.
+#define RANK_KEY(id, r) (((unsigned long long)(id) << 20) | (unsigned long long)(r))
+__global__ __launch_bounds__(256) void k_rank_keys(const int64_t* __restrict__ ids, int R, int span, int* __restrict__ rank) {
+    __shared__ unsigned long long tile[1024];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long key = r < R ? RANK_KEY(ids[r], r) : ~0ull;
+    const int j0 = blockIdx.y * span, j1 = min(R, j0 + span);
+    int cnt = 0;
+    for (int t0 = j0; t0 < j1; t0 += 1024) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < 1024; q += 256) {
+            const int j = t0 + q;
+            tile[q] = j < j1 ? RANK_KEY(ids[j], j) : ~0ull;
+        }
+        __syncthreads();
+        const int n = min(1024, j1 - t0);
+        for (int q = 0; q < n; ++q) cnt += tile[q] < key;
+    }
+    if (r < R && cnt) atomicAdd(rank + r, cnt);           // integer: order independent
+}
+__global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ rank, int R, int* __restrict__ perm) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R) perm[rank[r]] = r;
+}
+__global__ __launch_bounds__(256) void k_emb_grad_grouped(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                          const float* __restrict__ gamma, const int64_t* __restrict__ ids,
+                                                          const int* __restrict__ perm, float* __restrict__ table_grad) {
+    __shared__ int rows[1024];
+    __shared__ float part[4][64];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t id = ids[perm[i]];
+    if (i > 0 && ids[perm[i - 1]] == id) return;          // not the head of its segment
+    int len = 0;
+    for (;;) {                                            // segment length (every wave computes the same value)
+        const int j = i + len + lane;
+        const bool same = j < R && ids[perm[j]] == id;
+        const unsigned long long m = __ballot(same);
+        const int run = (m == ~0ull) ? 64 : __ffsll((long long)~m) - 1;
+        len += run;
+        if (run < 64) break;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                  // column blocks of 64 (dim <= 256)
+    for (int base = 0; base < len; base += 1024) {
+        const int n = min(1024, len - base);
+        __syncthreads();
+        for (int q = threadIdx.x; q < n; q += 256) rows[q] = perm[i + base + q];
+        __syncthreads();
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const int sub = sb * 64 + lane;
+            if (sb * 64 >= dim) break;
+            const bool cok = sub < dim;
+            float a = acc[sb];
+            int m = w;
+            for (; m + 12 < n; m += 16) {
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + 4 * u] * F + c0 + sub] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += x[u];
+            }
+            for (; m < n; m += 4) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
+            acc[sb] = a;
+        }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        if (sb * 64 >= dim) break;
+        const int sub = sb * 64 + lane;
+        __syncthreads();
+        part[w][lane] = acc[sb];
+        __syncthreads();
+        if (w == 0 && sub < dim)
+            table_grad[(size_t)id * dim + sub] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) * gamma[c0 + sub];
+    }
 }
 
 // occurrence counts of pool slots over the sampled negatives (only used for the empty-buffer first batch,
@@ -281,15 +390,45 @@ extern "C" int cham_item_assemble(const int64_t* ids, int R, int g1_begin, int g
     return CHAM_OK;
 }
 
-extern "C" int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, const int64_t* desc, const float* gamma,
-                                int src_kind, const int64_t* cat, const int64_t* ids, const int64_t* meta_cat, int n_items,
-                                float* dgamma, float* dbeta, float* grads, void* stream) {
-    if (!dxs || !xraw || !desc || !gamma || !dgamma || !dbeta || !grads || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+extern "C" int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, void* stream) {
+    if (!dxs || !xraw || !dgamma || !dbeta || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_scale_bwd_cols, dim3(F), dim3(256), 0, (hipStream_t)stream, dxs, xraw, R, F, dgamma, dbeta);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
+                                  const int64_t* ids, int cardinality, float* table_grad, void* stream) {
+    if (!dxs || !gamma || !keysrc || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || c0 + dim > F || cardinality <= 0)
+        return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_emb_grad_scan, dim3(cardinality), dim3(1024), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, keysrc,
+                       ids, table_grad);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" size_t cham_group_rows_workspace_bytes(int R) { return R > 0 ? (size_t)R * sizeof(int) : 0; }
+extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ids || !perm || !workspace || R <= 0 || R >= (1 << 20) || workspace_bytes < cham_group_rows_workspace_bytes(R))
+        return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_scale_bwd_cols, dim3(F), dim3(256), 0, st, dxs, xraw, R, F, dgamma, dbeta);
-    const size_t n = (size_t)R * F;
-    hipLaunchKernelGGL(k_emb_scatter_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxs, R, F, desc, gamma,
-                       src_kind, cat, ids, meta_cat, n_items, grads);
+    int* rank = reinterpret_cast<int*>(workspace);
+    if (hipMemsetAsync(rank, 0, (size_t)R * sizeof(int), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    int span = ((R + 31) / 32 + 1023) / 1024 * 1024;       // <= 32 key ranges, whole LDS tiles
+    if (span < 1024) span = 1024;
+    const int ns = (R + span - 1) / span;
+    hipLaunchKernelGGL(k_rank_keys, dim3((R + 255) / 256, ns), dim3(256), 0, st, ids, R, span, rank);
+    hipLaunchKernelGGL(k_perm_from_rank, dim3((R + 255) / 256), dim3(256), 0, st, rank, R, perm);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
+                                     const int32_t* perm, float* table_grad, void* stream) {
+    if (!dxs || !gamma || !ids || !perm || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 256 || c0 + dim > F)
+        return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_emb_grad_grouped, dim3(R), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm,
+                       table_grad);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

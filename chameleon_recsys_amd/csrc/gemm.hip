@@ -780,8 +780,17 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
     }
 }
 
+// Launch counters per tile instance (tests assert that a shape really ran on the instance it is meant to cover):
+// [0] 128x128, [1] 256x128, [2] 256x256, [3] 256x64, [4] 256x32; +8 for the bf16 kernels; [14] = epilogue variant (EPI) and
+// [15] = K-splits of the LAST launch (bench.py reconstructs the kernel symbol of a timed launch).  Not thread-safe (test / bench aid).
+static long long g_tile_launches[16];
+extern "C" void cham_gemm_launch_counts(long long* out16, int reset) {
+    for (int i = 0; i < 16; ++i) { if (out16) out16[i] = g_tile_launches[i]; if (reset) g_tile_launches[i] = 0; }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool BF16>
 static int launch_epi(GemmParams& p, hipStream_t st) {
+    g_tile_launches[14] = EPI; g_tile_launches[15] = p.splits;
     size_t smem;
     const void* kern;
     if (BF16) {
@@ -869,13 +878,6 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 
 static int g_variant = -1;     // -1 = automatic
 extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
-// Launch counters per tile instance (tests assert that a shape really ran on the instance it is meant to cover):
-// [0] 128x128, [1] 256x128, [2] 256x256, [3] 256x64, [4] 256x32; +8 for the bf16 kernels.  Not thread-safe (test aid).
-static long long g_tile_launches[16];
-extern "C" void cham_gemm_launch_counts(long long* out16, int reset) {
-    for (int i = 0; i < 16; ++i) { if (out16) out16[i] = g_tile_launches[i]; if (reset) g_tile_launches[i] = 0; }
-}
-
 // C[M,N] = (A[M,K] B[N,K]^T) (.) pred[row / NC] (.) (1 - Z^2);  dpred[g] = (sum_{rows of g} (A B^T) (.) Z) (.) (1 - pred[g]^2)
 // = the scorer's first-layer dgrad + the backward of `cand (.) pred` + the CAR tanh derivative in one pass (see mulpred_epilogue).
 extern "C" size_t cham_gemm_mulpred_bwd_workspace_bytes(int M, int N, int NC) {

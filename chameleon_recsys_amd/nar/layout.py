@@ -175,6 +175,22 @@ class ParamLayout:
     def ctx_descriptors(self):
         return self._desc(self._ctx_cols)
 
+    @staticmethod
+    def _emb_groups(cols):
+        """Embedding column groups of a feature matrix: (kind, feat, first column, dim, table rows, flat offset of the table)."""
+        out, seen = [], set()
+        for c, (kind, feat, sub, dim, ent) in enumerate(cols):
+            if kind in (COL_EMB, COL_ITEMEMB) and ent.name not in seen:
+                seen.add(ent.name)
+                out.append((kind, feat, c - sub, dim, ent.shape[0], ent.offset))
+        return out
+
+    def ctx_emb_groups(self):
+        return self._emb_groups(self._ctx_cols)
+
+    def item_emb_groups(self):
+        return self._emb_groups(self._item_cols)
+
     def item_descriptors(self):
         return self._desc(self._item_cols)
 

@@ -17,7 +17,7 @@ import torch
 
 from .. import _lib
 from .._lib import check, ptr
-from .layout import ParamLayout
+from .layout import COL_ITEMEMB, ParamLayout
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 
@@ -122,6 +122,7 @@ class NARRuntime:
             mc = np.zeros((1, self.n_items), np.int64)
         self.meta_cat = torch.from_numpy(np.ascontiguousarray(mc)).to(dev)
         self.ctx_desc = torch.from_numpy(L.ctx_descriptors()).to(dev)
+        self.ctx_emb_groups, self.item_emb_groups = L.ctx_emb_groups(), L.item_emb_groups()
         self.item_desc = torch.from_numpy(L.item_descriptors()).to(dev)
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
@@ -210,17 +211,27 @@ class NARRuntime:
         if splits != 1:
             ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
         prof = self.profile
+        bf16 = self.gemm_dtype == 'bf16' and not force_f32
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0 = self._tile_counts()
             e0.record()       # torch's current stream == the stream the kernel is launched on (_stream())
-        fn = self.lib.cham_gemm_bf16 if (self.gemm_dtype == 'bf16' and not force_f32) else self.lib.cham_gemm_f32
+        fn = self.lib.cham_gemm_bf16 if bf16 else self.lib.cham_gemm_f32
         check(fn(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
                                      ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
                                      ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
         if prof is not None:
             e1.record()
-            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=splits, act=act, dref=dref is not None,
-                             ev=(e0, e1)))
+            c1 = self._tile_counts()
+            tile = next((i for i in range(13) if c1[i] != c0[i]), -1)
+            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c1[15]), act=act, dref=dref is not None, dact=dact,
+                             bias=bias is not None, rowscale=rowscale is not None, bf16=bf16, tile=tile, epi=int(c1[14]), ev=(e0, e1)))
+
+    def _tile_counts(self):
+        import ctypes
+        out = (ctypes.c_longlong * 16)()
+        self.lib.cham_gemm_launch_counts(out, 0)
+        return list(out)
 
     def gemm_mulpred_bwd(self, dS1, Ws1, dZ2c, Z2c, pred, dpred, Rc, C, K, NC):
         """Scorer layer-1 dgrad fused with the backward of `cand (.) pred` and the CAR tanh (csrc/gemm.hip mulpred_epilogue).
@@ -301,6 +312,8 @@ class StepPlan:
         self.stats = f32(3, 8)
         self.stat_scratch = f32(3 * max(1, int(rt.params['recent_clicks_for_normalization'])))
         self.w_rows = f32(RV)
+        self.perm = torch.zeros(RV, dtype=torch.int32, device=dev)          # item rows grouped by id (cham_group_rows)
+        self.group_ws = torch.zeros(RV, dtype=torch.int32, device=dev)
         self.Xc_raw, self.Xc_s, self.dXc = f32(BT, Fc), f32(BT, Fc), f32(BT, Fc)
         self.Xi_raw, self.Xi_s, self.dXi = f32(RV, Fi), f32(RV, Fi), f32(RV, Fi)
         # CAR
@@ -599,6 +612,8 @@ class NARModuleModel:
             pl.ids_all[2 * BT + pmax:2 * BT + pmax + 1].zero_()      # the pad item row moves with P
         pl.ref_ts[:BT].copy_(d['ets_rows'])
         pl.ref_ts[BT:RV].fill_(d['max_ts'])
+        if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
+            check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.group_ws), pl.group_ws.numel() * 4, s), "cham_group_rows")
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
         if st['n_last'] > 0 and st.get('device'):
@@ -847,12 +862,21 @@ class NARModuleModel:
             rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
             rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
             rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
-            # scale/center + embedding tables
-            check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(rt.ctx_desc), ptr(p('gamma_ctx')), 0, ptr(d['cat']),
-                                       None, None, 0, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), ptr(rt.grads), st), "cham_feature_bwd")
-            check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(rt.item_desc), ptr(p('gamma_item')), 1, None,
-                                       ptr(pl.ids_all), ptr(rt.meta_cat), rt.n_items, ptr(g('gamma_item')), ptr(g('beta_item')),
-                                       ptr(rt.grads), st), "cham_feature_bwd")
+            # scale/center + embedding tables (fixed summation order: the step is bit-reproducible)
+            check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), st), "cham_feature_bwd")
+            check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(g('gamma_item')), ptr(g('beta_item')), st), "cham_feature_bwd")
+            n_rows_cat = d['cat'].shape[1]
+            for kind, feat, c0, dim, card, off in rt.ctx_emb_groups:
+                check(lib.cham_emb_grad_scan(ptr(pl.dXc), BT, Fc, c0, dim, ptr(p('gamma_ctx')), d['cat'].data_ptr() + 8 * feat * n_rows_cat,
+                                             None, card, rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
+            for kind, feat, c0, dim, card, off in rt.item_emb_groups:
+                if kind == COL_ITEMEMB:
+                    check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')), ptr(pl.ids_all), ptr(pl.perm),
+                                                    rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_grouped")
+                else:
+                    check(lib.cham_emb_grad_scan(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')),
+                                                 rt.meta_cat.data_ptr() + 8 * feat * rt.n_items, ptr(pl.ids_all), card,
+                                                 rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
 
         if swap:
             # the lanes trade places for the last phase: the W2 wgrad (4 ms of matrix work, nothing but Adam waits for it) on this

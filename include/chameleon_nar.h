@@ -61,10 +61,23 @@ int cham_item_assemble(const int64_t* ids, int R, int g1_begin, int g2_begin, co
                        const float* ace, int ld_ace, const float* rec_raw, const float* nov_raw, const float* stats,
                        const int64_t* desc, int F, const float* params, const float* gamma, const float* beta, float* xraw,
                        float* xs, void* stream);
-/* backward of the two above: dgamma/dbeta + embedding scatter-add (TF IndexedSlices of embedding_lookup, :741, :918) */
-int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, const int64_t* desc, const float* gamma, int src_kind,
-                     const int64_t* cat, const int64_t* ids, const int64_t* meta_cat, int n_items, float* dgamma, float* dbeta,
-                     float* grads, void* stream);
+/* backward of the two above, scale/center part (nar_model.py:887-907): dgamma[c] = sum_r dxs[r,c] * xraw[r,c], dbeta[c] = sum_r dxs[r,c] */
+int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, void* stream);
+
+/* --- K6 embedding-table gradients (the IndexedSlices TF builds for tf.nn.embedding_lookup, nar_model.py:741, 918), DETERMINISTIC:
+ * rows of dxs that looked up the same table row are summed in a fixed order, no float atomics.
+ * table_grad[key, sub] = gamma[c0 + sub] * sum_{r : key(r) == key} dxs[r, c0 + sub]   (table rows nobody looked up are not written:
+ * the caller zeroes the embedding-gradient region first).
+ *  - cham_emb_grad_scan: small tables (context / metadata embeddings), one workgroup per table row scanning the R source keys;
+ *    key(r) = keysrc[r] (ids == NULL) or keysrc[ids[r]] (article metadata of item rows);
+ *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows ranks the rows by (id, row) (depends on the
+ *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key; ids >= 0, R < 2^20, dim <= 256. */
+int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
+                       const int64_t* ids, int cardinality, float* table_grad, void* stream);
+size_t cham_group_rows_workspace_bytes(int R);
+int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream);
+int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
+                          const int32_t* perm, float* table_grad, void* stream);
 
 /* --- K2/K4 fp32 MFMA GEMM with fused prologue/epilogue: tf.layers.Dense at nar_model.py:374-405, 410-426, 447-473,
  * the RNN input projection (:1308-1361) and their gradients.
@@ -83,7 +96,8 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
 /* test aid: launches per tile instance since the last reset - out16[0..4] = fp32 128x128, 256x128, 256x256, 256x64, 256x32;
- * out16[8..12] = the same tiles of the bf16 kernels.  Parity tests assert that a shape ran on the instance it is meant to cover. */
+ * out16[8..12] = the same tiles of the bf16 kernels; out16[14] / out16[15] = epilogue variant / K-splits of the last launch.
+ * Parity tests assert that a shape ran on the instance it is meant to cover; bench.py names the kernel symbol of a timed launch. */
 void cham_gemm_launch_counts(long long* out16, int reset);
 
 /* --- PreCAR combine (factorised nar_model.py:356-405): Z1[row] = leaky(U[u(row)] + V[v(row)]) and its backward.

@@ -323,6 +323,21 @@ class NAROracle:
         self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
         return s3 @ w['match4/kernel'] + w['match4/bias']       # last layer: fused into the softmax kernel, fp32 in every mode
 
+    def _stage(self, name):
+        """Optional wall-clock accounting per stage (bench.py's cpu_baseline leg sets ``self.timers = {}``)."""
+        import contextlib
+        import time
+        timers = getattr(self, 'timers', None)
+        if timers is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def cm():
+            t0 = time.perf_counter()
+            yield
+            timers[name] = timers.get(name, 0.0) + time.perf_counter() - t0
+        return cm()
+
     def _tap(self, name, t):
         """Optional capture of leaky-ReLU outputs (tests use them to detect kink sign flips)."""
         taps = getattr(self, 'debug_taps', None)
@@ -359,7 +374,8 @@ class NAROracle:
         buffer_t = torch.as_tensor(buffer_np)
         pop_t = torch.as_tensor(np.asarray(pop_norm, dtype=np.float32))                   # placeholder is tf.float32
         if neg_items is None:
-            neg_items = osampler.batch_negative_samples(all_clicked.numpy(), buffer_np, N, n_buf, self.seed, step)
+            with self._stage('sampler'):
+                neg_items = osampler.batch_negative_samples(all_clicked.numpy(), buffer_np, N, n_buf, self.seed, step)
         neg = torch.as_tensor(neg_items).long()                                           # [B,T,N]  (:275)
 
         scfg = p['session_features_config']['sequence_features']
@@ -370,24 +386,28 @@ class NAROracle:
         gamma, beta = self.w['gamma'], self.w['beta']
         # keep_prob == 1.0 (every shipped script) -> dropout is the identity (:338, 352, 368)
         assert p.get('dropout_keep_prob', 1.0) == 1.0 or not train, "oracle restates keep_prob=1.0 only"
-        x_in = torch.cat([ctx, self._item_features(item_clicked, event_ts, buffer_t, pop_t, max_ts if global_max_ts is not None else None)], 2) * gamma + beta   # :328-333
-        x_pos = torch.cat([ctx, self._item_features(label_next, max_ts, buffer_t, pop_t)], 2) * gamma + beta     # :343-347
-        ctx_tiled = ctx.unsqueeze(2).expand(B, T, neg.shape[2], ctx.shape[-1])                                     # :360
-        x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364
-        car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos), self._car(x_neg)                             # :374-405
-        rnn_out = self._rnn(car_in, seq_len)                                                                      # :408
-        fc1 = _leaky(self._mm(rnn_out, self.w['FC1/kernel']) + self.w['FC1/bias'])                                        # :411
-        self._tap('FC1', fc1)
-        pred = torch.tanh(self._mm(fc1, self.w['FC2/kernel']) + self.w['FC2/bias'])                                       # :423
-        s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
-        s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500
-        logits = torch.cat([s_pos, s_neg], 2)                                                                     # :511
-        tau = torch.tensor(p['softmax_temperature'], dtype=torch.float32)
-        probs = torch.softmax(logits / tau, dim=-1)                                                               # :514-515
-        loss_mask = mask.float()
-        xe = -(torch.log(probs[:, :, 0]) * loss_mask).sum() / loss_mask.sum()                                     # :660-664
-        reg = self.reg_loss()                                                                                     # :655
-        total = xe + reg
+        with self._stage('gather'):
+            x_in = torch.cat([ctx, self._item_features(item_clicked, event_ts, buffer_t, pop_t, max_ts if global_max_ts is not None else None)], 2) * gamma + beta   # :328-333
+            x_pos = torch.cat([ctx, self._item_features(label_next, max_ts, buffer_t, pop_t)], 2) * gamma + beta     # :343-347
+            ctx_tiled = ctx.unsqueeze(2).expand(B, T, neg.shape[2], ctx.shape[-1])                                     # :360
+            x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364
+        with self._stage('CAR'):
+            car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos), self._car(x_neg)                             # :374-405
+        with self._stage('RNN'):
+            rnn_out = self._rnn(car_in, seq_len)                                                                      # :408
+        with self._stage('scorer'):
+            fc1 = _leaky(self._mm(rnn_out, self.w['FC1/kernel']) + self.w['FC1/bias'])                                        # :411
+            self._tap('FC1', fc1)
+            pred = torch.tanh(self._mm(fc1, self.w['FC2/kernel']) + self.w['FC2/bias'])                                       # :423
+            s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
+            s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500
+            logits = torch.cat([s_pos, s_neg], 2)                                                                     # :511
+            tau = torch.tensor(p['softmax_temperature'], dtype=torch.float32)
+            probs = torch.softmax(logits / tau, dim=-1)                                                               # :514-515
+            loss_mask = mask.float()
+            xe = -(torch.log(probs[:, :, 0]) * loss_mask).sum() / loss_mask.sum()                                     # :660-664
+            reg = self.reg_loss()                                                                                     # :655
+            total = xe + reg
         if p.get('novelty_reg_factor', 0.0) > 0.0:                                                                # :673-683
             neg_prob = torch.softmax(s_neg / tau, dim=-1)
             neg_nov = -(torch.log(pop_t[neg]) / torch.log(torch.tensor(2.0)))
@@ -409,10 +429,12 @@ class NAROracle:
         for v in self.w.values():
             v.grad = None
         out = self.forward(features, labels, buffer_ids, pop_norm, 'train', neg_items)
-        out['total_loss'].backward()
-        grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)).clone())
-                            for k, v in self.w.items())
-        self.adam_update(grads)
+        with self._stage('backward'):
+            out['total_loss'].backward()
+        with self._stage('Adam'):
+            grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)).clone())
+                                for k, v in self.w.items())
+            self.adam_update(grads)
         out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         if return_grads:
             out['grads'] = grads

@@ -76,7 +76,7 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
     losses, flat, m, _ = _run(1, 0, batches, p)
     assert np.abs(losses - r0['losses']).max() < 2e-5, (losses, r0['losses'])
-    # two SINGLE-process runs already differ by up to ~1.4e-4 of max|m| after three steps (float atomics in the embedding scatter ->
-    # last-bit gradient differences -> Adam's first steps flip the sign of near-zero updates -> slightly different later gradients)
+    # the sum of two row shards' gradients differs from the single-process gradient in the last bits (fp32 summation order);
+    # every kernel of the step is deterministic (no float atomics), so that is the only difference
     from chameleon_recsys_amd.nar.nar_model import NARRuntime
-    H.assert_flat_close(NARRuntime(p).layout, r0['flat'], m_dp, flat, m, p['lr'], n_steps=STEPS, m_tol=1e-3)
+    H.assert_flat_close(NARRuntime(p).layout, r0['flat'], m_dp, flat, m, p['lr'], n_steps=STEPS, m_tol=1e-4)

@@ -323,3 +323,43 @@ def test_step_parity_novelty_regularised_loss(gpu):
         assert abs(plain - float(ref['total_loss'].detach())) > 0.05        # the term is not negligible in this set-up
         assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < LOGIT_TOL
     _mode_parity(p, 3e-4, lambda ref: ref['total_loss'] - ref['reg_loss'], check_fwd)
+
+
+def test_training_is_bit_reproducible(gpu):
+    """Two runs of the same four optimizer steps (device-resident state, two-lane stream schedule, presampled negatives) end with
+    BIT-IDENTICAL weights and Adam slots: every reduction of the step has a fixed order (split-K partials, column sums, the PreCAR
+    slot scatter, the embedding-table gradients) - no float atomics anywhere.  SURVEY section 5 asks for exactly this mode."""
+    from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
+    p = H.tiny_params()
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    runs = []
+    for _ in range(2):
+        model, _o = H.make_pair(p)
+        st = DeviceClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'],
+                                     p['recent_clicks_for_normalization'], 1000)
+        dev = [model.upload_batch(f, l) for f, l in batches]
+        losses = []
+        for i, d in enumerate(dev):
+            model.feed_state(st, st)
+            losses.append(model.train_step(d).clone())
+            st.update_from_device_batch(d['aci'], d['g_event_ts'])
+            if i + 1 < len(dev):
+                model.presample(dev[i + 1])
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), model.rt.flat.cpu().clone(), model.rt.m.cpu().clone(), model.rt.v.cpu().clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+
+
+def test_step_parity_fewer_candidates_than_negatives(gpu):
+    """A catalog too small to offer N unique valid candidates: every click's negatives end in zero padding (nar_model.py:1252) and
+    the zero-padding item row collects the gradient of ALL of them (the reference backpropagates through padded negatives too)."""
+    p = H.tiny_params(n_items=32, neg=40, neg_from_buffer=30, buffer_size=300, for_norm=100)
+    batches = synthetic.make_batches(5, 64, 8, 32, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    for i in (3, 4):
+        _compare_step(model, orc, *batches[i], st)
+        neg = model._plan.neg_ids.cpu().numpy()
+        valid = np.asarray(batches[i][1]['label_next_item']) != 0
+        assert (neg[valid] == 0).mean() > 0.125, "this case is meant to exercise > 12.5 % padded negatives"
