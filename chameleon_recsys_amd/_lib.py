@@ -29,6 +29,10 @@ _SIGNATURES = {
                               P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_bf16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int,
                                P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
+    "cham_gemm_b16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
+                              P, c_size_t, c_int, P]),
+    "cham_gemm_b16_set_variant": (None, [c_int]),
+    "cham_gemm_b16_launch_counts": (None, [P, c_int]),
     "cham_gemm_set_variant": (None, [c_int]),
     "cham_gemm_launch_counts": (None, [P, c_int]),
     "cham_combine_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_long, c_long, P]),

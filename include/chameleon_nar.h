@@ -93,6 +93,21 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
                    int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
                    int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 
+/* bf16-RESIDENT GEMMs of the bf16 configuration (csrc/gemm_b16.hip): the matrices with one row per candidate live in HBM as bf16
+ * (weights: a bf16 shadow of the fp32 master copy); fp32 accumulation / bias / activation.
+ *   transA = 0, transB = 1 (NT): A [M, lda], B [N, ldb] bf16, k contiguous; C bf16 (out_f32 = 0) or fp32 [M, ldc];
+ *     epilogue + bias (fp32) and act, or x act'(dref) with dref = the saved bf16 activation [M, ldr] (dgrad, bf16 out);
+ *   transA = 1, transB = 0 (TN): A stored [K, lda >= M], B stored [K, ldb >= N] bf16; C fp32 (+)=; split-K through `workspace`
+ *     (splits_hint 1 = none, 0 = automatic; fixed-order reduction).
+ * K % 8 == 0 (NT), M % 8 == 0 and N % 8 == 0 (TN), N % 4 == 0, leading dimensions % 8 == 0, 16-byte aligned bases. */
+int cham_gemm_b16(const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc, int out_f32, int M,
+                  int N, int K, const float* bias, int act, const void* dref, int ldr, int dact, int accumulate, float* workspace,
+                  size_t workspace_bytes, int splits_hint, void* stream);
+/* test / tuning aids: tile variant for N > 64 (0 = 128x128, 1 = 256x128 / 8 waves, 2 = 256x128 / 4 waves, -1 = automatic) and
+ * launches per tile instance since the last reset (out8[0..4] = 128x128, 256x128/8, 256x128/4, 256x64, 256x32) */
+void cham_gemm_b16_set_variant(int variant);
+void cham_gemm_b16_launch_counts(long long* out8, int reset);
+
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
 /* test aid: launches per tile instance since the last reset - out16[0..4] = fp32 128x128, 256x128, 256x256, 256x64, 256x32;
