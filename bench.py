@@ -30,6 +30,7 @@ ADRESSA = dict(n_items=13000, ace_dim=250, seq_len=30, batch=256, neg=100, neg_f
                C=1024, H=256, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2, lr=3e-4,
                reg_weight_decay=1e-4)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PFLOP/s headline includes 2:1 sparsity)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 
 
@@ -82,9 +83,12 @@ def cpu_baseline(params, cfg, length_dist, seed, n_steps=20):
 def gemm_symbol(r):
     """The C++ kernel symbol a profiled GEMM launch ran on, rebuilt from the library's own record of the launch (tile instance,
     epilogue variant) - the names `rocprofv3 --stats` lists."""
-    bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
     tf = lambda b: "true" if b else "false"
     ak, bkc, epi = not r['transA'], bool(r['transB']), r['epi']
+    if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
+        bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
+        return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
     rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
     if r['bf16']:
         return "void gemm_bf16_kernel<%d, %d, %d, %d, 32, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
@@ -342,8 +346,13 @@ def main():
         e['n'] += 1
         e['ms'] += r['ev'][0].elapsed_time(r['ev'][1])
         e['flop'] += 2.0 * r['M'] * r['N'] * r['K']
-        # operands + output, each touched once (fp32 storage): A + B + bias + C (+ the saved activation a dgrad epilogue reads)
-        e['bytes'] += 4.0 * (r['M'] * r['K'] + r['K'] * r['N'] + r['M'] * r['N'] * (2 if r['dref'] else 1) + (r['N'] if r['bias'] else 0))
+        # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
+        # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
+        if r.get('b16'):
+            e['bytes'] += 2.0 * (r['M'] * r['K'] + r['K'] * r['N'] + (r['M'] * r['N'] if r['dref'] else 0)) + \
+                (4.0 if (r['out_f32'] or r['epi'] == 6) else 2.0) * r['M'] * r['N'] + (4.0 * r['N'] if r['bias'] else 0)
+        else:
+            e['bytes'] += 4.0 * (r['M'] * r['K'] + r['K'] * r['N'] + r['M'] * r['N'] * (2 if r['dref'] else 1) + (r['N'] if r['bias'] else 0))
     ranked = sorted(by_sym.items(), key=lambda kv: -kv[1]['ms'])
     ms_all = sum(e['ms'] for e in by_sym.values())
     fl_all = sum(e['flop'] for e in by_sym.values())
@@ -352,15 +361,16 @@ def main():
         r = e['r']
         mode = "NN" if not r['transA'] and not r['transB'] else ("NT (dgrad)" if r['transB'] else "TN (wgrad)")
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
-            sym, "bf16" if r['bf16'] else "fp32", mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
+            sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else "fp32", mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])
 
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else FP32_MATRIX_PEAK_TFLOPS
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
-                "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_fp32_mfma_peak": round(tf_s / FP32_MATRIX_PEAK_TFLOPS, 4),
-                "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4)}
+                "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
+                "mfma_peak_tflops": peak, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4)}
     DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
     n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
@@ -433,10 +443,14 @@ def main():
                          "all_gemm_tflops": round(fl_all / (ms_all * 1e-3) / 1e12, 2) if ms_all > 0 else 0.0,
                          "step_reference_dense_tflops": round(3 * dense_fwd / (ms_step * 1e-3) / 1e12, 2)},
         }
-        if args.dtype == "bf16":     # the matrix cores run 16x faster than in fp32: the same launches are bound by moving their operands
-            gbs = dom['bytes'] / (ms_nn * 1e-3) / 1e9 if ms_nn > 0 else 0.0
-            out["roofline"].update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBPS, 4),
-                                   traffic=None, traffic_source=None)
+        if args.dtype == "bf16":     # bf16 MFMA is 16x the fp32 rate: name whichever roof binds the dominant launch at its shape
+            t_mfma, t_hbm = fl_nn / (BF16_MATRIX_PEAK_TFLOPS * 1e12), dom['bytes'] / (HBM_PEAK_GBPS * 1e9)
+            if t_hbm > t_mfma:
+                gbs = dom['bytes'] / (ms_nn * 1e-3) / 1e9 if ms_nn > 0 else 0.0
+                out["roofline"].update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBPS, 4))
+            else:
+                out["roofline"].update(bound="mfma", peak=BF16_MATRIX_PEAK_TFLOPS, frac=round(achieved / BF16_MATRIX_PEAK_TFLOPS, 4))
+            out["roofline"].update(traffic=None, traffic_source=None)
         if ragged is not None:
             out["g1_like_session_lengths"] = ragged
         if world == 1 and not args.no_boundary_leg and args.config == "g1" and args.dtype == "f32":

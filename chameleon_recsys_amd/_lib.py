@@ -38,6 +38,14 @@ _SIGNATURES = {
     "cham_combine_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_long, c_long, P]),
     "cham_combine_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cham_combine_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "cham_combine_fwd_b16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "cham_combine_bwd_b16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "cham_mulpred_bwd_b16": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "cham_mul_rows_b16": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "cham_score_softmax_fwd_b16": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, c_float, P, P, P, P]),
+    "cham_score_softmax_bwd_b16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, c_float, P, P, P, P, P]),
+    "cham_colsum_b16": (c_int, [P, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
+    "cham_cast_b16": (c_int, [P, c_int, c_int, P, P, P]),
     "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_ugrnn_point_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),

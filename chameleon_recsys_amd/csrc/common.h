@@ -69,6 +69,21 @@ __device__ __forceinline__ uint64_t philox_sort_key(uint32_t q, uint32_t j, uint
     return ((uint64_t)philox_rand32(q, j, b, stage, seed, step) << 32) | (uint64_t)q;
 }
 
+// ---- 4 consecutive elements of a row as float4: fp32 rows (16-byte access) or bf16 rows (8-byte access, the bf16 configuration's
+// candidate-row matrices).  bf16 -> fp32 is exact; fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4(__bf16* p, const float4& v) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = b;
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -286,11 +286,13 @@ __global__ __launch_bounds__(256) void gemm_b16_splitk_reduce(const float* __res
     }
 }
 
-static long long g_b16_launches[8];      // [0] 128x128, [1] 256x128 / 8 waves, [2] 256x128 / 4 waves, [3] 256x64, [4] 256x32 (test aid)
+// [0] 128x128, [1] 256x128 / 8 waves, [2] 256x128 / 4 waves, [3] 256x64, [4] 256x32; of the LAST launch: [5] fp32 output, [6] epilogue
+// variant, [7] K-splits (test / bench aid, not thread-safe)
+static long long g_b16_launches[8];
 static int g_b16_variant = -1;
 extern "C" void cham_gemm_b16_set_variant(int v) { g_b16_variant = v; }
 extern "C" void cham_gemm_b16_launch_counts(long long* out8, int reset) {
-    for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_b16_launches[i]; if (reset) g_b16_launches[i] = 0; }
+    for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_b16_launches[i]; if (reset && i < 5) g_b16_launches[i] = 0; }
 }
 
 template <int BM, int BN, int WM, int WN, bool AK, bool BKC, int EPI, bool OUTF32>
@@ -300,6 +302,7 @@ static int b16_launch_epi(B16Params& p, hipStream_t st) {
     using LB = Stage16<BN, BK, BKC, WM * WN * 64>;
     constexpr int ASZ = AK ? BM * LA::LD : BK * LA::LD, BSZ = BKC ? BN * LB::LD : BK * LB::LD;
     const size_t smem = (size_t)2 * (ASZ + BSZ) * 2;
+    g_b16_launches[5] = OUTF32; g_b16_launches[6] = EPI; g_b16_launches[7] = p.splits;
     auto k = gemm_b16_kernel<BM, BN, WM, WN, AK, BKC, EPI, OUTF32>;
     static bool done = false;
     if (!done) {

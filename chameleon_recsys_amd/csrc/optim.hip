@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
 
 // out[c] = sum_r w[r] * X[r, c]   (w optional).  Stage 1: fixed row chunks -> partial[chunk][F]; stage 2 sums
 // the chunks in order.  Deterministic; X is streamed once with float4 loads when F/4 divides 256.
-__global__ __launch_bounds__(256) void k_colsum_vec(const float* __restrict__ X, int ld, int R, int F, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum_vec(const T* __restrict__ X, int ld, int R, int F, const float* __restrict__ w,
                                                     int rows_per_chunk, float* __restrict__ partial) {
     __shared__ float4 sm[256];
     const int nf4 = F / 4, rpi = 256 / nf4;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_colsum_vec(const float* __restrict__ X,
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = r0 + rl; r < r1; r += rpi) {
-        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ld + c4 * 4);
+        const float4 x = ld4(X + (size_t)r * ld + c4 * 4);
         const float ww = w ? w[r] : 1.f;
         acc.x += ww * x.x; acc.y += ww * x.y; acc.z += ww * x.z; acc.w += ww * x.w;
     }
@@ -165,9 +166,49 @@ extern "C" int cham_colsum(const float* X, int ld, int R, int F, const float* w,
     const int nchunks = (R + rpc - 1) / rpc;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (F % 4 == 0) && (F / 4 <= 256) && (256 % (F / 4) == 0) && (ld % 4 == 0);
-    if (vec) hipLaunchKernelGGL(k_colsum_vec, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
+    if (vec) hipLaunchKernelGGL(k_colsum_vec<float>, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
     else hipLaunchKernelGGL(k_colsum_gen, dim3(nchunks), dim3(256), 0, st, X, ld, R, F, w, rpc, workspace);
     hipLaunchKernelGGL(k_colsum_final, dim3((F + 15) / 16), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+// bf16 configuration: column sums of a bf16 matrix (bias gradients over the candidate rows); F % 4 == 0, F <= 1024, 256 % (F/4) == 0
+extern "C" int cham_colsum_b16(const void* X, int ld, int R, int F, const float* w, float* out, int accumulate,
+                               float* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !out || !workspace || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    if (workspace_bytes < cham_colsum_workspace_bytes(R, F)) return -CHAM_ERR_ARG;
+    if ((F % 4) || (F / 4 > 256) || (256 % (F / 4)) || (ld % 4)) return -CHAM_ERR_ARG;
+    int rpc = (R + 1023) / 1024; if (rpc < 64) rpc = 64;
+    const int nchunks = (R + rpc - 1) / rpc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colsum_vec<__bf16>, dim3(nchunks), dim3(256), 0, st, reinterpret_cast<const __bf16*>(X), ld, R, F, w, rpc, workspace);
+    hipLaunchKernelGGL(k_colsum_final, dim3((F + 15) / 16), dim3(256), 0, st, workspace, nchunks, F, out, accumulate);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// bf16 shadow of a weight matrix W [R, Cc] (fp32 master copy): dst = bf16(W) [R, Cc] and / or dstT = bf16(W)^T [Cc, R] - the
+// k-contiguous operand forms of the forward (W^T) and dgrad (W) GEMMs of the bf16 configuration.  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void k_cast_b16(const float* __restrict__ W, int R, int Cc, __bf16* __restrict__ dst, __bf16* __restrict__ dstT) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < R && c < Cc) ? W[(size_t)r * Cc + c] : 0.f;
+        t[i][tx] = v;
+        if (dst && r < R && c < Cc) dst[(size_t)r * Cc + c] = (__bf16)v;
+    }
+    __syncthreads();
+    if (dstT)
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, r = r0 + tx;
+            if (r < R && c < Cc) dstT[(size_t)c * R + r] = (__bf16)t[tx][i];
+        }
+}
+extern "C" int cham_cast_b16(const float* W, int R, int Cc, void* dst, void* dstT, void* stream) {
+    if (!W || (!dst && !dstT) || R <= 0 || Cc <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_cast_b16, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, W, R, Cc,
+                       reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -46,12 +46,13 @@ __global__ __launch_bounds__(256) void k_combine_fwd(const float* __restrict__ U
 // The candidate rows of one position share U[bt]: one workgroup per position keeps its U row in registers and streams the 1+N
 // candidate rows (4 independent V-row loads in flight) - the row-per-workgroup form above pays a dependent slot -> V -> store
 // chain and a workgroup launch per 4 KB written.
+template <typename T>
 __global__ __launch_bounds__(256) void k_combine_fwd_cand(const float* __restrict__ U, const float* __restrict__ V, int C,
                                                           int BT, int N, int pmax, const int* __restrict__ neg_slot,
-                                                          float* __restrict__ Z1) {
+                                                          T* __restrict__ Z1c /* candidate rows only */) {
     const int bt = blockIdx.x, NC = N + 1;
     const float4* pu = reinterpret_cast<const float4*>(U + (size_t)bt * C);
-    float4* po = reinterpret_cast<float4*>(Z1 + ((size_t)BT + (size_t)bt * NC) * C);
+    T* po = Z1c + (size_t)bt * NC * C;
     for (int k = threadIdx.x; k < C / 4; k += 256) {
         const float4 a = pu[k];
         for (int c0 = 0; c0 < NC; c0 += 4) {
@@ -67,24 +68,26 @@ __global__ __launch_bounds__(256) void k_combine_fwd_cand(const float* __restric
                 float4 o;
                 o.x = act_fwd(a.x + b[i].x, ACT_LEAKY); o.y = act_fwd(a.y + b[i].y, ACT_LEAKY);
                 o.z = act_fwd(a.z + b[i].z, ACT_LEAKY); o.w = act_fwd(a.w + b[i].w, ACT_LEAKY);
-                po[(size_t)(c0 + i) * (C / 4) + k] = o;
+                st4(po + (size_t)(c0 + i) * C + 4 * k, o);
             }
         }
     }
 }
 
 // dU[bt] = dpre[input bt] + sum_c dpre[cand (bt,c)];  dV_in[bt] = dpre[input bt];  dV_pos[bt] = dpre[cand (bt,0)]
-__global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__ dpre, int C, int BT, int N,
-                                                       float* __restrict__ dU, float* __restrict__ dV) {
+// (T = element type of the candidate rows: fp32, or bf16 in the bf16 configuration; the clicked-input rows are fp32 in both)
+template <typename T>
+__global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__ dpre_in, const T* __restrict__ dpre_cand, int C, int BT,
+                                                       int N, float* __restrict__ dU, float* __restrict__ dV) {
     const int bt = blockIdx.x;
-    const float4* pin = reinterpret_cast<const float4*>(dpre + (size_t)bt * C);
-    const float4* pc = reinterpret_cast<const float4*>(dpre + ((size_t)BT + (size_t)bt * (N + 1)) * C);
+    const float4* pin = reinterpret_cast<const float4*>(dpre_in + (size_t)bt * C);
+    const T* pc = dpre_cand + (size_t)bt * (N + 1) * C;
     for (int k = threadIdx.x; k < C / 4; k += 256) {
         const float4 a = pin[k];
-        const float4 p0 = pc[k];
+        const float4 p0 = ld4(pc + 4 * k);
         float4 s = make_float4(a.x + p0.x, a.y + p0.y, a.z + p0.z, a.w + p0.w);
         for (int c = 1; c <= N; ++c) {
-            const float4 x = pc[(size_t)c * (C / 4) + k];
+            const float4 x = ld4(pc + (size_t)c * C + 4 * k);
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
         reinterpret_cast<float4*>(dU + (size_t)bt * C)[k] = s;
@@ -127,7 +130,8 @@ __device__ __forceinline__ int block_sum_int(int v, int* red /*[4]*/) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void k_slot_reduce(const float* __restrict__ dpre, int C, int BT, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void k_slot_reduce(const T* __restrict__ cand /* candidate rows of dpre */, int C, int BT, int N,
                                                      const int* __restrict__ neg_slot, const unsigned* __restrict__ bitmap, int W,
                                                      int nslots, float* __restrict__ partial /*[nchunk][nslots][C]*/,
                                                      float* __restrict__ dV) {
@@ -179,19 +183,18 @@ __global__ __launch_bounds__(256) void k_slot_reduce(const float* __restrict__ d
     }
     __syncthreads();
     float* out = hot ? partial + ((size_t)chunk * nslots + s) * C : dV + ((size_t)2 * BT + s) * C;
-    const float* cand = dpre + (size_t)BT * C;
     for (int k = tid; k < C / 4; k += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = 0;
         for (; t + 8 <= cnt; t += 8) {
             float4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4*>(cand + (size_t)list[t + u] * C)[k];
+            for (int u = 0; u < 8; ++u) x[u] = ld4(cand + (size_t)list[t + u] * C + 4 * k);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         for (; t < cnt; ++t) {
-            const float4 x = reinterpret_cast<const float4*>(cand + (size_t)list[t] * C)[k];
+            const float4 x = ld4(cand + (size_t)list[t] * C + 4 * k);
             acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
         }
         reinterpret_cast<float4*>(out)[k] = acc;
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(256) void k_slot_final(const float* __restrict__ pa
 
 // The zero-padding slot: rows of one chunk of the slot table that hold `slot`, compacted IN ORDER into an LDS list (ballot-free
 // per-thread bit masks + popcount prefix) and summed; chunk_len <= SLOT_LIST, so the list holds every match.
-__global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* __restrict__ dpre, int C, int BT, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const T* __restrict__ cand /* candidate rows of dpre */, int C, int BT, int N,
                                                                    const int* __restrict__ neg_slot, int slot,
                                                                    float* __restrict__ partial /*[nchunk][C]*/,
                                                                    int chunk_len /* multiple of 1024, <= SLOT_LIST */) {
@@ -262,16 +266,16 @@ __global__ __launch_bounds__(256) void k_combine_bwd_slots_partial(const float* 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const size_t i = i0 + list[t + u];
-                const size_t row = (size_t)BT + (i / N) * (N + 1) + 1 + (i % N);
-                x[u] = reinterpret_cast<const float4*>(dpre + row * C)[k];
+                const size_t row = (i / N) * (N + 1) + 1 + (i % N);
+                x[u] = ld4(cand + row * C + 4 * k);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         for (; t < cnt; ++t) {
             const size_t i = i0 + list[t];
-            const size_t row = (size_t)BT + (i / N) * (N + 1) + 1 + (i % N);
-            const float4 x = reinterpret_cast<const float4*>(dpre + row * C)[k];
+            const size_t row = (i / N) * (N + 1) + 1 + (i % N);
+            const float4 x = ld4(cand + row * C + 4 * k);
             acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
         }
         reinterpret_cast<float4*>(partial + (size_t)chunk * C)[k] = acc;
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(256) void k_combine_bwd_pad_final(const float* __re
 
 // in place: dM[row] <- dM[row] * pred[bt] * (1 - Z2c[row]^2)   (gradient w.r.t. the CAR tanh pre-activation)
 // dpred_pre[bt]    = (sum_c dM[row] * Z2c[row]) * (1 - pred[bt]^2) (gradient w.r.t. the FC2 tanh pre-activation)
-__global__ __launch_bounds__(256) void k_mulpred_bwd(float* __restrict__ dM, const float* __restrict__ Z2c,
+template <typename T>
+__global__ __launch_bounds__(256) void k_mulpred_bwd(T* __restrict__ dM, const T* __restrict__ Z2c,
                                                      const float* __restrict__ pred, int C, int N, float* __restrict__ dpred_pre) {
     const int bt = blockIdx.x;
     const float4* pp = reinterpret_cast<const float4*>(pred + (size_t)bt * C);
@@ -299,14 +304,14 @@ __global__ __launch_bounds__(256) void k_mulpred_bwd(float* __restrict__ dM, con
         const float4 p = pp[k];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = 0; c <= N; ++c) {
-            const size_t off = ((size_t)bt * (N + 1) + c) * (C / 4) + k;
-            const float4 g = reinterpret_cast<const float4*>(dM)[off];
-            const float4 z = reinterpret_cast<const float4*>(Z2c)[off];
+            const size_t off = ((size_t)bt * (N + 1) + c) * C + 4 * k;
+            const float4 g = ld4(dM + off);
+            const float4 z = ld4(Z2c + off);
             acc.x += g.x * z.x; acc.y += g.y * z.y; acc.z += g.z * z.z; acc.w += g.w * z.w;
             float4 o;
             o.x = g.x * p.x * (1.f - z.x * z.x); o.y = g.y * p.y * (1.f - z.y * z.y);
             o.z = g.z * p.z * (1.f - z.z * z.z); o.w = g.w * p.w * (1.f - z.w * z.w);
-            reinterpret_cast<float4*>(dM)[off] = o;
+            st4(dM + off, o);
         }
         float4 o;
         o.x = acc.x * (1.f - p.x * p.x); o.y = acc.y * (1.f - p.y * p.y);
@@ -315,10 +320,31 @@ __global__ __launch_bounds__(256) void k_mulpred_bwd(float* __restrict__ dM, con
     }
 }
 
+// bf16 configuration: Mc[row] = bf16(Z2c[row] * pred[bt]) - the `cand (.) pred` product of nar_model.py:478-495 as the bf16 operand
+// of the scorer's first layer and of its weight gradient (the fp32 path fuses it into the GEMM's staging as a row scale)
+__global__ __launch_bounds__(256) void k_mul_rows_b16(const __bf16* __restrict__ Z2c, const float* __restrict__ pred, int C, int NC,
+                                                      __bf16* __restrict__ Mc) {
+    const int bt = blockIdx.x;
+    const float4* pp = reinterpret_cast<const float4*>(pred + (size_t)bt * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 p = pp[k];
+        for (int c0 = 0; c0 < NC; c0 += 4) {
+            float4 z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = ld4(Z2c + ((size_t)bt * NC + min(c0 + i, NC - 1)) * C + 4 * k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i >= NC) break;
+                st4(Mc + ((size_t)bt * NC + c0 + i) * C + 4 * k, make_float4(z[i].x * p.x, z[i].y * p.y, z[i].z * p.z, z[i].w * p.w));
+            }
+        }
+    }
+}
+
 // last scorer layer (K3 -> 1) + softmax(logits/tau) + masked NLL.  One wave per click (b,t); lanes over the
 // 1+N candidates; max / sum by wavefront shuffles.
-template <int K3>
-__global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restrict__ S3, const float* __restrict__ w4,
+template <int K3, typename T>
+__global__ __launch_bounds__(256) void k_score_softmax_fwd(const T* __restrict__ S3, const float* __restrict__ w4,
                                                            const float* __restrict__ b4, int BT, int N, float inv_tau,
                                                            const unsigned char* __restrict__ mask,
                                                            float* __restrict__ logits, float* __restrict__ probs,
@@ -334,10 +360,10 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restri
     const float bias = b4[0];
     float mx = -INFINITY;
     for (int c = lane; c < NC; c += 64) {
-        const float4* r = reinterpret_cast<const float4*>(S3 + ((size_t)bt * NC + c) * K3);
+        const T* r = S3 + ((size_t)bt * NC + c) * K3;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < K3 / 4; ++k) { const float4 x = r[k]; s += x.x * w[4 * k] + x.y * w[4 * k + 1] + x.z * w[4 * k + 2] + x.w * w[4 * k + 3]; }
+        for (int k = 0; k < K3 / 4; ++k) { const float4 x = ld4(r + 4 * k); s += x.x * w[4 * k] + x.y * w[4 * k + 1] + x.z * w[4 * k + 2] + x.w * w[4 * k + 3]; }
         s += bias;
         logits[(size_t)bt * NC + c] = s;
         mx = fmaxf(mx, s * inv_tau);
@@ -379,11 +405,11 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const float* __restri
 }
 
 // ds[row] = (p - [c==0]) * mask / (tau * sum(mask));  dS3pre[row,k] = ds * w4[k] * leaky'(S3[row,k])
-template <int K3>
-__global__ __launch_bounds__(256) void k_score_softmax_bwd(const float* __restrict__ S3, const float* __restrict__ w4,
+template <int K3, typename T>
+__global__ __launch_bounds__(256) void k_score_softmax_bwd(const T* __restrict__ S3, const float* __restrict__ w4,
                                                            const float* __restrict__ probs, const unsigned char* __restrict__ mask,
                                                            int BT, int N, float scale /* 1/(tau*sum_mask) */,
-                                                           float* __restrict__ ds, float* __restrict__ dS3, float nov_factor,
+                                                           float* __restrict__ ds, T* __restrict__ dS3, float nov_factor,
                                                            const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
                                                            const float* __restrict__ logits, float inv_tau,
                                                            const float* __restrict__ nov_aux) {
@@ -399,17 +425,17 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const float* __restri
         g -= nov_factor * scale * q * (nov_c - nov_aux[(size_t)bt * 3 + 2]);
     }
     ds[row] = g;
-    const float4* r = reinterpret_cast<const float4*>(S3 + row * K3);
-    float4* o = reinterpret_cast<float4*>(dS3 + row * K3);
+    const T* r = S3 + row * K3;
+    T* o = dS3 + row * K3;
 #pragma unroll
     for (int k = 0; k < K3 / 4; ++k) {
-        const float4 x = r[k];
+        const float4 x = ld4(r + 4 * k);
         float4 y;
         y.x = g * w4[4 * k] * act_bwd_from_out(x.x, ACT_LEAKY);
         y.y = g * w4[4 * k + 1] * act_bwd_from_out(x.y, ACT_LEAKY);
         y.z = g * w4[4 * k + 2] * act_bwd_from_out(x.z, ACT_LEAKY);
         y.w = g * w4[4 * k + 3] * act_bwd_from_out(x.w, ACT_LEAKY);
-        o[k] = y;
+        st4(o + 4 * k, y);
     }
 }
 
@@ -448,10 +474,20 @@ extern "C" int cham_combine_fwd(const float* U, const float* V, int C, int BT, i
     const long rows = (long)BT + (long)BT * (N + 1);
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > rows) return -CHAM_ERR_ARG;
     if (row_begin == BT && row_count == (long)BT * (N + 1))         // all candidate rows: one workgroup per position
-        hipLaunchKernelGGL(k_combine_fwd_cand, dim3((unsigned)BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot, Z1);
+        hipLaunchKernelGGL(k_combine_fwd_cand<float>, dim3((unsigned)BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
+                           Z1 + (size_t)BT * C);
     else
         hipLaunchKernelGGL(k_combine_fwd, dim3((unsigned)row_count), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax,
                            neg_slot, Z1, (int)row_begin);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+// bf16 configuration: the BT*(1+N) candidate rows as bf16 (the clicked-input rows stay fp32: cham_combine_fwd on rows [0, BT))
+extern "C" int cham_combine_fwd_b16(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                                    void* Z1c, void* stream) {
+    if (!U || !V || !neg_slot || !Z1c || (C & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_combine_fwd_cand<__bf16>, dim3((unsigned)BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
+                       reinterpret_cast<__bf16*>(Z1c));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -474,9 +510,10 @@ extern "C" size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pma
     return w.bitmap_bytes + w.partial_bytes + w.pad_bytes;
 }
 
-extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot,
-                                float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
-    if (!dpre || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0 || pmax <= 0) return -CHAM_ERR_ARG;
+template <typename T>
+static int combine_bwd_impl(const float* dpre_in, const T* dpre_cand, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                            float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dpre_in || !dpre_cand || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0 || pmax <= 0) return -CHAM_ERR_ARG;
     if (workspace_bytes < cham_combine_bwd_workspace_bytes(C, BT, N, pmax) || ((uintptr_t)workspace & 15)) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const SlotWs w = slot_ws(C, BT, N, pmax);
@@ -484,50 +521,103 @@ extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pma
     float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes);
     float* pad_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes + w.partial_bytes);
     const size_t n = (size_t)BT * N;
-    hipLaunchKernelGGL(k_combine_bwd_u, dim3(BT), dim3(256), 0, st, dpre, C, BT, N, dU, dV);
+    hipLaunchKernelGGL(k_combine_bwd_u<T>, dim3(BT), dim3(256), 0, st, dpre_in, dpre_cand, C, BT, N, dU, dV);
     if (hipMemsetAsync(bitmap, 0, (size_t)pmax * w.W * sizeof(unsigned), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_slot_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, neg_slot, n, N, pmax, w.W, bitmap);
-    hipLaunchKernelGGL(k_slot_reduce, dim3(pmax, w.nchunk), dim3(256), 0, st, dpre, C, BT, N, neg_slot, bitmap, w.W, pmax, partial, dV);
+    hipLaunchKernelGGL(k_slot_reduce<T>, dim3(pmax, w.nchunk), dim3(256), 0, st, dpre_cand, C, BT, N, neg_slot, bitmap, w.W, pmax, partial, dV);
     hipLaunchKernelGGL(k_slot_final, dim3(pmax), dim3(256), 0, st, partial, C, pmax, w.nchunk, BT, bitmap, w.W, dV);
-    hipLaunchKernelGGL(k_combine_bwd_slots_partial, dim3(w.nchunk_pad), dim3(256), 0, st, dpre, C, BT, N, neg_slot, pmax,
+    hipLaunchKernelGGL(k_combine_bwd_slots_partial<T>, dim3(w.nchunk_pad), dim3(256), 0, st, dpre_cand, C, BT, N, neg_slot, pmax,
                        pad_partial, SLOT_LIST);
     hipLaunchKernelGGL(k_combine_bwd_pad_final, dim3(1), dim3(256), 0, st, pad_partial, C, w.nchunk_pad,
                        dV + ((size_t)2 * BT + pmax) * C);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                                float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dpre || BT <= 0 || C <= 0) return -CHAM_ERR_ARG;
+    return combine_bwd_impl<float>(dpre, dpre + (size_t)BT * C, C, BT, N, pmax, neg_slot, dU, dV, workspace, workspace_bytes, stream);
+}
+// bf16 configuration: clicked-input rows fp32 [BT, C], candidate rows bf16 [BT*(1+N), C]
+extern "C" int cham_combine_bwd_b16(const float* dpre_in, const void* dpre_cand, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                                    float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
+    return combine_bwd_impl<__bf16>(dpre_in, reinterpret_cast<const __bf16*>(dpre_cand), C, BT, N, pmax, neg_slot, dU, dV, workspace,
+                                    workspace_bytes, stream);
+}
 
 extern "C" int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre,
                                 void* stream) {
     if (!dM || !Z2c || !pred || !dpred_pre || (C & 3) || BT <= 0) return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_mulpred_bwd, dim3(BT), dim3(256), 0, (hipStream_t)stream, dM, Z2c, pred, C, N, dpred_pre);
+    hipLaunchKernelGGL(k_mulpred_bwd<float>, dim3(BT), dim3(256), 0, (hipStream_t)stream, dM, Z2c, pred, C, N, dpred_pre);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" int cham_mulpred_bwd_b16(void* dM, const void* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream) {
+    if (!dM || !Z2c || !pred || !dpred_pre || (C & 3) || BT <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_mulpred_bwd<__bf16>, dim3(BT), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<__bf16*>(dM),
+                       reinterpret_cast<const __bf16*>(Z2c), pred, C, N, dpred_pre);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" int cham_mul_rows_b16(const void* Z2c, const float* pred, int C, int BT, int NC, void* Mc, void* stream) {
+    if (!Z2c || !pred || !Mc || (C & 3) || BT <= 0 || NC <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_mul_rows_b16, dim3(BT), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(Z2c), pred, C, NC,
+                       reinterpret_cast<__bf16*>(Mc));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
 
-extern "C" int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
-                                      const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
-                                      const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream) {
+template <typename T>
+static int score_softmax_fwd_impl(const T* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                                  const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                                  const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream) {
     if (!S3 || !w4 || !b4 || !mask || !logits || !probs || !nll || K3 != 32 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
     if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !nov_aux)) return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_score_softmax_fwd<32>, dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S3, w4, b4, BT, N,
+    hipLaunchKernelGGL((k_score_softmax_fwd<32, T>), dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S3, w4, b4, BT, N,
                        1.0f / tau, mask, logits, probs, nll, novelty_reg_factor, neg_ids, pop_norm, nov_aux);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+extern "C" int cham_score_softmax_fwd(const float* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                                      const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                                      const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream) {
+    return score_softmax_fwd_impl<float>(S3, K3, w4, b4, BT, N, tau, mask, logits, probs, nll, novelty_reg_factor, neg_ids, pop_norm,
+                                         nov_aux, stream);
+}
+extern "C" int cham_score_softmax_fwd_b16(const void* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                                          const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                                          const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream) {
+    return score_softmax_fwd_impl<__bf16>(reinterpret_cast<const __bf16*>(S3), K3, w4, b4, BT, N, tau, mask, logits, probs, nll,
+                                          novelty_reg_factor, neg_ids, pop_norm, nov_aux, stream);
+}
 
-extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
-                                      int BT, int N, float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor,
-                                      const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
-                                      void* stream) {
+template <typename T>
+static int score_softmax_bwd_impl(const T* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                  int BT, int N, float tau, float sum_mask, float* ds, T* dS3, float novelty_reg_factor,
+                                  const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                  void* stream) {
     if (!S3 || !w4 || !probs || !mask || !ds || !dS3 || K3 != 32 || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
     if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !logits || !nov_aux)) return -CHAM_ERR_ARG;
     const size_t rows = (size_t)BT * (N + 1);
-    hipLaunchKernelGGL(k_score_softmax_bwd<32>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
+    hipLaunchKernelGGL((k_score_softmax_bwd<32, T>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
                        probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3, novelty_reg_factor, neg_ids, pop_norm, logits,
                        1.0f / tau, nov_aux);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                      int BT, int N, float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor,
+                                      const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                      void* stream) {
+    return score_softmax_bwd_impl<float>(S3, K3, w4, probs, mask, BT, N, tau, sum_mask, ds, dS3, novelty_reg_factor, neg_ids, pop_norm,
+                                         logits, nov_aux, stream);
+}
+extern "C" int cham_score_softmax_bwd_b16(const void* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                          int BT, int N, float tau, float sum_mask, float* ds, void* dS3, float novelty_reg_factor,
+                                          const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                          void* stream) {
+    return score_softmax_bwd_impl<__bf16>(reinterpret_cast<const __bf16*>(S3), K3, w4, probs, mask, BT, N, tau, sum_mask, ds,
+                                          reinterpret_cast<__bf16*>(dS3), novelty_reg_factor, neg_ids, pop_norm, logits, nov_aux, stream);
 }
 
 extern "C" int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t* neg_ids, const uint8_t* mask, int BT,

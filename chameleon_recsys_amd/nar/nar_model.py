@@ -155,6 +155,17 @@ class NARRuntime:
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
+        # bf16 configuration: bf16 shadows (plain + transposed) of the weights whose GEMMs run over the candidate rows, refreshed
+        # whenever the fp32 master copy changed (csrc/gemm_b16.hip wants both operands k-contiguous: W^T forward, W dgrad)
+        self.b16 = self.gemm_dtype == 'bf16'
+        self.shadow, self._shadow_key, self.weights_version = {}, None, 0
+        if self.b16:
+            if L.C % 128:
+                raise ValueError("gemm_dtype='bf16' needs CAR_embedding_size % 128 == 0")
+            for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
+                r, c = L.entries[name].shape
+                self.shadow[name] = torch.zeros(r, c, dtype=torch.bfloat16, device=dev)
+                self.shadow[name + 'T'] = torch.zeros(c, r, dtype=torch.bfloat16, device=dev)
         self._plans = {}
         self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
         self.plan_bytes_budget = 128 << 30        # of the 288 GB: activations of the cached shapes
@@ -181,6 +192,18 @@ class NARRuntime:
 
     def load_logical_weights(self, logical):
         self.flat.copy_(torch.from_numpy(self.layout.pack(logical)))
+        self.weights_version += 1
+
+    def refresh_shadows(self):
+        """bf16 shadows of the candidate-row GEMM weights, once per weight version (one small launch per weight)."""
+        key = (self.global_step, self.weights_version)
+        if not self.b16 or key == self._shadow_key:
+            return
+        for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
+            r, c = self.layout.entries[name].shape
+            check(self.lib.cham_cast_b16(ptr(self.p(name)), r, c, ptr(self.shadow[name]), ptr(self.shadow[name + 'T']), _stream()),
+                  "cham_cast_b16")
+        self._shadow_key = key
 
     def state_dict(self):
         return {'flat': self.flat.cpu(), 'm': self.m.cpu(), 'v': self.v.cpu(), 'global_step': self.global_step}
@@ -188,6 +211,7 @@ class NARRuntime:
     def load_state_dict(self, sd):
         self.flat.copy_(sd['flat']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.global_step = int(sd['global_step'])
+        self.weights_version += 1
 
     def plan(self, B, T, N, n_buf, Bg=None):
         """Buffers for one batch shape, cached: ragged hourly files produce a handful of padded lengths T.  Least-recently-used
@@ -233,6 +257,34 @@ class NARRuntime:
         self.lib.cham_gemm_launch_counts(out, 0)
         return list(out)
 
+    def gemm_b16(self, A, lda, transA, B, ldb, transB, C, ldc, out_f32, M, N, K, bias=None, act=ACT_NONE, dref=None, ldr=0,
+                 dact=ACT_NONE, accumulate=0, splits=1):
+        """bf16-resident GEMM (csrc/gemm_b16.hip): NT (transA=0, transB=1) or TN (transA=1, transB=0)."""
+        ws = None
+        if splits != 1:
+            ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0 = self._tile_counts_b16()
+            e0.record()
+        check(self.lib.cham_gemm_b16(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, out_f32, M, N, K, ptr(bias), act, ptr(dref),
+                                     ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()),
+              "cham_gemm_b16")
+        if prof is not None:
+            e1.record()
+            c1 = self._tile_counts_b16()
+            tile = next((i for i in range(5) if c1[i] != c0[i]), -1)
+            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c1[7]), act=act, dref=dref is not None, dact=dact,
+                             bias=bias is not None, rowscale=False, bf16=True, b16=True, out_f32=int(c1[5]), tile=tile, epi=int(c1[6]),
+                             ev=(e0, e1)))
+
+    def _tile_counts_b16(self):
+        import ctypes
+        out = (ctypes.c_longlong * 8)()
+        self.lib.cham_gemm_b16_launch_counts(out, 0)
+        return list(out)
+
     def gemm_mulpred_bwd(self, dS1, Ws1, dZ2c, Z2c, pred, dpred, Rc, C, K, NC):
         """Scorer layer-1 dgrad fused with the backward of `cand (.) pred` and the CAR tanh (csrc/gemm.hip mulpred_epilogue).
         Returns False when the fused instance does not apply (bf16 mode, workspace too small) - the caller runs the two-pass form."""
@@ -251,10 +303,10 @@ class NARRuntime:
             prof.append(dict(M=Rc, N=C, K=K, transA=0, transB=1, splits=1, act=0, dref=True, ev=(e0, e1)))
         return True
 
-    def colsum(self, X, ld, R, F, out, w=None, accumulate=0):
+    def colsum(self, X, ld, R, F, out, w=None, accumulate=0, b16=False):
         ws = self.colsum_ws_side if torch.cuda.current_stream() == self.side_stream else self.colsum_ws
-        check(self.lib.cham_colsum(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws), ws.numel() * 4, _stream()),
-              "cham_colsum")
+        check((self.lib.cham_colsum_b16 if b16 else self.lib.cham_colsum)(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws),
+                                                                           ws.numel() * 4, _stream()), "cham_colsum")
 
     def side(self):
         """Context manager: run the enclosed launches on the side stream (or inline when overlap is disabled)."""
@@ -277,7 +329,7 @@ class StepPlan:
     def estimate_bytes(L, B, T, N):
         """Dominant buffers only: Z1, Z2, dZ1, dZ2 over all CAR rows + the scorer activations over the candidate rows."""
         rows = B * T * (N + 2)
-        return 4 * (4 * rows * L.C + 2 * rows * (128 + 64 + 32))
+        return 4 * (4 * rows * L.C + 2 * rows * (128 + 64 + 32))        # (the bf16 configuration needs ~5/8 of this)
 
     def __init__(self, rt, B, T, N, n_buf, Bg):
         L, dev = rt.layout, rt.device
@@ -319,10 +371,17 @@ class StepPlan:
         # CAR
         self.U, self.dU = f32(BT, C), f32(BT, C)
         self.V, self.dV = f32(RV, C), f32(RV, C)
-        self.Z1 = f32(Rall, C)
-        self.Z2 = f32(Rall, C)
-        self.dZ2 = f32(Rall, C)
-        self.dZ1 = f32(Rall, C)
+        b16 = rt.b16
+        bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        cand = bf if b16 else f32                 # storage of the matrices with one row per candidate
+        if b16:       # clicked-input rows stay fp32 (they feed / come from the fp32 recurrent branch); candidate rows are bf16
+            self.Z1, self.Z2, self.dZ2, self.dZ1 = f32(BT, C), f32(BT, C), f32(BT, C), f32(BT, C)
+            self.Z1c, self.Z2c, self.dZ2c, self.dZ1c, self.Mc = bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C)
+        else:         # one [BT + Rc, C] matrix each: clicked-input rows first (Z1c ... are views taken per step: BT = valid positions)
+            self.Z1 = f32(Rall, C)
+            self.Z2 = f32(Rall, C)
+            self.dZ2 = f32(Rall, C)
+            self.dZ1 = f32(Rall, C)
         # RNN
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
         NG = L.NG
@@ -344,9 +403,9 @@ class StepPlan:
         # FCs / scorer
         self.FC1, self.dFC1 = f32(BT, 512), f32(BT, 512)
         self.pred, self.dpred = f32(BT, C), f32(BT, C)
-        self.S1, self.dS1 = f32(Rc, 128), f32(Rc, 128)
-        self.S2, self.dS2 = f32(Rc, 64), f32(Rc, 64)
-        self.S3, self.dS3 = f32(Rc, 32), f32(Rc, 32)
+        self.S1, self.dS1 = cand(Rc, 128), cand(Rc, 128)
+        self.S2, self.dS2 = cand(Rc, 64), cand(Rc, 64)
+        self.S3, self.dS3 = cand(Rc, 32), cand(Rc, 32)
         self.ds = f32(Rc)
         self.logits, self.probs = f32(BT, NC), f32(BT, NC)
         self.nll = f32(BT)
@@ -637,6 +696,7 @@ class NARModuleModel:
                                      ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
                                      ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
               "cham_item_assemble")
+        rt.refresh_shadows()
         # factorised PreCAR: U (per click) + V (per unique item row), then CAR
         rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
         rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
@@ -671,17 +731,30 @@ class NARModuleModel:
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
             rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
         # ... the candidate rows: PreCAR combine (HBM-bound) + the dominant GEMM, CAR layer 2 on the B*T*(1+N) rows
-        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
-        rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
-        rt.join()
-        # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
-        Z2c = pl.Z2[BT:Rall]
-        rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
-        rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
-        rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
-        check(lib.cham_score_softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
-                                         ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
-                                         ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
+        if rt.b16:
+            # bf16 configuration: candidate-row matrices are bf16 in HBM, weights through their bf16 shadows (csrc/gemm_b16.hip)
+            sh = rt.shadow
+            check(lib.cham_combine_fwd_b16(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1c), s), "cham_combine_fwd_b16")
+            rt.gemm_b16(pl.Z1c, C, 0, sh['W2T'], C, 1, pl.Z2c, C, 0, Rc, C, C, bias=p('b2'), act=ACT_TANH)
+            rt.join()
+            check(lib.cham_mul_rows_b16(ptr(pl.Z2c), ptr(pl.pred), C, BT, NC, ptr(pl.Mc), s), "cham_mul_rows_b16")
+            rt.gemm_b16(pl.Mc, C, 0, sh['Ws1T'], C, 1, pl.S1, 128, 0, Rc, 128, C, bias=p('bs1'), act=ACT_LEAKY)
+            rt.gemm_b16(pl.S1, 128, 0, sh['Ws2T'], 128, 1, pl.S2, 64, 0, Rc, 64, 128, bias=p('bs2'), act=ACT_LEAKY)
+            rt.gemm_b16(pl.S2, 64, 0, sh['Ws3T'], 64, 1, pl.S3, 32, 0, Rc, 32, 64, bias=p('bs3'), act=ACT_LEAKY)
+            softmax_fwd = lib.cham_score_softmax_fwd_b16
+        else:
+            check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
+            rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+            rt.join()
+            # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
+            Z2c = pl.Z2[BT:Rall]
+            rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
+            rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
+            rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
+            softmax_fwd = lib.cham_score_softmax_fwd
+        check(softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
+                          ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
+                          ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
@@ -708,7 +781,9 @@ class NARModuleModel:
         cell, NGH = (1 if L.cell == 'gru' else 0), L.NG * L.Hp
         p, g = rt.p, rt.g
         main_stream, on = torch.cuda.current_stream(), rt.overlap
-        swap = on and rt.tail_on_side
+        b16 = rt.b16
+        sh = rt.shadow
+        swap = on and rt.tail_on_side and not b16
 
         def mark():                      # event on the current stream
             if not on:
@@ -734,44 +809,60 @@ class NARModuleModel:
 
         rt.grads[:L.emb_end].zero_()
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
-        check(lib.cham_score_softmax_bwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N,
-                                         float(self.softmax_temperature), d['sum_mask'], ptr(pl.ds), ptr(pl.dS3),
-                                         self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']),
-                                         ptr(pl.logits), ptr(pl.nov_aux), s),
-              "cham_score_softmax_bwd")
+        check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
+            ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), d['sum_mask'],
+            ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
+            ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
         if self._dev_state.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
         # matrix work that then runs beside the HBM-bound k_mulpred_bwd instead of beside the MFMA-bound CAR dgrad - and the small
         # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it
-        rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
-        rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
-        Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
+        if b16:
+            rt.gemm_b16(pl.dS3, 32, 0, sh['Ws3'], 32, 1, pl.dS2, 64, 0, Rc, 64, 32, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
+            rt.gemm_b16(pl.dS2, 64, 0, sh['Ws2'], 64, 1, pl.dS1, 128, 0, Rc, 128, 64, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+            Z2c, dZ2c = pl.Z2c[:Rc], pl.dZ2c[:Rc]
+        else:
+            rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
+            rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+            Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
-        fused = (not (on and rt.split_mulpred and BT >= 256)) and \
+        fused = (not b16) and (not (on and rt.split_mulpred and BT >= 256)) and \
             rt.gemm_mulpred_bwd(pl.dS1, p('Ws1'), dZ2c, Z2c, pl.pred, pl.dpred, Rc, C, 128, NC)
-        if not fused:
+        if b16:
+            rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
+        elif not fused:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         with side(e_start, e_dS1):
-            rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
-            rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
-            rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
-            rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
-            rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
-            rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
-            rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
+            if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
+                rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
+                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
+                rt.gemm_b16(pl.S1, 128, 1, pl.dS2, 64, 0, g('Ws2'), 64, 1, 128, 64, Rc, splits=0)
+                rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'), b16=True)
+                rt.gemm_b16(pl.S2, 64, 1, pl.dS3, 32, 0, g('Ws3'), 32, 1, 64, 32, Rc, splits=0)
+                rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'), b16=True)
+                rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds, b16=True)
+            else:
+                rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
+                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
+                rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
+                rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
+                rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
+                rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
+                rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
             rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
         # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
         # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
         # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
-        half = BT // 2 if (on and rt.split_mulpred and BT >= 256) else BT
+        half = BT // 2 if (on and rt.split_mulpred and BT >= 256 and not b16) else BT
         if fused:
             half = BT
 
         def mulpred(g0, g1):
-            check(lib.cham_mulpred_bwd(ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N,
-                                       ptr(pl.dpred[g0:g1]), _stream()), "cham_mulpred_bwd")
+            check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(
+                ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N, ptr(pl.dpred[g0:g1]),
+                _stream()), "cham_mulpred_bwd")
         if not fused:
             mulpred(0, half)
         e_halfB = None
@@ -825,7 +916,13 @@ class NARModuleModel:
                     # 256 workgroups fill every CU's register file for 4 ms) - the main lane's PreCAR backward waits for it ...
                     rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
                     e_dZ1in = mark()
-                    if not swap:
+                    if b16:
+                        # ... and the CAR layer-2 weight gradient: the candidate rows (bf16, TN) + the clicked-input rows (fp32), runs beside it
+                        rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0)
+                        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
+                        rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
+                        rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
+                    elif not swap:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
                         rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
@@ -843,8 +940,10 @@ class NARModuleModel:
         # slower inside the step; profiles/r01_notes.md item 10)
         if rt.dgrad_nn:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
+        if b16:
+            rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY)
         for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
-            if r1 <= r0:
+            if r1 <= r0 or b16:
                 continue
             if ev is not None:
                 main_wait(ev)
@@ -855,8 +954,12 @@ class NARModuleModel:
         def precar_backward(ws):
             """PreCAR combine scatter, W1 weight gradients, feature / embedding backward (on whatever lane is current)."""
             st = _stream()
-            check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
-                  "cham_combine_bwd")
+            if b16:
+                check(lib.cham_combine_bwd_b16(ptr(pl.dZ1), ptr(pl.dZ1c), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws),
+                                               ws.numel() * 4, st), "cham_combine_bwd_b16")
+            else:
+                check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
+                      "cham_combine_bwd")
             rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
             rt.colsum(pl.dU, C, BT, C, g('b1'))
             rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
@@ -897,7 +1000,7 @@ class NARModuleModel:
     def apply_gradients(self):
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
         rt, L = self.rt, self.rt.layout
-        rt.global_step += 1
+        rt.global_step += 1           # (also invalidates the bf16 weight shadows: NARRuntime.refresh_shadows keys on it)
         t = rt.global_step
         lr_t = self.lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
 

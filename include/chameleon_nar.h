@@ -124,6 +124,28 @@ size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pmax);
 int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
                      float* workspace, size_t workspace_bytes, void* stream);
 
+/* --- bf16 configuration (BASELINE configs[2]): the matrices with one row per candidate are bf16 in HBM.  Twins of the entry points
+ * above / below that read or write such matrices (same arithmetic in fp32 registers; only the storage type differs), plus the
+ * two helpers the configuration adds:
+ *   cham_mul_rows_b16: Mc[row] = bf16(Z2c[row] * pred[row / NC]) - the `cand (.) pred` product of nar_model.py:478-495 as a bf16 GEMM
+ *     operand (the fp32 path fuses it into the GEMM staging as a row scale);
+ *   cham_cast_b16: bf16 shadow of an fp32 weight [R, Cc]: dst = bf16(W) and / or dstT = bf16(W)^T (either may be NULL). */
+int cham_combine_fwd_b16(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1c,
+                         void* stream);
+int cham_combine_bwd_b16(const float* dpre_in, const void* dpre_cand, int C, int BT, int N, int pmax, const int32_t* neg_slot,
+                         float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream);
+int cham_mulpred_bwd_b16(void* dM, const void* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream);
+int cham_mul_rows_b16(const void* Z2c, const float* pred, int C, int BT, int NC, void* Mc, void* stream);
+int cham_score_softmax_fwd_b16(const void* S3, int K3, const float* w4, const float* b4, int BT, int N, float tau,
+                               const uint8_t* mask, float* logits, float* probs, float* nll, float novelty_reg_factor,
+                               const int64_t* neg_ids, const float* pop_norm, float* nov_aux, void* stream);
+int cham_score_softmax_bwd_b16(const void* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N,
+                               float tau, float sum_mask, float* ds, void* dS3, float novelty_reg_factor, const int64_t* neg_ids,
+                               const float* pop_norm, const float* logits, const float* nov_aux, void* stream);
+int cham_colsum_b16(const void* X, int ld, int R, int F, const float* w, float* out, int accumulate, float* workspace,
+                    size_t workspace_bytes, void* stream);
+int cham_cast_b16(const float* W, int R, int Cc, void* dst, void* dstT, void* stream);
+
 /* --- K3 recurrent cell time steps: nar_model.py:1308-1361.
  * cell_kind 0 = UGRNN (tf.contrib.rnn.UGRNNCell, the reference's cell, :1317): xproj [B,T,2Hp] = x W_x + b (gate | candidate),
  *   Wh [Hp,2Hp]; saves hprev, G (gate), Cc (candidate); R / RH unused (NULL).

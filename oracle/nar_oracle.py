@@ -44,6 +44,19 @@ class _BF16MatMul(torch.autograd.Function):
         return ga, a2.t() @ gb.reshape(-1, g.shape[-1])
 
 
+class _StoreBF16(torch.autograd.Function):
+    """Value stored as bf16 in HBM (round to nearest even), gradient passed through: the bf16 configuration keeps the matrices with
+    one row per candidate (PreCAR / CAR / scorer activations) in bf16 (csrc/gemm_b16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def _leaky(x):
     return torch.nn.functional.leaky_relu(x, 0.2)   # tf.nn.leaky_relu default alpha=0.2
 
@@ -269,11 +282,16 @@ class NAROracle:
             feats.append(self._novelty(ids, buffer_ids, pop_norm))
         return torch.cat(feats, dim=-1)
 
-    def _car(self, x):
+    def _store(self, x):
+        """Candidate-row matrices are bf16-resident in the bf16 configuration; identity otherwise."""
+        return _StoreBF16.apply(x) if self.gemm_dtype == 'bf16' else x
+
+    def _car(self, x, candidate_rows=False):
         w = self.w
         pre = _leaky(self._mm(x, w['PreCAR/kernel']) + w['PreCAR/bias'])        # nar_model.py:375-382
         self._tap('Z1', pre)
-        return torch.tanh(self._mm(pre, w['CAR/kernel']) + w['CAR/bias'])       # :384-403
+        out = torch.tanh(self._mm(pre, w['CAR/kernel']) + w['CAR/bias'])        # :384-403
+        return self._store(out) if candidate_rows else out
 
     # -- nar_model.py:1308-1361 (UGRNNCell / GRUCell semantics: SURVEY A.6)
     def _rnn(self, x, lengths):
@@ -319,7 +337,7 @@ class NAROracle:
         w = self.w
         s1 = _leaky(self._mm(m, w['match1/kernel']) + w['match1/bias'])
         s2 = _leaky(self._mm(s1, w['match2/kernel']) + w['match2/bias'])
-        s3 = _leaky(self._mm(s2, w['match3/kernel']) + w['match3/bias'])
+        s3 = self._store(_leaky(self._mm(s2, w['match3/kernel']) + w['match3/bias']))
         self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
         return s3 @ w['match4/kernel'] + w['match4/bias']       # last layer: fused into the softmax kernel, fp32 in every mode
 
@@ -392,7 +410,7 @@ class NAROracle:
             ctx_tiled = ctx.unsqueeze(2).expand(B, T, neg.shape[2], ctx.shape[-1])                                     # :360
             x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364
         with self._stage('CAR'):
-            car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos), self._car(x_neg)                             # :374-405
+            car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos, True), self._car(x_neg, True)                 # :374-405
         with self._stage('RNN'):
             rnn_out = self._rnn(car_in, seq_len)                                                                      # :408
         with self._stage('scorer'):
