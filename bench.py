@@ -343,6 +343,8 @@ def main():
         if r['tile'] < 0:
             continue
         e = by_sym.setdefault(gemm_symbol(r), dict(n=0, ms=0.0, flop=0.0, bytes=0.0, r=r))
+        if r['M'] * r['N'] * r['K'] > e['r']['M'] * e['r']['N'] * e['r']['K']:
+            e['r'] = r
         e['n'] += 1
         e['ms'] += r['ev'][0].elapsed_time(r['ev'][1])
         e['flop'] += 2.0 * r['M'] * r['N'] * r['K']
@@ -359,7 +361,8 @@ def main():
 
     def describe(sym, e):
         r = e['r']
-        mode = "NN" if not r['transA'] and not r['transB'] else ("NT (dgrad)" if r['transB'] else "TN (wgrad)")
+        mode = "NN" if not r['transA'] and not r['transB'] else ("TN (wgrad)" if r['transA'] else
+                                                                 ("NT (dgrad)" if r['dref'] or not r['bias'] else "NT (forward, transposed weight shadow)"))
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
             sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else "fp32", mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])

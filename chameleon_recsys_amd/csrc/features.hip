@@ -236,11 +236,16 @@ __global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ 
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < R) perm[rank[r]] = r;
 }
-__global__ __launch_bounds__(256) void k_emb_grad_grouped(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+// NTH = 64: segments of <= 32 rows (almost all: one wave, lanes over the columns, rows in order, 4 loads in flight);
+// NTH = 1024: longer segments (popular articles sit in hundreds to thousands of a batch's rows): 16 waves = (16 / column blocks)
+// row stripes x column blocks of 64, stripe s takes rows s, s + S, ... in order, the stripe sums are added in stripe order.
+// Both are launched over all R sorted positions; a workgroup that is not the head of a segment of its length class exits.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_emb_grad_grouped(const float* __restrict__ dxs, int R, int F, int c0, int dim,
                                                           const float* __restrict__ gamma, const int64_t* __restrict__ ids,
                                                           const int* __restrict__ perm, float* __restrict__ table_grad) {
-    __shared__ int rows[1024];
-    __shared__ float part[4][64];
+    constexpr int NW = NTH / 64;
+    __shared__ float part[NW][64];
     const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t id = ids[perm[i]];
     if (i > 0 && ids[perm[i - 1]] == id) return;          // not the head of its segment
@@ -251,41 +256,50 @@ __global__ __launch_bounds__(256) void k_emb_grad_grouped(const float* __restric
         const unsigned long long m = __ballot(same);
         const int run = (m == ~0ull) ? 64 : __ffsll((long long)~m) - 1;
         len += run;
-        if (run < 64) break;
+        if (run < 64 || NTH == 64) break;                 // (the one-wave launch only needs to know whether len <= 32)
     }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};                  // column blocks of 64 (dim <= 256)
-    for (int base = 0; base < len; base += 1024) {
-        const int n = min(1024, len - base);
-        __syncthreads();
-        for (int q = threadIdx.x; q < n; q += 256) rows[q] = perm[i + base + q];
-        __syncthreads();
-#pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-            const int sub = sb * 64 + lane;
-            if (sb * 64 >= dim) break;
+    if ((NTH == 64) != (len <= 32)) return;               // the other launch's length class
+    const int* rows = perm + i;
+    const int ncb = (dim + 63) / 64;                      // column blocks of 64 (dim <= 256)
+    if (NTH == 64) {
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int sub = cb * 64 + lane;
             const bool cok = sub < dim;
-            float a = acc[sb];
-            int m = w;
-            for (; m + 12 < n; m += 16) {
+            float a = 0.f;
+            int m = 0;
+            for (; m + 4 <= len; m += 4) {
                 float x[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + 4 * u] * F + c0 + sub] : 0.f;
+                for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + u] * F + c0 + sub] : 0.f;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a += x[u];
             }
-            for (; m < n; m += 4) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
-            acc[sb] = a;
+            for (; m < len; ++m) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
+            if (cok) table_grad[(size_t)id * dim + sub] = a * gamma[c0 + sub];
         }
+        return;
     }
+    const int ncb2 = ncb <= 1 ? 1 : (ncb <= 2 ? 2 : 4), S = NW / ncb2;      // wave w = stripe * ncb2 + column block
+    const int cb = w % ncb2, stripe = w / ncb2;
+    const int sub = cb * 64 + lane;
+    const bool cok = cb < ncb && sub < dim;
+    float a = 0.f;
+    int m = stripe;
+    for (; m + 3 * S < len; m += 4 * S) {
+        float x[4];
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
-        if (sb * 64 >= dim) break;
-        const int sub = sb * 64 + lane;
-        __syncthreads();
-        part[w][lane] = acc[sb];
-        __syncthreads();
-        if (w == 0 && sub < dim)
-            table_grad[(size_t)id * dim + sub] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) * gamma[c0 + sub];
+        for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + u * S] * F + c0 + sub] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += x[u];
+    }
+    for (; m < len; m += S) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
+    part[w][lane] = a;
+    __syncthreads();
+    if (w < ncb) {                                        // wave w finishes column block w: stripe sums in stripe order
+        const int sub2 = w * 64 + lane;
+        float t = 0.f;
+        for (int s2 = 0; s2 < S; ++s2) t += part[s2 * ncb2 + w][lane];
+        if (sub2 < dim) table_grad[(size_t)id * dim + sub2] = t * gamma[c0 + sub2];
     }
 }
 
@@ -427,8 +441,75 @@ extern "C" int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int
                                      const int32_t* perm, float* table_grad, void* stream) {
     if (!dxs || !gamma || !ids || !perm || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 256 || c0 + dim > F)
         return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_emb_grad_grouped, dim3(R), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm,
-                       table_grad);
+    hipLaunchKernelGGL(k_emb_grad_grouped<64>, dim3(R), dim3(64), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, table_grad);
+    hipLaunchKernelGGL(k_emb_grad_grouped<1024>, dim3(R), dim3(1024), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, table_grad);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dropout (keep_prob < 1: nar_model.py:338, 352, 368 on the three feature tensors, :418 on FC1, :1331 DropoutWrapper on every
+// recurrent layer's output).  tf.nn.dropout of TF 1.12: y = x / keep_prob * mask.  TF's own random streams are not reproducible
+// without TF; the mask is defined by the same counter-based generator as the negative sampler (common.h philox_rand32, contract:
+// oracle/philox.py): element (session row b [GLOBAL], time step t, column c, site, negative n) is kept iff
+//     Philox4x32-10(ctr = (c, t, b, site + 256 n), key = (seed, step))[0] < floor(keep_prob * 2^32)
+// - a pure function of the element's coordinates, so it is independent of row shards, valid-position compaction and padding, and
+// the backward pass recomputes it instead of storing it.
+//   row r of the matrix -> (position index r / group, sub = r % group); sub 0 uses site_first (n = 0), sub > 0 site_rest (n = sub - 1);
+//   position index -> (b, t) through pos[] (compacted layouts) or directly ([B, T] layouts); column c -> logical feature column
+//   c < col_split ? c : c - col_shift (the item columns of the padded [ctx | item] layout).
+__global__ __launch_bounds__(256) void k_dropout(const float* __restrict__ x, float* __restrict__ y, size_t rows, int cols, int ld,
+                                                 float keep, uint32_t thr, uint32_t seed, uint32_t step, int site_first, int site_rest,
+                                                 int group, const int* __restrict__ pos, int T, int row_begin, int col_split, int col_shift) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (size_t)cols) return;
+    const size_t r = i / cols;
+    const int c = (int)(i % cols);
+    const size_t pi = r / group;
+    const int sub = (int)(r % group);
+    const int q = pos ? pos[pi] : (int)pi;
+    const uint32_t b = (uint32_t)(row_begin + q / T), t = (uint32_t)(q % T);
+    const uint32_t site = (uint32_t)(sub == 0 ? site_first : site_rest) + 256u * (uint32_t)(sub == 0 ? 0 : sub - 1);
+    const uint32_t cl = (uint32_t)(c < col_split ? c : c - col_shift);
+    const bool kept = philox_rand32(cl, t, b, site, seed, step) < thr;
+    const float v = x[r * ld + c];
+    y[r * ld + c] = kept ? v / keep : 0.f;
+}
+extern "C" int cham_dropout(const float* x, float* y, long rows, int cols, int ld, float keep_prob, uint32_t seed, uint32_t step,
+                            int site_first, int site_rest, int group, const int32_t* pos, int T, int row_begin, int col_split,
+                            int col_shift, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ld < cols || group <= 0 || T <= 0 || !(keep_prob > 0.f) || keep_prob >= 1.f) return -CHAM_ERR_ARG;
+    const uint32_t thr = (uint32_t)((double)keep_prob * 4294967296.0);
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)rows, cols, ld,
+                       keep_prob, thr, seed, step, site_first, site_rest, group, pos, T, row_begin, col_split, col_shift);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// Dense (un-factorised) PreCAR input rows for the dropout path: X[row] = [Xc_s[position] | Xi_s[item row of the CAR row]], rows in the
+// CAR row order (BT clicked inputs, then BT*(1+N) candidates).  With a per-element mask the rows are occurrence-specific, so the
+// de-duplication / factorisation of the default path (scorer.hip) does not apply.
+__global__ __launch_bounds__(256) void k_dense_rows(const float* __restrict__ Xc, int Fc, const float* __restrict__ Xi, int Fi, int BT, int N,
+                                                    int pmax, const int* __restrict__ neg_slot, float* __restrict__ X) {
+    const int row = blockIdx.x, Fw = Fc + Fi;
+    int u, v;
+    if (row < BT) { u = row; v = row; }
+    else {
+        const int i = row - BT, bt = i / (N + 1), c = i % (N + 1);
+        u = bt;
+        if (c == 0) v = BT + bt;
+        else { int s = neg_slot[(size_t)bt * N + (c - 1)]; if (s < 0) s = pmax; v = 2 * BT + s; }
+    }
+    float* o = X + (size_t)row * Fw;
+    for (int k = threadIdx.x; k < Fc / 4; k += 256) reinterpret_cast<float4*>(o)[k] = reinterpret_cast<const float4*>(Xc + (size_t)u * Fc)[k];
+    for (int k = threadIdx.x; k < Fi / 4; k += 256) reinterpret_cast<float4*>(o + Fc)[k] = reinterpret_cast<const float4*>(Xi + (size_t)v * Fi)[k];
+}
+extern "C" int cham_dense_rows(const float* Xc_s, int Fc, const float* Xi_s, int Fi, int BT, int N, int pmax, const int32_t* neg_slot,
+                               float* X, void* stream) {
+    if (!Xc_s || !Xi_s || !neg_slot || !X || (Fc & 3) || (Fi & 3) || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_dense_rows, dim3((unsigned)(BT + BT * (N + 1))), dim3(256), 0, (hipStream_t)stream, Xc_s, Fc, Xi_s, Fi, BT, N, pmax,
+                       neg_slot, X);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -358,6 +358,9 @@ static int b16_by_shape(B16Params& p, int act, int dact, int out_f32, hipStream_
         // 256x128 while the grid still covers the 256 CUs; g_b16_variant: 0 = 128x128, 1 = 256x128 / 8 waves (64x64 per wave),
         // 2 = 256x128 / 4 waves (128x64 per wave: half the LDS fragment bytes per MFMA)
         int v = ((long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splits >= 256) ? 1 : 0;
+        // TN (split-K partial epilogue: 208 VGPRs, two workgroups per CU) is faster on the 4-wave 128x64-per-wave instance (W2 wgrad
+        // 785 vs 707 TFLOP/s stand-alone); the NT epilogues push that instance past 256 VGPRs and it loses (425 vs 653)
+        if (v == 1 && !AK && p.splits > 1) v = 2;
         if (g_b16_variant >= 0) v = g_b16_variant;
         ++g_b16_launches[v];
         if (v == 1) return b16_launch_cfg<256, 128, 4, 2, AK, BKC>(p, act, dact, out_f32, st);

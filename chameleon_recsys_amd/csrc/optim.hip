@@ -70,7 +70,15 @@ __global__ __launch_bounds__(256) void k_colsum_vec(const T* __restrict__ X, int
     const int c4 = threadIdx.x % nf4, rl = threadIdx.x / nf4;
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0 + rl; r < r1; r += rpi) {
+    int r = r0 + rl;
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {            // 4 independent row loads in flight (a lane's loads are otherwise a latency chain)
+        float4 x[4]; float ww[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x[u] = ld4(X + (size_t)(r + u * rpi) * ld + c4 * 4); ww[u] = w ? w[r + u * rpi] : 1.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += ww[u] * x[u].x; acc.y += ww[u] * x[u].y; acc.z += ww[u] * x[u].z; acc.w += ww[u] * x[u].w; }
+    }
+    for (; r < r1; r += rpi) {
         const float4 x = ld4(X + (size_t)r * ld + c4 * 4);
         const float ww = w ? w[r] : 1.f;
         acc.x += ww * x.x; acc.y += ww * x.y; acc.z += ww * x.z; acc.w += ww * x.w;

@@ -419,6 +419,19 @@ class StepPlan:
         self.Z2f, self.rnn_c, self.drnn_c, self.dxproj_c = f32(BT, C), f32(BT, Hp), f32(BT, Hp), f32(BT, NG * Hp)
         self.pos, self.P = None, BT
 
+    def dropout_buffers(self, rt):
+        """Buffers of the dropout path (keep_prob < 1: dense PreCAR input rows, dropped FC1 / recurrent outputs) - allocated on first use."""
+        if getattr(self, 'Xd', None) is None:
+            L, dev = rt.layout, rt.device
+            f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            Fw = L.Fc + L.Fi
+            self.Xd, self.dXd = f32(self.Rall, Fw), f32(self.Rall, Fw)
+            self.dUx, self.dVx = f32(self.BT, Fw), f32(self.RV, Fw)
+            self.FC1d = f32(self.BT, 512)
+            self.rnn_drop = [f32(self.BT, L.Hp) for _ in range(L.L)]
+            need = rt.lib.cham_combine_bwd_workspace_bytes(Fw, self.B * self.T, self.N, self.pmax)
+            self.drop_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+
     def use_sampler_set(self, k):
         self._samp_cur = k
         for name, t in self._samp[k].items():
@@ -453,9 +466,10 @@ class NARModuleModel:
             raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
         self.novelty_reg_factor = float(novelty_reg_factor)
         self.is_training = (mode == ModeKeys.TRAIN)
-        if self.is_training and keep_prob != 1.0:
-            raise NotImplementedError("dropout_keep_prob < 1.0: the de-duplicated / factorised CAR path requires the "
-                                      "reference's shipped keep_prob = 1.0 (SURVEY section 7)")
+        if self.is_training and not (0.0 < keep_prob <= 1.0):
+            raise ValueError("dropout_keep_prob must be in (0, 1]")
+        if self.is_training and keep_prob != 1.0 and gemm_dtype == 'bf16':
+            raise NotImplementedError("dropout_keep_prob < 1.0 is built for the fp32 configuration only")
         self.mode = mode
         self.inputs, self.labels = inputs, labels
         self.lr, self.keep_prob = lr, keep_prob
@@ -697,12 +711,33 @@ class NARModuleModel:
                                      ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
               "cham_item_assemble")
         rt.refresh_shadows()
-        # factorised PreCAR: U (per click) + V (per unique item row), then CAR
-        rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
-        rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
+        drop = self.is_training and self.keep_prob < 1.0
         pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])
-        # PreCAR combine + CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
-        check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
+        if drop:
+            # dropout_keep_prob < 1 (nar_model.py:338, 352, 368): the per-element masks make every CAR row occurrence-specific, so
+            # the PreCAR layer runs on the dense [clicked | candidates] x [ctx | item] rows instead of the factorised U + V form
+            pl.dropout_buffers(rt)
+            keep, Fw, e1, e2 = float(self.keep_prob), Fc + Fi, L.entries['W1c'], L.entries['W1i']
+            assert e2.offset == e1.offset + e1.size
+            W1 = rt.flat[e1.offset:e2.offset + e2.size].view(Fw, C)
+            gW1 = rt.grads[e1.offset:e2.offset + e2.size].view(Fw, C)
+
+            def dropout(x, y, rows, cols, ld, site_first, site_rest, group, posmap, col_split=None, col_shift=0):
+                check(lib.cham_dropout(ptr(x), ptr(y), rows, cols, ld, keep, rt.tf_random_seed, step & 0xFFFFFFFF, site_first, site_rest,
+                                       group, ptr(posmap), T, d['row_begin'], cols if col_split is None else col_split, col_shift,
+                                       _stream()), "cham_dropout")
+            self._drop = dict(fn=dropout, W1=W1, gW1=gW1, Fw=Fw)
+            check(lib.cham_dense_rows(ptr(pl.Xc_s), Fc, ptr(pl.Xi_s), Fi, BT, N, pmax, ptr(neg_slot), ptr(pl.Xd), s), "cham_dense_rows")
+            dropout(pl.Xd, pl.Xd, BT, Fw, Fw, 16, 16, 1, pos, Fc, Fc - L.f_ctx)
+            dropout(pl.Xd[BT:], pl.Xd[BT:], Rc, Fw, Fw, 17, 18, NC, pos, Fc, Fc - L.f_ctx)
+            rt.gemm(pl.Xd, W1, pl.Z1, BT, C, Fw, Fw, C, C, bias=p('b1'), act=ACT_LEAKY)      # clicked-input rows first ...
+        else:
+            self._drop = None
+            # factorised PreCAR: U (per click) + V (per unique item row), then CAR
+            rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
+            rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
+            # PreCAR combine + CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
+            check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
         rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.fork()
         with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
@@ -725,11 +760,18 @@ class NARModuleModel:
                                            ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
                                            ptr(pl.RH[l]), _stream()), "cham_rnn_fwd")
                 x, ldx, K = pl.rnn_out[l], Hp, Hp
+                if drop:     # DropoutWrapper(output_keep_prob), nar_model.py:1331: the layer's OUTPUT is dropped, its state is not
+                    dropout(pl.rnn_out[l], pl.rnn_drop[l], BTf, Hp, Hp, 20 + l, 20 + l, 1, None)
+                    x = pl.rnn_drop[l]
             if pos is not None:
                 check(lib.cham_rows_gather(ptr(x), ptr(pos), BT, Hp, ptr(pl.rnn_c), _stream()), "cham_rows_gather")
                 x = pl.rnn_c
             rt.gemm(x, p('Wf1'), pl.FC1, BT, 512, Hp, Hp, 512, 512, bias=p('bf1'), act=ACT_LEAKY)
-            rt.gemm(pl.FC1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
+            fc1 = pl.FC1
+            if drop:         # nar_model.py:418
+                dropout(pl.FC1, pl.FC1d, BT, 512, 512, 19, 19, 1, pos)
+                fc1 = pl.FC1d
+            rt.gemm(fc1, p('Wf2'), pl.pred, BT, C, 512, 512, C, C, bias=p('bf2'), act=ACT_TANH)
         # ... the candidate rows: PreCAR combine (HBM-bound) + the dominant GEMM, CAR layer 2 on the B*T*(1+N) rows
         if rt.b16:
             # bf16 configuration: candidate-row matrices are bf16 in HBM, weights through their bf16 shadows (csrc/gemm_b16.hip)
@@ -743,7 +785,10 @@ class NARModuleModel:
             rt.gemm_b16(pl.S2, 64, 0, sh['Ws3T'], 64, 1, pl.S3, 32, 0, Rc, 32, 64, bias=p('bs3'), act=ACT_LEAKY)
             softmax_fwd = lib.cham_score_softmax_fwd_b16
         else:
-            check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
+            if drop:
+                rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
+            else:
+                check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
             rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
             rt.join()
             # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
@@ -783,7 +828,9 @@ class NARModuleModel:
         main_stream, on = torch.cuda.current_stream(), rt.overlap
         b16 = rt.b16
         sh = rt.shadow
-        swap = on and rt.tail_on_side and not b16
+        drop = self._drop
+        dropout = drop['fn'] if drop else None
+        swap = on and rt.tail_on_side and not b16 and not drop
 
         def mark():                      # event on the current stream
             if not on:
@@ -879,10 +926,13 @@ class NARModuleModel:
         last = L.L - 1
         with side(e_dZ2c):
             ss = _stream()
-            rt.gemm(pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
+            rt.gemm(pl.FC1d if drop else pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
             rt.colsum(pl.dpred, C, BT, C, g('bf2'))
             rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
-            rt.gemm(pl.rnn_c if pos is not None else pl.rnn_out[last], pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
+            if drop:                     # (mask and leaky' are both element-wise factors: the order does not matter)
+                dropout(pl.dFC1, pl.dFC1, BT, 512, 512, 19, 19, 1, pos)
+            rnn_y = (lambda l: pl.rnn_drop[l]) if drop else (lambda l: pl.rnn_out[l])     # what the next layer / FC1 consumed
+            rt.gemm(pl.rnn_c if pos is not None else rnn_y(last), pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
             rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
             if pos is not None:          # d rnn_out back into the [B, T] layout (zero at padded steps)
                 rt.gemm(pl.dFC1, p('Wf1'), pl.drnn_c, BT, Hp, 512, 512, 512, Hp, transB=1)
@@ -890,6 +940,8 @@ class NARModuleModel:
                 check(lib.cham_rows_scatter(ptr(pl.drnn_c), ptr(pos), BT, Hp, ptr(pl.drnn), ss), "cham_rows_scatter")
             else:
                 rt.gemm(pl.dFC1, p('Wf1'), pl.drnn, BT, Hp, 512, 512, 512, Hp, transB=1)
+            if drop:
+                dropout(pl.drnn, pl.drnn, BTf, Hp, Hp, 20 + last, 20 + last, 1, None)
             for l in range(last, -1, -1):
                 if L.rnn_stepwise:
                     pl.carry.zero_()
@@ -929,7 +981,9 @@ class NARModuleModel:
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
-                    rt.gemm(pl.rnn_out[l - 1], pl.dxproj, g('rnn%d/Wx' % l), Hp, NGH, BTf, Hp, NGH, NGH, transA=1, splits=0)
+                    rt.gemm(rnn_y(l - 1), pl.dxproj, g('rnn%d/Wx' % l), Hp, NGH, BTf, Hp, NGH, NGH, transA=1, splits=0)
+                    if drop:
+                        dropout(pl.drnn, pl.drnn, BTf, Hp, Hp, 20 + l - 1, 20 + l - 1, 1, None)
                 # recurrent weights: their forward product runs in the fp32 time-step kernel -> fp32 wgrad in every mode
                 rt.gemm(pl.hprev[l], pl.dxproj, g('rnn%d/Wh' % l), Hp, 2 * Hp, BTf, Hp, NGH, 2 * Hp, transA=1, splits=0, force_f32=True)
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
@@ -954,17 +1008,29 @@ class NARModuleModel:
         def precar_backward(ws):
             """PreCAR combine scatter, W1 weight gradients, feature / embedding backward (on whatever lane is current)."""
             st = _stream()
-            if b16:
+            if drop:        # dense PreCAR backward: one weight gradient over all CAR rows, d(input rows) masked, then summed per
+                #             position / per item row by the same deterministic scatter as the factorised path (width Fc + Fi)
+                Fw = drop['Fw']
+                rt.gemm(pl.Xd, pl.dZ1, drop['gW1'], Fw, C, Rall, Fw, C, C, transA=1, splits=0)
+                rt.colsum(pl.dZ1, C, Rall, C, g('b1'))
+                rt.gemm(pl.dZ1, drop['W1'], pl.dXd, Rall, Fw, C, C, C, Fw, transB=1)
+                dropout(pl.dXd, pl.dXd, BT, Fw, Fw, 16, 16, 1, pos, Fc, Fc - L.f_ctx)
+                dropout(pl.dXd[BT:], pl.dXd[BT:], Rc, Fw, Fw, 17, 18, NC, pos, Fc, Fc - L.f_ctx)
+                check(lib.cham_combine_bwd(ptr(pl.dXd), Fw, BT, N, pmax, ptr(neg_slot), ptr(pl.dUx), ptr(pl.dVx), ptr(pl.drop_ws),
+                                           pl.drop_ws.numel() * 4, st), "cham_combine_bwd")
+                pl.dXc[:BT].copy_(pl.dUx[:BT, :Fc]); pl.dXi[:RV].copy_(pl.dVx[:RV, Fc:])
+            elif b16:
                 check(lib.cham_combine_bwd_b16(ptr(pl.dZ1), ptr(pl.dZ1c), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws),
                                                ws.numel() * 4, st), "cham_combine_bwd_b16")
             else:
                 check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
                       "cham_combine_bwd")
-            rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
-            rt.colsum(pl.dU, C, BT, C, g('b1'))
-            rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
-            rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
-            rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
+            if not drop:
+                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+                rt.colsum(pl.dU, C, BT, C, g('b1'))
+                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
+                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
             # scale/center + embedding tables (fixed summation order: the step is bit-reproducible)
             check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), st), "cham_feature_bwd")
             check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(g('gamma_item')), ptr(g('beta_item')), st), "cham_feature_bwd")

@@ -79,6 +79,19 @@ int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* workspace, s
 int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
                           const int32_t* perm, float* table_grad, void* stream);
 
+/* --- dropout (dropout_keep_prob < 1): tf.layers.dropout at nar_model.py:338, 352, 368, 418 and DropoutWrapper(output_keep_prob) at
+ * :1331.  y = x / keep_prob * mask (TF 1.12 tf.nn.dropout); the mask is a pure function of the element's coordinates:
+ * kept iff Philox4x32-10(ctr = (column, t, GLOBAL session row, site + 256 n), key = (seed, step))[0] < floor(keep_prob * 2^32)
+ * (oracle/philox.py) - independent of row shards / compaction, recomputed in the backward pass.  Row r -> position r / group,
+ * sub = r % group (sub 0: site_first; sub > 0: site_rest, n = sub - 1); position -> (b, t) through pos[] or directly;
+ * column c -> c < col_split ? c : c - col_shift.  In place (y == x) allowed.
+ * cham_dense_rows: the un-factorised PreCAR input rows [clicked | candidates] x [ctx | item] the dropout path needs. */
+int cham_dropout(const float* x, float* y, long rows, int cols, int ld, float keep_prob, uint32_t seed, uint32_t step,
+                 int site_first, int site_rest, int group, const int32_t* pos, int T, int row_begin, int col_split, int col_shift,
+                 void* stream);
+int cham_dense_rows(const float* Xc_s, int Fc, const float* Xi_s, int Fi, int BT, int N, int pmax, const int32_t* neg_slot, float* X,
+                    void* stream);
+
 /* --- K2/K4 fp32 MFMA GEMM with fused prologue/epilogue: tf.layers.Dense at nar_model.py:374-405, 410-426, 447-473,
  * the RNN input projection (:1308-1361) and their gradients.
  * C[M,N] (+)= epi(op(A)[M,K] * op(B)[K,N]); transA: A stored [K,M]; transB: B stored [N,K];

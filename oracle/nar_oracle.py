@@ -14,6 +14,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from . import philox
 from . import sampler as osampler
 
 ARTICLE_REQ_FEATURES = ['article_id', 'created_at_ts']          # nar_model.py:22
@@ -282,6 +283,29 @@ class NAROracle:
             feats.append(self._novelty(ids, buffer_ids, pop_norm))
         return torch.cat(feats, dim=-1)
 
+    # -- tf.layers.dropout / DropoutWrapper (nar_model.py:338, 352, 368, 418, 1331): y = x / keep_prob * mask (TF 1.12 tf.nn.dropout).
+    #    TF's random streams are not reproducible here; the mask is the counter-based one the HIP path uses (csrc/features.hip
+    #    k_dropout): element (column c, step t, session row b, site, negative n) is kept iff
+    #    Philox4x32-10(ctr = (c, t, b, site + 256 n), key = (seed, step))[0] < floor(keep_prob * 2^32)
+    SITE_INPUT, SITE_POSITIVE, SITE_NEGATIVE, SITE_FC1, SITE_RNN = 16, 17, 18, 19, 20
+
+    def _dropout(self, x, site, step):
+        keep = float(self.p.get('dropout_keep_prob', 1.0))
+        if keep >= 1.0 or not self._train:
+            return x
+        thr = int(np.float32(keep).astype(np.float64) * 4294967296.0)
+        shp = x.shape                                     # [B, T, F] or [B, T, N, F]
+        b = np.arange(shp[0], dtype=np.uint64).reshape(-1, 1, 1)
+        t = np.arange(shp[1], dtype=np.uint64).reshape(1, -1, 1)
+        c = np.arange(shp[-1], dtype=np.uint64).reshape(1, 1, -1)
+        if x.dim() == 4:
+            n = np.arange(shp[2], dtype=np.uint64).reshape(1, 1, -1, 1)
+            r = philox.rand32(c[:, :, None, :], t[:, :, None, :], b[:, :, None, :], np.uint64(site) + np.uint64(256) * n, self.seed, step)
+        else:
+            r = philox.rand32(c, t, b, site, self.seed, step)
+        mask = torch.from_numpy((np.broadcast_to(r, shp) < np.uint64(thr)).astype(np.float32))
+        return x / torch.tensor(np.float32(keep)) * mask
+
     def _store(self, x):
         """Candidate-row matrices are bf16-resident in the bf16 configuration; identity otherwise."""
         return _StoreBF16.apply(x) if self.gemm_dtype == 'bf16' else x
@@ -330,7 +354,7 @@ class NAROracle:
                 valid = (t < lengths).unsqueeze(1)
                 ys.append(torch.where(valid, hn, torch.zeros_like(hn)))   # dynamic_rnn: zero output past length
                 h = torch.where(valid, hn, h)                              # state carried unchanged
-            out = torch.stack(ys, 1)
+            out = self._dropout(torch.stack(ys, 1), self.SITE_RNN + l, self._step)        # DropoutWrapper(output_keep_prob), :1331
         return out
 
     def _scorer(self, m):
@@ -402,13 +426,14 @@ class NAROracle:
         if ctx is None:
             ctx = torch.zeros(B, T, 1)                                                     # :323-325
         gamma, beta = self.w['gamma'], self.w['beta']
-        # keep_prob == 1.0 (every shipped script) -> dropout is the identity (:338, 352, 368)
-        assert p.get('dropout_keep_prob', 1.0) == 1.0 or not train, "oracle restates keep_prob=1.0 only"
+        self._train, self._step = train, step
         with self._stage('gather'):
             x_in = torch.cat([ctx, self._item_features(item_clicked, event_ts, buffer_t, pop_t, max_ts if global_max_ts is not None else None)], 2) * gamma + beta   # :328-333
             x_pos = torch.cat([ctx, self._item_features(label_next, max_ts, buffer_t, pop_t)], 2) * gamma + beta     # :343-347
             ctx_tiled = ctx.unsqueeze(2).expand(B, T, neg.shape[2], ctx.shape[-1])                                     # :360
             x_neg = torch.cat([ctx_tiled, self._item_features(neg, max_ts, buffer_t, pop_t)], 3) * gamma + beta       # :356-364
+            x_in, x_pos, x_neg = (self._dropout(x_in, self.SITE_INPUT, step), self._dropout(x_pos, self.SITE_POSITIVE, step),
+                                  self._dropout(x_neg, self.SITE_NEGATIVE, step))                                       # :338, 352, 368
         with self._stage('CAR'):
             car_in, car_pos, car_neg = self._car(x_in), self._car(x_pos, True), self._car(x_neg, True)                 # :374-405
         with self._stage('RNN'):
@@ -416,6 +441,7 @@ class NAROracle:
         with self._stage('scorer'):
             fc1 = _leaky(self._mm(rnn_out, self.w['FC1/kernel']) + self.w['FC1/bias'])                                        # :411
             self._tap('FC1', fc1)
+            fc1 = self._dropout(fc1, self.SITE_FC1, step)                                                                 # :418
             pred = torch.tanh(self._mm(fc1, self.w['FC2/kernel']) + self.w['FC2/bias'])                                       # :423
             s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
             s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500

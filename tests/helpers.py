@@ -42,13 +42,14 @@ def make_pair(p, seed=3):
             w[k] = (1.0 + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
     rt.load_logical_weights(w)
     model = NARModuleModel(ModeKeys.TRAIN, None, None, p['session_features_config'], p['articles_features_config'],
-                           p['batch_size'], p['lr'], 1.0, p['train_total_negative_samples'],
+                           p['batch_size'], p['lr'], p.get('dropout_keep_prob', 1.0), p['train_total_negative_samples'],
                            p['train_negative_samples_from_buffer'], p['content_article_embeddings_matrix'],
                            softmax_temperature=p['softmax_temperature'], reg_weight_decay=p['reg_weight_decay'],
                            recent_clicks_buffer_max_size=p['recent_clicks_buffer_max_size'],
                            recent_clicks_for_normalization=p['recent_clicks_for_normalization'],
                            articles_metadata=p['articles_metadata'], CAR_embedding_size=p['CAR_embedding_size'],
-                           rnn_units=p['rnn_units'], novelty_reg_factor=p.get('novelty_reg_factor', 0.0), runtime=rt)
+                           rnn_units=p['rnn_units'], novelty_reg_factor=p.get('novelty_reg_factor', 0.0), runtime=rt,
+                           rnn_num_layers=p.get('rnn_num_layers', 1), rnn_cell=p.get('rnn_cell', 'ugrnn'), gemm_dtype=p.get('gemm_dtype', 'f32'))
     orc = NAROracle(p, weights=w)
     return model, orc
 

@@ -363,3 +363,49 @@ def test_step_parity_fewer_candidates_than_negatives(gpu):
         neg = model._plan.neg_ids.cpu().numpy()
         valid = np.asarray(batches[i][1]['label_next_item']) != 0
         assert (neg[valid] == 0).mean() > 0.125, "this case is meant to exercise > 12.5 % padded negatives"
+
+
+@pytest.mark.parametrize("cell,layers,keep", [("ugrnn", 1, 0.8), ("gru", 2, 0.9)])
+def test_step_parity_dropout(gpu, cell, layers, keep):
+    """dropout_keep_prob < 1 (the reference's hyper-tuning config searches 0.8 / 0.9: nar_mlengine_hypertuning.yaml:40-45): dropout on
+    the three feature tensors (nar_model.py:338, 352, 368 - the dense, un-factorised PreCAR path), on FC1 (:418) and on every recurrent
+    layer's output (:1331), with the counter-based masks both sides share: bit-exact negatives, logits / loss 1e-3, gradients."""
+    p = H.tiny_params(C=128, H=96, neg=9, batch_size=40, rnn_cell=cell, rnn_num_layers=layers, dropout_keep_prob=keep)
+    batches = synthetic.make_batches(5, 40, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=5)
+    assert model.keep_prob == keep
+    flips = []
+    for i in (2, 3, 4):
+        flips.append(_compare_step(model, orc, *batches[i], st))
+        x_neg = orc.forward(*batches[i], st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm(), 'train')['x_neg']
+        mask = np.asarray(batches[i][1]['label_next_item']) != 0
+        dropped = float((x_neg.detach().numpy()[mask] == 0).mean())
+        assert dropped > (1.0 - keep) * 0.8, dropped            # the masks really are applied (one-hot zeros come on top)
+        model.rt.global_step += 1; orc.global_step += 1          # a new mask / sample key per step
+    assert min(flips) == 0, flips
+
+
+def test_dropout_is_identity_in_eval_and_independent_of_row_shards(gpu):
+    """EVAL never drops (nar_trainer_gcom.py:245); TRAIN masks are keyed by the GLOBAL session row and time step, so two row shards
+    reproduce the full batch's logits (data-parallel / micro-batched steps see the same masks)."""
+    from chameleon_recsys_amd.nar import parallel
+    p = H.tiny_params(dropout_keep_prob=0.8)
+    batches = synthetic.make_batches(4, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, _ = H.make_pair(p)
+    f, l = batches[3]
+    model.feed_state(st.get_articles_recent_pop_norm(), st.get_recent_clicks_buffer())
+    model.forward(model.upload_batch(f, l)); model.backward()
+    torch.cuda.synchronize()
+    full = model.outputs_numpy()
+    g_full = model.rt.grads.clone()
+    g_sum, logits = torch.zeros_like(g_full), []
+    for r in range(2):
+        b, e = parallel.shard_rows(64, r, 2)
+        fl, ll = parallel.slice_batch(f, l, b, e)
+        model.forward(model.upload_batch(fl, ll, f, l, row_begin=b)); model.backward()
+        torch.cuda.synchronize()
+        logits.append(model.outputs_numpy()['logits']); g_sum += model.rt.grads
+    assert np.abs(np.concatenate(logits) - full['logits']).max() < 1e-5
+    assert float((g_sum - g_full).abs().max()) < 2e-5 * float(g_full.abs().max()) + 1e-7
