@@ -2,7 +2,8 @@
 
 Mirrors nar_module/nar/clicked_items_state.py:10-250 for the parts the NAR training step consumes
 (update_items_state :187-193, buffer :206-228, recent pop :231-246, global pop :248-250, snapshot around eval
-:49-79).  The co-occurrence matrix / cold-start bookkeeping (:252-255, benchmarks only) are out of scope.
+:49-79) and the item cold-start bookkeeping (:43-45, 97-104, 196-203).  The co-occurrence matrix (:252-255, benchmarks only) is
+out of scope.
 Vectorised numpy (np.bincount instead of collections.Counter); results are bit-identical to the reference class
 (tests/golden/state_trace.npz).
 """
@@ -11,7 +12,42 @@ import numpy as np
 MILISECS_BY_HOUR = 1000 * 60 * 60
 
 
-class ClickedItemsState:
+class _ColdStartBookkeeping:
+    """Item cold-start analysis (--eval_cold_start): the step an item was clicked first and, through evaluation.ColdStartAnalysisState,
+    how many steps later it first showed up in a top-n recommendation list (clicked_items_state.py:43-45, 97-104, 196-203; snapshot /
+    restore :57-59, 75-79).  Host-side dictionaries in both state classes - it only runs when the flag is set."""
+
+    def _reset_cold_start(self):
+        from .evaluation import ColdStartAnalysisState
+        self.current_step = 0
+        self.items_first_click_step = dict()
+        self.cold_start_state = ColdStartAnalysisState()
+
+    def _save_cold_start(self):
+        from copy import deepcopy
+        self._cold_chkp = (deepcopy(self.items_first_click_step), deepcopy(self.cold_start_state), self.current_step)
+
+    def _restore_cold_start(self):
+        self.items_first_click_step, self.cold_start_state, self.current_step = self._cold_chkp
+        del self._cold_chkp
+
+    def increment_current_step(self):
+        self.current_step += 1
+
+    def get_current_step(self):
+        return self.current_step
+
+    def get_cold_start_state(self):
+        return self.cold_start_state
+
+    def update_items_first_click_step(self, batch_clicked_items):
+        step = self.get_current_step()
+        for item_id in set(int(x) for x in batch_clicked_items) - {0}:
+            if item_id not in self.items_first_click_step:
+                self.items_first_click_step[item_id] = step
+
+
+class ClickedItemsState(_ColdStartBookkeeping):
 
     def __init__(self, recent_clicks_buffer_hours, recent_clicks_buffer_max_size, recent_clicks_for_normalization, num_items):
         self.recent_clicks_buffer_hours = recent_clicks_buffer_hours
@@ -26,20 +62,20 @@ class ClickedItemsState:
         self._update_recent_pop_norm(self.articles_recent_pop)
         # two columns (article_id, click_timestamp), newest first
         self.pop_recent_clicks_buffer = np.zeros(shape=[self.recent_clicks_buffer_max_size, 2], dtype=np.int64)
-        self.current_step = 0
+        self._reset_cold_start()
 
     def save_state_checkpoint(self):
         self.articles_pop_chkp = np.copy(self.articles_pop)
         self.pop_recent_clicks_buffer_chkp = np.copy(self.pop_recent_clicks_buffer)
         self.articles_recent_pop_chkp = np.copy(self.articles_recent_pop)
-        self.current_step_chkp = self.current_step
+        self._save_cold_start()
 
     def restore_state_checkpoint(self):
         self.articles_pop = self.articles_pop_chkp
         self.pop_recent_clicks_buffer = self.pop_recent_clicks_buffer_chkp
         # NB the reference does not restore articles_recent_pop(_norm) (clicked_items_state.py:61-79): it is recomputed
         # from the restored buffer at the next update.  We keep that behaviour.
-        self.current_step = self.current_step_chkp
+        self._restore_cold_start()
         del self.articles_pop_chkp, self.pop_recent_clicks_buffer_chkp, self.articles_recent_pop_chkp
 
     def get_articles_pop(self):
@@ -53,12 +89,6 @@ class ClickedItemsState:
 
     def get_recent_clicks_buffer(self):
         return self.pop_recent_clicks_buffer[:, 0]
-
-    def increment_current_step(self):
-        self.current_step += 1
-
-    def get_current_step(self):
-        return self.current_step
 
     def update_items_state(self, batch_clicked_items, batch_clicked_timestamps):
         self._update_recently_clicked_items_buffer(batch_clicked_items, batch_clicked_timestamps)
@@ -100,7 +130,7 @@ def batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps):
     return batch_clicked_items[nz], ts[nz]
 
 
-class DeviceClickedItemsState:
+class DeviceClickedItemsState(_ColdStartBookkeeping):
     """The same state kept in HBM: recent-clicks ring buffer (ids, timestamps), recent popularity histogram,
     ``articles_recent_pop_norm`` (float32, what the graph is fed) and global popularity, updated by the HIP kernels of
     csrc/state.hip straight from the batch tensors the step already has on the device - no host round trip per step.
@@ -139,7 +169,7 @@ class DeviceClickedItemsState:
         self.pop_norm = t.full((n,), float(np.float32(1.0 / self.recent_clicks_for_normalization)), dtype=t.float32, device=dev)
         self.n_valid = t.zeros(1, dtype=t.int32, device=dev)
         self.n_updates = 0
-        self.current_step = 0
+        self._reset_cold_start()
         self._after_host_side_change()
 
     # ---- stream ordering
@@ -220,20 +250,15 @@ class DeviceClickedItemsState:
         self.sync_to_current()
         return np.stack([self.buf_ids.cpu().numpy(), self.buf_ts.cpu().numpy()], axis=1)
 
-    def increment_current_step(self):
-        self.current_step += 1
-
-    def get_current_step(self):
-        return self.current_step
-
     # ---- snapshot around evaluation (clicked_items_state.py:49-79: buffer + global pop; pop_norm is NOT restored)
     def save_state_checkpoint(self):
         self.sync_to_current()
-        self._chkp = (self.articles_pop.clone(), self.buf_ids.clone(), self.buf_ts.clone(), self.n_valid.clone(),
-                      self.n_updates, self.current_step)
+        self._chkp = (self.articles_pop.clone(), self.buf_ids.clone(), self.buf_ts.clone(), self.n_valid.clone(), self.n_updates)
+        self._save_cold_start()
 
     def restore_state_checkpoint(self):
         self.sync_to_current()          # the update still in flight writes the tensors that are being replaced
-        self.articles_pop, self.buf_ids, self.buf_ts, self.n_valid, self.n_updates, self.current_step = self._chkp
+        self.articles_pop, self.buf_ids, self.buf_ts, self.n_valid, self.n_updates = self._chkp
         del self._chkp
+        self._restore_cold_start()
         self._after_host_side_change()

@@ -64,3 +64,32 @@ class MRR(StreamingMetric):
 
     def result(self):
         return np.mean(self.mrr_results)
+
+
+class HitRateBySessionPosition(StreamingMetric):
+    """HitRate@N per session position (nar_module/nar/metrics.py:136-168): key = 1-based click column; also the average recent
+    normalised popularity of the labels at that position and the number of clicks counted there."""
+    name = 'hitrate_at_n_by_pos'
+
+    def reset(self):
+        self.hitrate_matches_by_session_pos = {}
+        self.hitrate_total_by_session_pos = {}
+        self.norm_pop_by_pos = {}
+
+    def add(self, predictions, labels, labels_norm_pop):
+        rank, valid = _first_hit_rank(predictions, labels, self.topn)
+        labels_norm_pop = np.asarray(labels_norm_pop, dtype=np.float64)
+        for col in np.flatnonzero(valid.any(axis=0)):
+            v = valid[:, col]
+            key = int(col) + 1
+            self.hitrate_total_by_session_pos[key] = self.hitrate_total_by_session_pos.get(key, 0) + int(v.sum())
+            self.norm_pop_by_pos[key] = self.norm_pop_by_pos.get(key, 0) + float(labels_norm_pop[:, col][v].sum())
+            hits = int(((rank[:, col] >= 0) & v).sum())
+            if hits:
+                self.hitrate_matches_by_session_pos[key] = self.hitrate_matches_by_session_pos.get(key, 0) + hits
+
+    def result(self):
+        tot = self.hitrate_total_by_session_pos
+        hitrate = {k: self.hitrate_matches_by_session_pos.get(k, 0) / float(tot[k]) for k in tot}
+        avg_pop = {k: self.norm_pop_by_pos.get(k, 0) / float(tot[k]) for k in tot}
+        return hitrate, avg_pop, tot

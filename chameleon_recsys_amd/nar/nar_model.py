@@ -1131,7 +1131,9 @@ class NARModuleModel:
                 d = staged[1]
             else:
                 d = self.upload_batch(self.inputs, self.labels)
-        self.forward(d)
+        pl = self.forward(d)
+        if self.eval_cold_start:       # nar_model.py:520: the ranked candidates are also needed while TRAINING for the cold-start analysis
+            self._rank_items(pl, d)
         self.backward()
         self.apply_gradients()
         return self.total_loss
@@ -1141,11 +1143,8 @@ class NARModuleModel:
         """Sampler key of the eval_iter-th batch of an evaluate() call (distinct from every training step's key)."""
         return (global_step + 1000003 * (eval_iter + 1)) & 0xFFFFFFFF
 
-    def evaluate_step(self, device_batch=None):
-        """EVAL-mode ``session.run``: forward with the eval negative-sample counts (nar_trainer_gcom.py:240-242) +
-        rank_items_by_predicted_prob (nar_model.py:777-794)."""
-        d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)
-        pl = self.forward(d)
+    def _rank_items(self, pl, d):
+        """rank_items_by_predicted_prob (nar_model.py:777-794) of the last forward pass -> self._eval (what the hook fetches)."""
         rt, dev = self.rt, self.rt.device
         ev = self._eval
         if ev is None or ev['pred_ids'].shape != (pl.B, pl.T, pl.NC):
@@ -1167,6 +1166,13 @@ class NARModuleModel:
             ev['pred_ids'].zero_(); ev['pred_probs'].zero_(); ev['label_rank'].fill_(-1)
             for src, dst, words in ((c[0], ev['pred_ids'], 2 * NC), (c[1], ev['pred_probs'], NC), (c[2], ev['label_rank'], 1)):
                 check(rt.lib.cham_rows_scatter(ptr(src), ptr(pl.pos), P, words, ptr(dst), _stream()), "cham_rows_scatter")
+
+    def evaluate_step(self, device_batch=None):
+        """EVAL-mode ``session.run``: forward with the eval negative-sample counts (nar_trainer_gcom.py:240-242) +
+        rank_items_by_predicted_prob (nar_model.py:777-794)."""
+        d = device_batch if device_batch is not None else self.upload_batch(self.inputs, self.labels)
+        pl = self.forward(d)
+        self._rank_items(pl, d)
         self._eval_iter += 1
         return self.total_loss
 
@@ -1191,9 +1197,11 @@ class ItemsStateUpdaterHook:
         metrics, metrics.py, plus the TF streaming twins nar_model.py:826-835, 859-885); always: the recent-clicks state
         update from the batch (:1635-1649);
       * begin / end (:1410-1431, :1669-1695): state snapshot around evaluation, metrics appended to
-        ``eval_sessions_metrics_log``.
+        ``eval_sessions_metrics_log``;
+      * ``eval_metrics_by_session_position`` (HitRate@n per click position, :1718) and ``eval_cold_start`` (steps between an
+        item's first click and its first top-n recommendation, :1480-1494, 1621-1625, 1662-1666; runs in TRAIN and EVAL).
     Out of scope: the baseline recommenders (``eval_benchmark_classifiers`` must be empty), the
-    co-occurrence matrix (:1650), cold-start analysis, novelty / diversity / coverage metrics."""
+    co-occurrence matrix (:1650), novelty / diversity / coverage metrics."""
 
     def __init__(self, mode, model, eval_metrics_top_n, clicked_items_state, eval_sessions_metrics_log,
                  sessions_negative_items_log=None, sessions_chameleon_recommendations_log=None,
@@ -1202,8 +1210,8 @@ class ItemsStateUpdaterHook:
                  eval_metric_ops=None):
         if eval_benchmark_classifiers:
             raise NotImplementedError("baseline recommenders (nar/benchmarks) are out of scope: pass --disable_eval_benchmarks")
-        if eval_cold_start or eval_metrics_by_session_position:
-            raise NotImplementedError("eval_cold_start / eval_metrics_by_session_position are not built")
+        self.eval_cold_start = eval_cold_start
+        self.eval_metrics_by_session_position = eval_metrics_by_session_position
         self.mode, self.model = mode, model
         self.eval_metrics_top_n = eval_metrics_top_n
         self.clicked_items_state = clicked_items_state
@@ -1216,10 +1224,12 @@ class ItemsStateUpdaterHook:
 
     def begin(self):
         if self.mode == ModeKeys.EVAL:
-            from .metrics import HitRate, MRR
+            from .metrics import HitRate, HitRateBySessionPosition, MRR
             self.clicked_items_state.save_state_checkpoint()                    # nar_model.py:1415
             self.eval_streaming_metrics_last = {}
-            self.streaming_metrics = [HitRate(self.eval_metrics_top_n), MRR(self.eval_metrics_top_n)]
+            self.streaming_metrics = [HitRate(self.eval_metrics_top_n), MRR(self.eval_metrics_top_n)]       # create_eval_metrics, :1696-1721
+            if self.eval_metrics_by_session_position:
+                self.streaming_metrics.append(HitRateBySessionPosition(self.eval_metrics_top_n))
             self.stats_logs = []
 
     def after_create_session(self, session=None, coord=None):
@@ -1231,7 +1241,7 @@ class ItemsStateUpdaterHook:
         fetches = {'clicked_items': m.item_clicked, 'clicked_timestamps': m.event_timestamp,
                    'next_item_labels': m.next_item_label, 'last_item_label': m.label_last_item,
                    'session_id': m.session_id, 'user_id': m.user_id}
-        if self.mode == ModeKeys.EVAL:
+        if self.eval_cold_start or self.mode == ModeKeys.EVAL:                 # nar_model.py:1444
             fetches.update(predicted_item_ids=m.predicted_item_ids, eval_batch_negative_items=m.batch_negative_items,
                            batch_items_count=m.batch_items_count, batch_unique_items_count=m.batch_unique_items_count,
                            predicted_item_probs=m.predicted_item_probs, label_rank=m.label_rank)
@@ -1278,10 +1288,16 @@ class ItemsStateUpdaterHook:
             self.stats_logs.append({'batch_items_count': r['batch_items_count'],
                                     'batch_unique_items_count': r['batch_unique_items_count'],
                                     'batch_sessions_count': len(sessions_ids)})
-            for metric in self.streaming_metrics:                              # evaluation.py:12-26 update_metrics
-                metric.add(predicted_item_ids, next_item_labels)
-            for metric in self.streaming_metrics:                              # evaluation.py:28-45
-                self.eval_streaming_metrics_last['{}_{}'.format(metric.name, 'chameleon')] = metric.result()
+            from .evaluation import compute_metrics_results, update_metrics
+            labels_norm_pop = preds_norm_pop = None
+            if self.eval_metrics_by_session_position:                          # nar_model.py:1590-1593
+                labels_norm_pop = self.clicked_items_state.get_articles_recent_pop_norm()[next_item_labels]
+            update_metrics(predicted_item_ids, next_item_labels, labels_norm_pop, preds_norm_pop, clicked_items,
+                           self.streaming_metrics, recommender='chameleon')
+            self.eval_streaming_metrics_last.update(compute_metrics_results(self.streaming_metrics, recommender='chameleon'))
+        if self.eval_cold_start:                                               # nar_model.py:1621-1625, both modes
+            self.update_items_cold_start_state(r['user_id'], clicked_items, next_item_labels, r['eval_batch_negative_items'],
+                                               r['predicted_item_ids'])
         # state update, nar_model.py:1635-1649
         if getattr(self.clicked_items_state, 'is_device', False):     # straight from the batch tensors already in HBM
             d = self.model._d
@@ -1291,9 +1307,22 @@ class ItemsStateUpdaterHook:
         ids, ts = batch_clicks_for_state(clicked_items, last_item_label, clicked_timestamps)
         self.clicked_items_state.update_items_state(ids, ts)
 
+    def update_items_cold_start_state(self, users_ids, clicked_items, next_item_labels, eval_batch_negative_items, predicted_item_ids):
+        """nar_model.py:1480-1494 (the benchmark recommenders' part, :1496-1501, is out of scope)."""
+        st = self.clicked_items_state
+        clicked_items_nonzero = set(np.asarray(clicked_items).reshape(-1).tolist()) | set(np.asarray(next_item_labels).reshape(-1).tolist())
+        clicked_items_nonzero.discard(0)
+        st.increment_current_step()
+        st.update_items_first_click_step(clicked_items_nonzero)
+        predicted_top_item_ids = np.asarray(predicted_item_ids)[:, :, :self.eval_metrics_top_n]
+        st.get_cold_start_state().update_items_num_steps_before_first_rec(predicted_top_item_ids, st.items_first_click_step,
+                                                                          st.get_current_step())
+
     def end(self, session=None):
         if self.mode == ModeKeys.EVAL:                                         # :1669-1695
             self.eval_streaming_metrics_last['clicks_count'] = int(np.sum([x['batch_items_count'] for x in self.stats_logs]))
             self.eval_streaming_metrics_last['sessions_count'] = int(np.sum([x['batch_sessions_count'] for x in self.stats_logs]))
+            if self.eval_cold_start:                                           # add_cold_start_stats, :1662-1666
+                self.eval_streaming_metrics_last['coldstart_chameleon'] = self.clicked_items_state.get_cold_start_state().get_statistics()
             self.eval_sessions_metrics_log.append(self.eval_streaming_metrics_last)
             self.clicked_items_state.restore_state_checkpoint()

@@ -9,6 +9,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).
 What the reference can run here (TensorFlow 1.12 is not installable, so nothing inside the TF graph):
   * nar_module/nar/clicked_items_state.py  ClickedItemsState  -> state_trace.npz
   * nar_module/nar/metrics.py              HitRate, MRR        -> metrics_hitrate_mrr.npz
+  * metrics.HitRateBySessionPosition, evaluation.ColdStartAnalysisState, the state's first-click bookkeeping -> eval_extras.npz
   * nar_module/nar/benchmarks/candidate_sampling.py (numpy clone of the graph's negative sampler; loaded by file
     path because the package __init__ pulls TF)              -> sampler_clone_stats.npz (distribution pin)
 The restated oracle's own outputs for one full tiny training step (weights, inputs, negatives, logits, loss,
@@ -87,6 +88,49 @@ def metrics_fixture():
     np.savez_compressed(os.path.join(GOLD, "metrics_hitrate_mrr.npz"), **out)
 
 
+def eval_extras_fixture():
+    """HitRateBySessionPosition (metrics.py:136-168), ColdStartAnalysisState (evaluation.py:50-90) and the state's first-click
+    bookkeeping (clicked_items_state.py:97-104, 196-203), executed from the reference on random streams."""
+    cis, metrics = _ref_nar()
+    from nar import evaluation as ref_eval                       # noqa: E402  (reference module)
+    rng = np.random.default_rng(23)
+    B, T, K, n_items, steps = 16, 7, 9, 60, 6
+    out = dict(cfg=np.array([B, T, K, n_items, steps]))
+    hr = metrics.HitRateBySessionPosition(5)
+    st = cis.ClickedItemsState(1.0, 100, 50, n_items)
+    for i in range(steps):
+        labels = rng.integers(1, n_items, size=(B, T)).astype(np.int64)
+        lens = rng.integers(1, T + 1, size=B)
+        labels[np.arange(T)[None, :] >= lens[:, None]] = 0
+        clicked = rng.integers(1, n_items, size=(B, T)).astype(np.int64)
+        clicked[labels == 0] = 0
+        preds = np.stack([[rng.permutation(n_items - 1)[:K] + 1 for _ in range(T)] for _ in range(B)]).astype(np.int64)
+        pop = rng.random((B, T))
+        hr.add(preds, labels, pop)
+        # ItemsStateUpdaterHook.update_items_cold_start_state, nar_model.py:1480-1494
+        nz = set(clicked.reshape(-1)).union(set(labels.reshape(-1))).difference(set([0]))
+        st.increment_current_step()
+        st.update_items_first_click_step(nz)
+        st.get_cold_start_state().update_items_num_steps_before_first_rec(preds[:, :, :5], st.items_first_click_step, st.get_current_step())
+        out.update({"labels_%d" % i: labels, "clicked_%d" % i: clicked, "preds_%d" % i: preds, "pop_%d" % i: pop})
+    hitrate, avg_pop, total = hr.result()
+    keys = sorted(total.keys())
+    out.update(pos_keys=np.array(keys), pos_hitrate=np.array([hitrate[k] for k in keys]), pos_avg_pop=np.array([avg_pop[k] for k in keys]),
+               pos_total=np.array([total[k] for k in keys]))
+    res = ref_eval.compute_metrics_results([hr], recommender='chameleon')
+    out.update(result_keys=np.array(sorted(res.keys())))
+    fc = st.items_first_click_step
+    ids = sorted(fc.keys())
+    out.update(first_click_ids=np.array(ids), first_click_step=np.array([fc[k] for k in ids]))
+    nb = st.get_cold_start_state().items_num_steps_before_first_rec
+    ids = sorted(nb.keys())
+    out.update(first_rec_ids=np.array(ids), first_rec_steps=np.array([nb[k] for k in ids]))
+    stats = st.get_cold_start_state().get_statistics()
+    skeys = sorted(stats.keys())
+    out.update(stats_keys=np.array(skeys), stats_values=np.array([float(stats[k]) for k in skeys]))
+    np.savez_compressed(os.path.join(GOLD, "eval_extras.npz"), **out)
+
+
 def sampler_clone_stats():
     """Distribution pin against the reference's numpy clone of the sampler (its RNG is un-seedable
     np.random.permutation inside -> we store first-pick frequencies over many draws with np.random.seed)."""
@@ -134,6 +178,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     state_trace()
     metrics_fixture()
+    eval_extras_fixture()
     sampler_clone_stats()
     nar_step_tiny()
     for f in sorted(os.listdir(GOLD)):

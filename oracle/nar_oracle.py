@@ -195,6 +195,7 @@ class NAROracle:
         self.cell = params.get('rnn_cell', 'ugrnn')
         self.seed = params.get('tf_random_seed', 42)
         self.gemm_dtype = params.get('gemm_dtype', 'f32')
+        self._train, self._step = False, 0          # set by forward(): dropout is active in TRAIN mode only
 
     def _mm(self, a, b):
         """Dense / matmul of the graph; bf16-rounded operands when the bf16 compute mode is emulated."""
