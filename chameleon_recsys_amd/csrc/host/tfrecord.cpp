@@ -15,12 +15,14 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -268,6 +270,26 @@ struct RecordReader {
         return TFR_OK;
     }
     void close() { if (gz) { gzclose(gz); gz = nullptr; } }
+    // like next(), but the record is left with its 4-byte data CRC appended and that CRC is NOT verified (worker threads do it)
+    int next_raw(bool check_len_crc) {
+        uint8_t hdr[12];
+        const int got = gzread(gz, hdr, 12);
+        if (got == 0) return TFR_EOF;
+        if (got != 12) return TFR_ERR_IO;
+        uint64_t len; uint32_t lcrc;
+        memcpy(&len, hdr, 8); memcpy(&lcrc, hdr + 8, 4);
+        if (check_len_crc && masked_crc(hdr, 8) != lcrc) return TFR_ERR_CRC;
+        if (len > (1ull << 31)) return TFR_ERR_CRC;
+        buf.resize(len + 4);
+        size_t off = 0;
+        while (off < len + 4) {
+            const unsigned want = (unsigned)std::min<size_t>(len + 4 - off, 1u << 30);
+            const int r = gzread(gz, buf.data() + off, want);
+            if (r <= 0) return TFR_ERR_IO;
+            off += r;
+        }
+        return TFR_OK;
+    }
     // TFR_OK + record in buf, TFR_EOF, or an error
     int next(bool check_crc) {
         uint8_t hdr[12];
@@ -300,75 +322,218 @@ struct Batch {
     std::vector<Session> sessions;
 };
 
+// Raw records of one batch: the inflate thread only splits the stream (and checks the 12-byte header CRC, which guards the
+// length); the data CRC and the protobuf decode run on the worker pool.
+struct RawBatch {
+    uint64_t seq = 0;
+    int file_idx = 0;
+    std::vector<uint8_t> bytes;            // records back to back: data followed by its 4-byte masked CRC
+    std::vector<size_t> off;               // start of record i; off.back() = bytes.size()
+};
+
+// tf.data pipeline of datasets.py:118-142: TFRecordDataset(files, 'GZIP') -> map(parse, num_parallel_calls = cpu_count) ->
+// padded_batch -> prefetch.  GZIP inflate is sequential per stream, so ONE thread inflates and cuts the record stream into
+// batches of raw records; `n_workers` threads verify the data CRC and decode the SequenceExamples of whole batches in
+// parallel; a reorder buffer hands the batches out in stream order (a batch may span two files, like the reference's).
 struct SessionReader {
     Schema sc;
     std::vector<std::string> files;
-    int batch_size = 128, truncate = 20, check_crc = 1, prefetch = 2;
-    // producer state
-    std::thread th;
+    int batch_size = 128, truncate = 20, check_crc = 1, prefetch = 2, n_workers = 1;
+    std::thread th_reader;
+    std::vector<std::thread> th_workers;
     std::mutex mu;
-    std::condition_variable cv_put, cv_get;
-    std::deque<std::unique_ptr<Batch>> q;
-    bool done = false, stop = false;
+    std::condition_variable cv_work, cv_space, cv_get;
+    std::deque<std::unique_ptr<RawBatch>> work;              // inflated, not yet decoded
+    std::map<uint64_t, std::unique_ptr<Batch>> ready;        // decoded, waiting for their turn
+    uint64_t next_out = 0, n_raw = 0;                        // next batch the consumer takes / number of raw batches produced
+    int in_decode = 0;
+    bool reader_done = false, stop = false;
     int error = TFR_OK;
+    uint64_t error_seq = ~0ull;                              // batches before this one are still delivered
     std::string error_file;
     std::unique_ptr<Batch> cur;
+    std::atomic<long long> ns_inflate{0}, ns_decode{0}, ns_reader_wait{0}, ns_batcher_wait{0};      // CHAM_TFRECORD_STATS=1 prints them at close
 
-    void produce() {
-        RecordReader rr;
-        FeatureVal tmp;
-        auto b = std::make_unique<Batch>();
+    void fail(int err, uint64_t seq, const std::string& file) {      // mu held
+        if (seq < error_seq) { error = err; error_seq = seq; error_file = file; }
+    }
+    static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    bool push_raw(std::unique_ptr<RawBatch> rb) {
+        const long long t0 = now_ns();
+        std::unique_lock<std::mutex> lk(mu);
+        // bound the batches in flight (raw + being decoded + decoded): prefetch depth + one per worker
+        cv_space.wait(lk, [&] { return stop || (int)(work.size() + ready.size()) + in_decode < prefetch + n_workers; });
+        ns_reader_wait += now_ns() - t0;
+        if (stop) return false;
+        rb->seq = n_raw++;
+        work.push_back(std::move(rb));
+        cv_work.notify_one();
+        return true;
+    }
+    // ---- stage 1: inflate.  One gzip stream is sequential, but the files of a chunk (hourly files) are independent streams:
+    // up to n_inflate files are inflated concurrently, each into its own bounded queue of record chunks; the batcher below walks
+    // the files IN ORDER and cuts the concatenated record stream into batches (a batch may span two files, like the reference's
+    // TFRecordDataset(files) -> padded_batch).
+    struct FileStream {
+        std::deque<std::unique_ptr<RawBatch>> chunks;      // up to batch_size records each
+        bool done = false;
         int err = TFR_OK;
-        for (size_t fi = 0; fi < files.size() && err == TFR_OK; ++fi) {
-            if ((err = rr.open(files[fi].c_str())) != TFR_OK) { error_file = files[fi]; break; }
-            for (;;) {
-                const int r = rr.next(check_crc != 0);
+    };
+    int n_inflate = 1;
+    std::deque<FileStream> streams;            // (deque: FileStream holds move-only chunks; never reallocated after start())
+    std::vector<std::thread> th_inflate;
+    std::mutex mu_in;
+    std::condition_variable cv_in_put, cv_in_get;
+    size_t next_file = 0;
+
+    void inflate_loop() {
+        for (;;) {
+            size_t fi;
+            {
+                std::lock_guard<std::mutex> lk(mu_in);
+                if (stop || next_file >= files.size()) return;
+                fi = next_file++;
+            }
+            RecordReader rr;
+            int err = rr.open(files[fi].c_str());
+            auto ch = std::make_unique<RawBatch>();
+            auto flush = [&](bool last) -> bool {
+                std::unique_lock<std::mutex> lk(mu_in);
+                cv_in_put.wait(lk, [&] { return stop || streams[fi].chunks.size() < 4; });
+                if (stop) return false;
+                if (ch->off.size() > 1) streams[fi].chunks.push_back(std::move(ch));
+                if (last) { streams[fi].done = true; streams[fi].err = err; }
+                cv_in_get.notify_all();
+                ch = std::make_unique<RawBatch>();
+                return true;
+            };
+            while (err == TFR_OK) {
+                const long long t0 = now_ns();
+                const int r = rr.next_raw(check_crc != 0);
+                ns_inflate += now_ns() - t0;
                 if (r == TFR_EOF) break;
-                if (r != TFR_OK) { err = r; error_file = files[fi]; break; }
-                b->sessions.emplace_back();
-                const int pr = parse_session(rr.buf.data(), rr.buf.size(), sc, truncate, b->sessions.back(), tmp);
-                if (pr != TFR_OK) { err = pr; error_file = files[fi]; break; }
-                if ((int)b->sessions.size() == batch_size) {
-                    if (!push(std::move(b))) { rr.close(); return; }
-                    b = std::make_unique<Batch>();
-                }
+                if (r != TFR_OK) { err = r; break; }
+                if (ch->off.empty()) ch->off.push_back(0);
+                ch->bytes.insert(ch->bytes.end(), rr.buf.begin(), rr.buf.end());
+                ch->off.push_back(ch->bytes.size());
+                if ((int)ch->off.size() - 1 == batch_size && !flush(false)) { rr.close(); return; }
             }
             rr.close();
+            if (!flush(true)) return;
         }
-        if (err == TFR_OK && !b->sessions.empty()) push(std::move(b));      // last batch is short (no drop_remainder)
-        std::lock_guard<std::mutex> lk(mu);
-        error = err; done = true;
-        cv_get.notify_all();
     }
-    bool push(std::unique_ptr<Batch> b) {
-        int L = 0;
-        for (auto& s : b->sessions) L = std::max(L, s.len);
-        b->B = (int)b->sessions.size();
-        b->T = L - 1;                                  // inputs drop their last element (datasets.py:72-74)
-        std::unique_lock<std::mutex> lk(mu);
-        cv_put.wait(lk, [&] { return stop || (int)q.size() < prefetch; });
-        if (stop) return false;
-        q.push_back(std::move(b));
-        cv_get.notify_one();
-        return true;
+    // ---- stage 2: batcher (cheap: byte-range appends)
+    void read_loop() {
+        auto rb = std::make_unique<RawBatch>();
+        int err = TFR_OK;
+        std::string err_file;
+        for (size_t fi = 0; fi < files.size() && err == TFR_OK; ++fi) {
+            for (;;) {
+                std::unique_ptr<RawBatch> ch;
+                bool file_done = false;
+                {
+                    std::unique_lock<std::mutex> lk(mu_in);
+                    const long long t0 = now_ns();
+                    cv_in_get.wait(lk, [&] { return stop || !streams[fi].chunks.empty() || streams[fi].done; });
+                    ns_batcher_wait += now_ns() - t0;
+                    if (stop) return;
+                    if (!streams[fi].chunks.empty()) { ch = std::move(streams[fi].chunks.front()); streams[fi].chunks.pop_front(); cv_in_put.notify_all(); }
+                    else { file_done = true; if (streams[fi].err != TFR_OK) { err = streams[fi].err; err_file = files[fi]; } }
+                }
+                if (file_done) break;
+                const int n = (int)ch->off.size() - 1;
+                int i = 0;
+                while (i < n) {
+                    if (rb->off.empty()) { rb->off.push_back(0); rb->file_idx = (int)fi; }
+                    const int have = (int)rb->off.size() - 1;
+                    const int take = std::min(n - i, batch_size - have);
+                    const size_t b0 = ch->off[i], b1 = ch->off[i + take], base = rb->bytes.size();
+                    rb->bytes.insert(rb->bytes.end(), ch->bytes.begin() + b0, ch->bytes.begin() + b1);
+                    for (int k = 1; k <= take; ++k) rb->off.push_back(base + (ch->off[i + k] - b0));
+                    i += take;
+                    if ((int)rb->off.size() - 1 == batch_size) {
+                        if (!push_raw(std::move(rb))) return;
+                        rb = std::make_unique<RawBatch>();
+                    }
+                }
+            }
+        }
+        if (err == TFR_OK && rb->off.size() > 1) { if (!push_raw(std::move(rb))) return; }     // last batch is short (no drop_remainder)
+        std::lock_guard<std::mutex> lk(mu);
+        if (err != TFR_OK) fail(err, n_raw, err_file);       // everything cut before the error is still delivered
+        reader_done = true;
+        cv_work.notify_all(); cv_get.notify_all();
+    }
+    void work_loop() {
+        FeatureVal tmp;
+        for (;;) {
+            std::unique_ptr<RawBatch> rb;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !work.empty() || reader_done; });
+                if (stop || (work.empty() && reader_done)) return;
+                rb = std::move(work.front());
+                work.pop_front();
+                ++in_decode;
+            }
+            const long long t0 = now_ns();
+            auto b = std::make_unique<Batch>();
+            int err = TFR_OK;
+            const int n = (int)rb->off.size() - 1;
+            b->sessions.resize(n);
+            int L = 0;
+            for (int i = 0; i < n && err == TFR_OK; ++i) {
+                const uint8_t* p = rb->bytes.data() + rb->off[i];
+                const size_t len = rb->off[i + 1] - rb->off[i] - 4;
+                uint32_t dcrc;
+                memcpy(&dcrc, p + len, 4);
+                if (check_crc && masked_crc(p, len) != dcrc) { err = TFR_ERR_CRC; break; }
+                err = parse_session(p, len, sc, truncate, b->sessions[i], tmp);
+                L = std::max(L, b->sessions[i].len);
+            }
+            b->B = n;
+            b->T = L - 1;                                  // inputs drop their last element (datasets.py:72-74)
+            ns_decode += now_ns() - t0;
+            std::lock_guard<std::mutex> lk(mu);
+            --in_decode;
+            if (err != TFR_OK) fail(err, rb->seq, files[rb->file_idx]);
+            else ready[rb->seq] = std::move(b);
+            cv_get.notify_all();
+        }
+    }
+    void start() {
+        for (size_t i = 0; i < files.size(); ++i) streams.emplace_back();
+        for (int i = 0; i < n_inflate; ++i) th_inflate.emplace_back([this] { inflate_loop(); });
+        th_reader = std::thread([this] { read_loop(); });
+        for (int i = 0; i < n_workers; ++i) th_workers.emplace_back([this] { work_loop(); });
     }
     // TFR_OK / TFR_EOF / error
     int next() {
         std::unique_lock<std::mutex> lk(mu);
-        cv_get.wait(lk, [&] { return !q.empty() || done; });
-        if (!q.empty()) {
-            cur = std::move(q.front());
-            q.pop_front();
-            cv_put.notify_one();
-            return TFR_OK;
+        for (;;) {
+            auto it = ready.find(next_out);
+            if (it != ready.end()) {
+                cur = std::move(it->second);
+                ready.erase(it);
+                ++next_out;
+                cv_space.notify_all();
+                return TFR_OK;
+            }
+            if (error != TFR_OK && next_out >= error_seq) { cur.reset(); return error; }
+            if (reader_done && next_out >= n_raw) { cur.reset(); return TFR_EOF; }
+            cv_get.wait(lk);
         }
-        cur.reset();
-        return error != TFR_OK ? error : TFR_EOF;
     }
     ~SessionReader() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv_put.notify_all();
-        if (th.joinable()) th.join();
+        { std::lock_guard<std::mutex> lk(mu); std::lock_guard<std::mutex> lk2(mu_in); stop = true; }
+        cv_space.notify_all(); cv_work.notify_all(); cv_get.notify_all(); cv_in_put.notify_all(); cv_in_get.notify_all();
+        for (auto& t : th_inflate) if (t.joinable()) t.join();
+        if (th_reader.joinable()) th_reader.join();
+        for (auto& t : th_workers) if (t.joinable()) t.join();
+        if (getenv("CHAM_TFRECORD_STATS"))
+            fprintf(stderr, "tfrecord reader: %llu batches; inflate %.1f ms over %d threads; batcher waited %.1f ms for records, %.1f ms for "
+                            "queue space; decode %.1f ms over %d workers\n", (unsigned long long)n_raw, ns_inflate / 1e6, n_inflate,
+                    ns_batcher_wait / 1e6, ns_reader_wait / 1e6, ns_decode / 1e6, n_workers);
     }
 };
 
@@ -439,8 +604,19 @@ void* cham_sessions_open(const char* const* files, int n_files, const char* cons
     if (e != TFR_OK) return nullptr;
     r->batch_size = batch_size; r->truncate = truncate_session_length; r->check_crc = check_crc;
     r->prefetch = prefetch > 0 ? prefetch : 1;
+    // decode threads: CHAM_TFRECORD_THREADS, default min(hardware threads, 8) (datasets.py:118-120 uses cpu_count() map calls; on
+    // the GPU box several ranks share the host, and ~8 threads already decode > 500 k sessions/s)
+    int nw = 0;
+    if (const char* e = getenv("CHAM_TFRECORD_THREADS")) nw = atoi(e);
+    if (nw <= 0) { nw = (int)std::thread::hardware_concurrency(); if (nw > 8) nw = 8; if (nw < 1) nw = 1; }
+    r->n_workers = nw;
+    int ni = 0;
+    if (const char* e = getenv("CHAM_TFRECORD_INFLATE_THREADS")) ni = atoi(e);
+    if (ni <= 0) ni = nw >= 8 ? 4 : (nw >= 4 ? 2 : 1);
+    if (ni > n_files) ni = n_files;
+    r->n_inflate = ni;
     SessionReader* raw = r.release();
-    raw->th = std::thread([raw] { raw->produce(); });
+    raw->start();
     return raw;
 }
 

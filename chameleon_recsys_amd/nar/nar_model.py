@@ -78,6 +78,39 @@ class variable_store:
         _VARIABLE_STORE = self._prev
 
 
+class _PinnedRing:
+    """Page-locked staging buffers for the per-step host -> device copies: a batch's arrays are packed into one
+    pinned arena and copied with truly asynchronous DMA (a copy from pageable memory goes through the driver's bounce buffer and
+    blocks the host).  A ring of arenas; an arena is re-used only after the copies issued from it have completed (event)."""
+
+    def __init__(self, n=4, nbytes=4 << 20):
+        self.n, self.nbytes = n, nbytes
+        self.bufs, self.events, self.k, self.off = [None] * n, [None] * n, -1, 0
+
+    def begin(self, need):
+        self.k = (self.k + 1) % self.n
+        if self.events[self.k] is not None:
+            self.events[self.k].synchronize()
+        if self.bufs[self.k] is None or self.bufs[self.k].numel() < need:
+            self.bufs[self.k] = torch.empty(max(need, self.nbytes), dtype=torch.uint8, pin_memory=True)
+        self.off = 0
+
+    def stage(self, a):
+        n = a.nbytes
+        if n == 0 or self.off + n > self.bufs[self.k].numel():      # (arena sized too small: this array goes through pageable memory)
+            return torch.from_numpy(a)
+        view = self.bufs[self.k][self.off:self.off + n]
+        self.off += (n + 255) & ~255
+        t = view.view(torch.from_numpy(a).dtype).view(a.shape)
+        t.copy_(torch.from_numpy(a))
+        return t
+
+    def end(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.events[self.k] = ev
+
+
 class NARRuntime:
     """Everything that outlives a single train()/evaluate() call: weights + Adam slots in ONE flat HBM buffer,
     resident article tables (ACE matrix, metadata - re-fed from numpy every step by the reference,
@@ -150,6 +183,7 @@ class NARRuntime:
         # form so far (1.2-1.5 ms vs 0.27 + 0.60 ms; profiles/r01_notes.md item 19) - experiment switch, default off
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
+        self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
         self.fuse_mulpred = os.environ.get("CHAM_FUSE_MULPRED", "0") == "1"
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
@@ -172,6 +206,7 @@ class NARRuntime:
         self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
         # data-parallel context (set by parallel.DataParallelNAR)
         self.dp_rank, self.dp_world, self.dp_allreduce, self.dp_sharded = 0, 1, None, None
+        self.dp_early_bucket, self.dp_gather_slots, self.dp_mode = None, None, 'allreduce'
 
     # ---- views into the flat buffers
     def view(self, flat, name):
@@ -206,7 +241,14 @@ class NARRuntime:
         self._shadow_key = key
 
     def state_dict(self):
-        return {'flat': self.flat.cpu(), 'm': self.m.cpu(), 'v': self.v.cpu(), 'global_step': self.global_step}
+        """Weights + Adam slots + step.  Under the sharded / hybrid data-parallel modes a rank only maintains the slots of the
+        parameter slice it owns: they are all-gathered first (a COLLECTIVE - every rank must call state_dict()), so that any
+        rank's checkpoint resumes the same optimizer trajectory in any mode (the mode is recorded)."""
+        m, v = self.m, self.v
+        if getattr(self, 'dp_gather_slots', None) is not None:
+            m, v = self.dp_gather_slots(m, v)
+        return {'flat': self.flat.cpu(), 'm': m.cpu(), 'v': v.cpu(), 'global_step': self.global_step,
+                'dp_mode': getattr(self, 'dp_mode', 'allreduce'), 'dp_world': self.dp_world}
 
     def load_state_dict(self, sd):
         self.flat.copy_(sd['flat']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
@@ -502,6 +544,7 @@ class NARModuleModel:
         self.pop_recent_items_buffer = None
         self._dev_state = None
         self.total_loss = None
+        self._accumulating = False             # train_step_microbatched: gradients of a micro-batch are not final
         self.train = self.train_step           # the reference's ``model.train`` op
         self._eval_iter = 0
         self._eval = None
@@ -582,10 +625,13 @@ class NARModuleModel:
             else np.zeros((1, B * T), np.float32)
         # H2D copies on their own stream: queued behind the running step's kernels on the compute stream, a copy from pageable
         # host memory blocks the host until that step has finished (one implicit synchronisation per step)
-        main, up = torch.cuda.current_stream(), self.rt.upload_stream
+        main, up, ring = torch.cuda.current_stream(), self.rt.upload_stream, self.rt.pinned
+        if ring is not None:                  # page-locked staging arena for this batch's arrays (sized generously: ~3x the inputs)
+            ring.begin(256 * 40 + 3 * 8 * (aci.size + 3 * B * T + (len(L.ctx_cat_names) + len(L.ctx_num_names) + 2) * B * T))
 
         def t(a):
-            x = torch.from_numpy(np.ascontiguousarray(a))
+            a = np.ascontiguousarray(a)
+            x = ring.stage(a) if ring is not None else torch.from_numpy(a)
             if up is None:
                 return x.to(dev, non_blocking=True)
             with torch.cuda.stream(up):
@@ -613,6 +659,8 @@ class NARModuleModel:
                      ets_rows=d['event_ts'].view(-1), mask=t(mrows.astype(np.uint8)), cat=t(cat), num=t(num))
         d['uploaded'] = torch.cuda.Event()
         d['uploaded'].record(up if up is not None else main)      # consumers (forward, presample) wait for exactly the copies above
+        if ring is not None:
+            ring.end(up if up is not None else main)
         return d
 
     def _neg_sample(self, pl, d, step, k, stream):
@@ -934,6 +982,8 @@ class NARModuleModel:
             rnn_y = (lambda l: pl.rnn_drop[l]) if drop else (lambda l: pl.rnn_out[l])     # what the next layer / FC1 consumed
             rt.gemm(pl.rnn_c if pos is not None else rnn_y(last), pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
             rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
+            if rt.dp_early_bucket is not None and not self._accumulating:
+                rt.dp_early_bucket(rt.grads)     # data parallel: [Wf1 .. Ws4] gradients are final - their all-reduce starts now
             if pos is not None:          # d rnn_out back into the [B, T] layout (zero at padded steps)
                 rt.gemm(pl.dFC1, p('Wf1'), pl.drnn_c, BT, Hp, 512, 512, 512, Hp, transB=1)
                 pl.drnn.zero_()
@@ -1096,6 +1146,7 @@ class NARModuleModel:
         if getattr(rt, 'grads_acc', None) is None:
             rt.grads_acc = torch.empty_like(rt.grads)
             rt.loss_acc = torch.zeros(3, dtype=torch.float32, device=rt.device)
+        self._accumulating = True
         for k, b in enumerate(range(0, n, micro_sessions)):
             e = min(n, b + micro_sessions)
             f, l = slice_batch(features, labels, b, e)
@@ -1103,6 +1154,7 @@ class NARModuleModel:
             self.backward()
             check(rt.lib.cham_accumulate(ptr(rt.grads_acc), ptr(rt.grads), rt.layout.total, int(k == 0), _stream()), "cham_accumulate")
             check(rt.lib.cham_loss_accumulate(ptr(rt.loss_acc), ptr(self._plan.loss), int(k == 0), _stream()), "cham_loss_accumulate")
+        self._accumulating = False
         rt.grads, rt.grads_acc = rt.grads_acc, rt.grads          # Adam (and the data-parallel all-reduce) read rt.grads
         self.apply_gradients()
         self.total_loss = rt.loss_acc

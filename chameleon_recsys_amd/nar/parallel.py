@@ -58,7 +58,22 @@ class DataParallelNAR:
             raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'hybrid' or 'sparse'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
+        rt.dp_mode = self.mode
+        self._early, self._early_work = None, None
         if self.world > 1:
+            L = getattr(rt, 'layout', None)
+            # Early bucket: the session-FC and scorer kernels [Wf1 .. Ws4] are contiguous in the flat buffer and their gradients
+            # are final long before the tail of the backward pass (PreCAR backward beside the W2 weight gradient): their
+            # all-reduce is issued from the side lane as soon as they are written and overlaps with the rest of the backward
+            # (allreduce / sparse modes; matters for strong scaling, where a 32-row step is ~2 ms).  CHAM_DP_EARLY_BUCKET=0: off.
+            ents = getattr(L, 'entries', None) or {}
+            if self.mode in ("allreduce", "sparse") and os.environ.get("CHAM_DP_EARLY_BUCKET", "1") == "1" and 'Wf1' in ents and 'Ws4' in ents:
+                a, b = L.entries['Wf1'].offset, L.entries['Ws4'].offset + L.entries['Ws4'].size
+                names = [e.name for e in L.entries.values() if a <= e.offset < b]
+                if names == ['Wf1', 'Wf2', 'Ws1', 'Ws2', 'Ws3', 'Ws4']:
+                    self._early = (a, b)
+                    rt.dp_early_bucket = self._issue_early_bucket
+            rt.dp_gather_slots = self._gather_slots
             if self.mode == "sharded":
                 if rt.flat.numel() % self.world:
                     raise ValueError("flat parameter buffer (%d) does not split over %d ranks" % (rt.flat.numel(), self.world))
@@ -80,27 +95,85 @@ class DataParallelNAR:
             # identical initial weights on every rank
             dist.broadcast(rt.flat, src=0, group=self.pg)
 
+    # ---- early bucket (see __init__)
+    def _issue_early_bucket(self, flat_grads):
+        """Called by the backward pass on the lane that produced the bucket, right after its last gradient was written."""
+        a, b = self._early
+        self._early_work = dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _wait_early_bucket(self):
+        if self._early_work is not None:
+            self._early_work.wait()            # (stream-ordered for RCCL: the current stream waits for the collective)
+            self._early_work = None
+            return True
+        return False
+
+    def _ranges_without_early(self, a, b, early_done):
+        """[a, b) minus the early bucket when that one was already reduced."""
+        if not early_done:
+            return [(a, b)]
+        ea, eb = self._early
+        out = []
+        if a < min(b, ea):
+            out.append((a, min(b, ea)))
+        if max(a, eb) < b:
+            out.append((max(a, eb), b))
+        return out
+
     def _allreduce(self, flat_grads):
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+        early = self._wait_early_bucket()
+        for a, b in self._ranges_without_early(0, flat_grads.numel(), early):
+            dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
     def _sparse_allreduce(self, flat_grads):
+        """ONE collective for everything but the early bucket: [flat buffer without the item table | touched item-table rows] packed
+        into a contiguous communication buffer (round 1 issued three: prefix, suffix, rows)."""
         from .._lib import check, ptr
         rt = self.model.rt
         off, n, dim = self._item
         aci, pool = rt.dp_touched          # GLOBAL batch ids [Bg, T+1] and the candidate pool of this step (device int64)
         ids = torch.cat([aci.reshape(-1), pool.reshape(-1), pool.new_zeros(1)]).to(torch.int32)
         L = ids.numel()
-        if self._compact is None or self._compact.shape[0] < L:
-            self._compact = torch.empty(L, dim, dtype=flat_grads.dtype, device=flat_grads.device)
-        buf, table = self._compact[:L], flat_grads[off:off + n * dim]
+        early = self._wait_early_bucket()
+        ranges = self._ranges_without_early(0, off, early) + self._ranges_without_early(off + n * dim, flat_grads.numel(), early)
+        n_dense = sum(b - a for a, b in ranges)
+        need = n_dense + L * dim
+        if self._compact is None or self._compact.numel() < need:
+            self._compact = torch.empty(need, dtype=flat_grads.dtype, device=flat_grads.device)
+        comm = self._compact[:need]
+        table = flat_grads[off:off + n * dim]
         st = torch.cuda.current_stream().cuda_stream
-        check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(buf), st), "cham_rows_gather")
-        if off > 0:
-            dist.all_reduce(flat_grads[:off], op=dist.ReduceOp.SUM, group=self.pg)
-        dist.all_reduce(flat_grads[off + n * dim:], op=dist.ReduceOp.SUM, group=self.pg)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        o = 0
+        for a, b in ranges:
+            comm[o:o + b - a].copy_(flat_grads[a:b]); o += b - a
+        rows = comm[n_dense:].view(L, dim)
+        check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
+        dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
+        o = 0
+        for a, b in ranges:
+            flat_grads[a:b].copy_(comm[o:o + b - a]); o += b - a
         # duplicate ids carry identical sums: concurrent writes of the same value
-        check(rt.lib.cham_rows_scatter(ptr(buf), ptr(ids), L, dim, ptr(table), st), "cham_rows_scatter")
+        check(rt.lib.cham_rows_scatter(ptr(rows), ptr(ids), L, dim, ptr(table), st), "cham_rows_scatter")
+
+    # ---- checkpoints (ADVICE r01): in the sharded / hybrid modes a rank's Adam slots are only valid on its own slice
+    def _gather_slots(self, m, v):
+        """Full (m, v) on every rank, for NARRuntime.state_dict(): the owned slices all-gathered (no-op in the replicated modes)."""
+        if self.world == 1 or self.mode in ("allreduce", "sparse"):
+            return m, v
+        total = m.numel()
+        E = total if self.mode == "sharded" else self.emb_sharded
+        n = E // self.world
+        a = self.rank * n
+        out = []
+        for x in (m, v):
+            full = x.clone()
+            if n > 0:
+                parts = [torch.empty(n, dtype=x.dtype, device=x.device) for _ in range(self.world)]
+                dist.all_gather(parts, x[a:a + n].clone(), group=self.pg)
+                for r, t in enumerate(parts):
+                    full[r * n:(r + 1) * n].copy_(t)
+            out.append(full)
+        return out[0], out[1]
 
     def _sharded_step(self, flat_grads, flat_params, adam):
         n = flat_params.numel() // self.world

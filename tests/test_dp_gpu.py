@@ -40,7 +40,9 @@ def _run(dp_world, rank, batches, p):
         losses.append(dp.global_loss().cpu().numpy())
         st.update_from_device_batch(d['aci'], d['g_event_ts'])
     torch.cuda.synchronize()
-    return np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy(), getattr(dp, 'emb_sharded', model.rt.layout.emb_end)
+    sd = model.rt.state_dict()        # checkpoint image: a collective in the sharded / hybrid modes (gathers the Adam slots)
+    return (np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy(), getattr(dp, 'emb_sharded', model.rt.layout.emb_end),
+            sd['m'].numpy(), sd['dp_mode'])
 
 
 def _worker(rank, world, port, out_dir, mode):
@@ -49,8 +51,9 @@ def _worker(rank, world, port, out_dir, mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p = _params()
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
-    losses, flat, m, E = _run(world, rank, batches, p)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=losses, flat=flat, m=m, E=E)
+    losses, flat, m, E, m_ckpt, ckpt_mode = _run(world, rank, batches, p)
+    assert ckpt_mode == mode
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=losses, flat=flat, m=m, E=E, m_ckpt=m_ckpt)
     dist.destroy_process_group()
 
 
@@ -74,7 +77,9 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
         m_dp = r0['m']
     p = _params()
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
-    losses, flat, m, _ = _run(1, 0, batches, p)
+    losses, flat, m, _, _, _ = _run(1, 0, batches, p)
+    # a checkpoint written by ANY rank holds the complete Adam slots, whatever the exchange mode
+    assert np.array_equal(r0['m_ckpt'], m_dp) and np.array_equal(r1['m_ckpt'], m_dp)
     assert np.abs(losses - r0['losses']).max() < 2e-5, (losses, r0['losses'])
     # the sum of two row shards' gradients differs from the single-process gradient in the last bits (fp32 summation order);
     # every kernel of the step is deterministic (no float atomics), so that is the only difference

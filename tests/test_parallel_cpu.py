@@ -115,13 +115,21 @@ def _mode_worker(rank, world, port, out_dir, mode):
     torch.set_num_threads(1)
     g0 = torch.Generator().manual_seed(0)
 
+    class _E:
+        def __init__(self, name, offset, size):
+            self.name, self.offset, self.size = name, offset, size
+
     class _Layout:
         emb_end = _N_EMB
+        # the session-FC / scorer kernels are contiguous (the early all-reduce bucket of parallel.DataParallelNAR)
+        entries = {n: _E(n, o, sz) for n, o, sz in (('emb', 0, _N_EMB), ('W2', _N_EMB, 500), ('Wf1', 2000, 300), ('Wf2', 2300, 200),
+                                                    ('Ws1', 2500, 100), ('Ws2', 2600, 60), ('Ws3', 2660, 40), ('Ws4', 2700, 20),
+                                                    ('b1', 2720, _N_TOTAL - 2720))}
 
     class _RT:
         flat = torch.randn(_N_TOTAL, generator=g0) if rank == 0 else torch.zeros(_N_TOTAL)     # broadcast must replicate rank 0
         layout = _Layout()
-        dp_rank = dp_world = dp_allreduce = dp_sharded = None
+        dp_rank = dp_world = dp_allreduce = dp_sharded = dp_early_bucket = dp_gather_slots = None
 
     class _Model:
         rt = _RT()
@@ -134,9 +142,14 @@ def _mode_worker(rank, world, port, out_dir, mode):
         if rt.dp_sharded is not None:
             rt.dp_sharded(grads, rt.flat, adam)
         else:
+            if mode == "allreduce":
+                assert rt.dp_early_bucket is not None and dp._early == (2000, 2720)
+                if step != 1:                                  # (step 1: no early issue - the whole buffer goes in one collective)
+                    rt.dp_early_bucket(grads)                  # what the backward pass does once [Wf1 .. Ws4] are final
             rt.dp_allreduce(grads)
             adam(0, _N_TOTAL, grads, 0)
-    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), flat=rt.flat.numpy(), m=m.numpy())
+    m_full, _ = rt.dp_gather_slots(m, m.clone())               # checkpoint path: full Adam slots on every rank
+    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), flat=rt.flat.numpy(), m=m.numpy(), m_full=m_full.numpy())
     dist.destroy_process_group()
 
 
@@ -153,6 +166,8 @@ def test_exchange_modes_match_single_process_step(tmp_path, mode):
     got = [np.load(str(tmp_path / ("%s_rank%d.npz" % (mode, r)))) for r in range(world)]
     for r in range(world):
         assert np.allclose(got[r]['flat'], flat.numpy(), atol=1e-6), (mode, r)      # every rank ends with the full updated parameters
+    for r in range(world):      # NARRuntime.state_dict(): the gathered slots are complete on every rank in every mode
+        assert np.allclose(got[r]['m_full'], m.numpy(), atol=1e-6), (mode, r)
     owned = np.zeros(_N_TOTAL)
     for r in range(world):
         owned += (got[r]['m'] != 0)

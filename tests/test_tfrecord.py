@@ -246,3 +246,52 @@ def test_export_and_resolve_files(tmp_path):
     assert list(chunks(list(range(5)), 2)) == [[0, 1], [2, 3], [4]]
     n = sum(len(f['session_id']) for f, _ in datasets.SessionDataset(out, cfg, batch_size=7))
     assert n == 25
+
+
+@pytest.mark.parametrize("threads,inflate", [(1, 1), (3, 2), (8, 4)])
+def test_threaded_reader_keeps_stream_order_across_files(tmp_path, monkeypatch, threads, inflate):
+    """The reader pipeline (parallel inflate of the chunk's files -> batcher -> pool of decode workers -> reorder buffer,
+    csrc/host/tfrecord.cpp) must hand out exactly the batches of the sequential tf.data pipeline it replaces (datasets.py:118-142):
+    stream order, batches spanning file boundaries, a short last batch - for any thread count."""
+    from chameleon_recsys_amd.nar import config, datasets, synthetic, tf_records_management as tfm
+    scfg = config.get_session_features_config_gcom(500)
+    files, sessions = [], []
+    sid = 0
+    for hour, n in enumerate([37, 5, 64, 1, 90, 23]):              # sizes that are no multiples of the batch size
+        ss = synthetic.make_sessions(n, 12, 500, scfg, 3, hour, 'g1', sid)
+        sid += n
+        sessions += ss
+        path = str(tmp_path / ("h%02d.tfrecord.gz" % hour))
+        tfm.save_rows_to_tf_record_file(ss, scfg, path)
+        files.append(path)
+    monkeypatch.setenv("CHAM_TFRECORD_THREADS", str(threads))
+    monkeypatch.setenv("CHAM_TFRECORD_INFLATE_THREADS", str(inflate))
+    got_ids, got_first, n_batches = [], [], 0
+    for f, l in datasets.SessionDataset(files, scfg, batch_size=16, truncate_sequence_length=10):
+        got_ids += f['session_id'].tolist()
+        got_first += f['item_clicked'][:, 0].tolist()
+        assert f['item_clicked'].shape[0] == (16 if n_batches < 13 else 12)       # 220 sessions = 13 x 16 + 12
+        n_batches += 1
+    assert n_batches == 14
+    assert got_ids == [s['session_id'] for s in sessions]
+    assert got_first == [int(s['item_clicked'][0]) for s in sessions]
+
+
+def test_threaded_reader_reports_a_corrupt_record_after_the_good_batches(tmp_path, monkeypatch):
+    from chameleon_recsys_amd._tfrecord import TFRecordError
+    from chameleon_recsys_amd.nar import config, datasets, synthetic, tf_records_management as tfm
+    import gzip
+    scfg = config.get_session_features_config_gcom(500)
+    good = str(tmp_path / "a.tfrecord.gz"); bad = str(tmp_path / "b.tfrecord.gz")
+    tfm.save_rows_to_tf_record_file(synthetic.make_sessions(40, 12, 500, scfg, 3, 0, 'g1', 0), scfg, good)
+    tfm.save_rows_to_tf_record_file(synthetic.make_sessions(40, 12, 500, scfg, 3, 1, 'g1', 40), scfg, bad)
+    raw = bytearray(gzip.open(bad).read())
+    raw[len(raw) // 2] ^= 0xFF                                     # flip one data byte: the record's CRC no longer matches
+    with gzip.open(bad, 'wb') as fh:
+        fh.write(bytes(raw))
+    monkeypatch.setenv("CHAM_TFRECORD_THREADS", "4")
+    seen = 0
+    with pytest.raises(TFRecordError):
+        for f, l in datasets.SessionDataset([good, bad], scfg, batch_size=8, truncate_sequence_length=10):
+            seen += f['item_clicked'].shape[0]
+    assert 40 <= seen < 80                                          # every batch before the corrupt record was delivered
