@@ -328,6 +328,15 @@ def main():
         dt = float(tt.item())
     loss = dp.global_loss().cpu().numpy()
 
+    # ---- host-side cost of submitting a step (Python + ctypes + HIP launches, no synchronisation): what bounds the step once the GPU
+    # is faster than the host (bf16 / short ragged batches)
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for i in range(3):
+        one_step(args.warmup + args.steps + 100 + i)
+    host_enqueue_ms = (time.perf_counter() - t_h) / 3 * 1e3
+    torch.cuda.synchronize()
+
     # ---- roofline leg: HIP-event timing of every GEMM launch over a few extra steps -------------------------
     rt.profile = []
     nprof = 3
@@ -434,6 +443,7 @@ def main():
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
+                       "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

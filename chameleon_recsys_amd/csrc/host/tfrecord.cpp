@@ -604,11 +604,12 @@ void* cham_sessions_open(const char* const* files, int n_files, const char* cons
     if (e != TFR_OK) return nullptr;
     r->batch_size = batch_size; r->truncate = truncate_session_length; r->check_crc = check_crc;
     r->prefetch = prefetch > 0 ? prefetch : 1;
-    // decode threads: CHAM_TFRECORD_THREADS, default min(hardware threads, 8) (datasets.py:118-120 uses cpu_count() map calls; on
-    // the GPU box several ranks share the host, and ~8 threads already decode > 500 k sessions/s)
+    // decode threads: CHAM_TFRECORD_THREADS, default min(hardware threads, 16) (datasets.py:118-120 uses cpu_count() map calls; on
+    // the GPU box 8 ranks share 256 host cores; 16 decode + 4 inflate threads: 369 k full-length / 981 k G1-like sessions/s,
+    // profiles/r02_decode_throughput.json)
     int nw = 0;
     if (const char* e = getenv("CHAM_TFRECORD_THREADS")) nw = atoi(e);
-    if (nw <= 0) { nw = (int)std::thread::hardware_concurrency(); if (nw > 8) nw = 8; if (nw < 1) nw = 1; }
+    if (nw <= 0) { nw = (int)std::thread::hardware_concurrency(); if (nw > 16) nw = 16; if (nw < 1) nw = 1; }
     r->n_workers = nw;
     int ni = 0;
     if (const char* e = getenv("CHAM_TFRECORD_INFLATE_THREADS")) ni = atoi(e);

@@ -718,7 +718,16 @@ class NARModuleModel:
             torch.cuda.current_stream().wait_event(ps[3])
         else:
             self._neg_sample(pl, d, step, pl._samp_cur, s)
-        rt.dp_touched = (d['aci'], pl.pool)       # item rows this step can touch on ANY rank (parallel.py, mode "sparse")
+        if rt.dp_mode == 'sparse' and rt.dp_world > 1:
+            # item rows this step can touch on ANY rank (parallel.py, mode "sparse"): GLOBAL clicked ids + candidate pool + pad item,
+            # as int32 row indices in a buffer of the plan (nothing is allocated or freed around the collective)
+            n1 = d['aci'].numel()
+            if getattr(pl, 'touched', None) is None or pl.touched.numel() < n1 + pmax + 1:
+                pl.touched = torch.zeros(n1 + pmax + 1, dtype=torch.int32, device=rt.device)
+            pl.touched[:n1].copy_(d['aci'].reshape(-1))
+            pl.touched[n1:n1 + pmax].copy_(pl.pool)
+            pl.touched[n1 + pmax:n1 + pmax + 1].zero_()
+            rt.dp_touched = pl.touched[:n1 + pmax + 1]
         neg_ids, neg_slot = pl.neg_ids, pl.neg_slot
         if pos is not None:
             neg_ids, neg_slot = pl.neg_ids_c, pl.neg_slot_c
@@ -970,6 +979,24 @@ class NARModuleModel:
             e_dZ2c = e_halfB
         else:
             e_dZ2c = mark()              # dZ2c final + dpred
+        # The candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only): the largest GEMM of the backward, ENQUEUED BEFORE the
+        # side lane's long launch sequence below - in the bf16 configuration the GPU keeps up with the host, and the ~25 launches of the
+        # side block (0.5-0.8 ms of host time) left this lane idle for that long (kernel-trace timeline, profiles/r02_notes.md);
+        # NT layout on the 256x256 tile.  (CHAM_DGRAD_NN=1: transpose W2 once and run it in the NN layout - faster stand-alone,
+        # slower inside the step; profiles/r01_notes.md item 10)
+        if rt.dgrad_nn:
+            check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
+        if b16:
+            rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY)
+        for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
+            if r1 <= r0 or b16:
+                continue
+            if ev is not None:
+                main_wait(ev)
+            if rt.dgrad_nn:
+                rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
+            else:
+                rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
         with side(e_dZ2c):
@@ -1039,22 +1066,6 @@ class NARModuleModel:
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
                     rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BTf, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
                 rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn%d/b' % l))
-        # ... beside the candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only): the largest GEMM of the backward,
-        # NT layout on the 256x256 tile.  (CHAM_DGRAD_NN=1: transpose W2 once and run it in the NN layout - faster stand-alone,
-        # slower inside the step; profiles/r01_notes.md item 10)
-        if rt.dgrad_nn:
-            check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
-        if b16:
-            rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY)
-        for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
-            if r1 <= r0 or b16:
-                continue
-            if ev is not None:
-                main_wait(ev)
-            if rt.dgrad_nn:
-                rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
-            else:
-                rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
         def precar_backward(ws):
             """PreCAR combine scatter, W1 weight gradients, feature / embedding backward (on whatever lane is current)."""
             st = _stream()

@@ -131,8 +131,11 @@ class DataParallelNAR:
         from .._lib import check, ptr
         rt = self.model.rt
         off, n, dim = self._item
-        aci, pool = rt.dp_touched          # GLOBAL batch ids [Bg, T+1] and the candidate pool of this step (device int64)
-        ids = torch.cat([aci.reshape(-1), pool.reshape(-1), pool.new_zeros(1)]).to(torch.int32)
+        # GLOBAL clicked ids + candidate pool + pad item of this step: int32 row indices in a buffer of the StepPlan, written by
+        # forward().  (Round 2 finding: building the list here from temporaries - torch.cat(...).to(int32), freed when this function
+        # returns - gave GPU memory-access faults with 8 ranks and the asynchronous state update; nothing is allocated or freed
+        # around the collective any more.  profiles/r02_notes.md)
+        ids = rt.dp_touched
         L = ids.numel()
         early = self._wait_early_bucket()
         ranges = self._ranges_without_early(0, off, early) + self._ranges_without_early(off + n * dim, flat_grads.numel(), early)
