@@ -94,23 +94,29 @@ __global__ __launch_bounds__(ST_THREADS) void k_state_buffer_update(
         buf_ids[k] = k < total ? new_ids[k] : 0;
         buf_ts[k] = k < total ? new_ts[k] : 0;
     }
-    if (tid == 0) *n_valid = total;
+    if (tid == 0) { n_valid[0] = total; n_valid[1] = 0; }       // [1]: clicks counted into recent_pop (k_state_hist)
 }
 
-__global__ __launch_bounds__(256) void k_state_hist(const int64_t* __restrict__ buf_ids, const int32_t* __restrict__ n_valid,
+__global__ __launch_bounds__(256) void k_state_hist(const int64_t* __restrict__ buf_ids, int32_t* __restrict__ n_valid,
                                                     int32_t* __restrict__ recent_pop, int n_items) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < *n_valid) {
+    bool counted = false;
+    if (i < n_valid[0]) {
         const int64_t id = buf_ids[i];
-        if (id > 0 && id < n_items) atomicAdd(&recent_pop[id], 1);
+        counted = id > 0 && id < n_items;
+        if (counted) atomicAdd(&recent_pop[id], 1);
     }
+    // the denominator of pop_norm is sum(recent_pop) (clicked_items_state.py:242-246): the clicks that were COUNTED - a retained
+    // buffer row with a zero id (zero-padding that survives the time window when timestamps are tiny) is not one of them
+    const unsigned long long m = __ballot(counted);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_valid[1], __popcll(m));
 }
 // pop_norm = max(recent_pop / (sum(recent_pop) + 1), 1 / recent_clicks_for_normalization)  in float64, fed as float32 (:242-246)
 __global__ __launch_bounds__(256) void k_state_pop_norm(const int32_t* __restrict__ recent_pop, const int32_t* __restrict__ n_valid,
                                                         int n_items, double min_norm, float* __restrict__ pop_norm) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_items) {
-        const double v = (double)recent_pop[i] / (double)(*n_valid + 1);
+        const double v = (double)recent_pop[i] / (double)(n_valid[1] + 1);
         pop_norm[i] = (float)(v > min_norm ? v : min_norm);
     }
 }
@@ -128,7 +134,8 @@ extern "C" size_t cham_state_workspace_bytes(int B, int buffer_size) {
 }
 
 // One state update from a batch that is already in HBM.  buf_ids/buf_ts [buffer_size] (newest first, zero padded),
-// recent_pop [n_items] int32, pop_norm [n_items] float32, articles_pop [n_items] int64, n_valid: device scalar.
+// recent_pop [n_items] int32, pop_norm [n_items] float32, articles_pop [n_items] int64, n_valid: device int32[2] = {rows retained in
+// the buffer, clicks counted into recent_pop}.
 extern "C" int cham_state_update(const int64_t* aci, const int64_t* event_ts, int B, int T, double buffer_hours,
                                  int64_t* buf_ids, int64_t* buf_ts, int buffer_size, int32_t* recent_pop, float* pop_norm,
                                  int64_t* articles_pop, int n_items, int for_norm, int32_t* n_valid, void* workspace,

@@ -167,7 +167,7 @@ class DeviceClickedItemsState(_ColdStartBookkeeping):
         self.articles_pop = t.zeros(n, dtype=t.int64, device=dev)
         # _update_recent_pop_norm(zeros): max(0 / 1, 1 / for_norm)
         self.pop_norm = t.full((n,), float(np.float32(1.0 / self.recent_clicks_for_normalization)), dtype=t.float32, device=dev)
-        self.n_valid = t.zeros(1, dtype=t.int32, device=dev)
+        self.n_valid = t.zeros(2, dtype=t.int32, device=dev)      # {rows retained in the buffer, clicks counted into recent_pop}
         self.n_updates = 0
         self._reset_cold_start()
         self._after_host_side_change()

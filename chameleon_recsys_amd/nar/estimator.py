@@ -104,6 +104,7 @@ class Estimator:
         seed = self.config.tf_random_seed
         self._store = dict(runtime=None, tf_random_seed=42 if seed is None else int(seed))
         self._last_ckpt_time = time.time()
+        self.warm_start_from = warm_start_from
         self.steps_per_sec = None
         if self.model_dir:
             os.makedirs(self.model_dir, exist_ok=True)
@@ -117,9 +118,19 @@ class Estimator:
         return p if p and os.path.exists(p) else None
 
     def _maybe_restore(self, created_now):
-        """A freshly created runtime (first call in this process) is restored from model_dir when a checkpoint exists."""
-        if created_now and self.latest_checkpoint():
-            sd = torch.load(self.latest_checkpoint(), map_location="cpu", weights_only=False)
+        """A freshly created runtime (first call in this process) is restored from model_dir when a checkpoint exists - or, failing
+        that, from ``warm_start_from`` (a checkpoint file or a model_dir; the reference copies a previous job's checkpoint into
+        model_dir for that, nar_trainer_gcom.py:450-459).  Checkpoints hold tensors, ints and strings only: ``weights_only=True``."""
+        if not created_now:
+            return
+        path = self.latest_checkpoint()
+        if path is None and self.warm_start_from:
+            w = self.warm_start_from
+            path = os.path.join(w, "model.ckpt.pt") if os.path.isdir(w) else w
+            if not os.path.exists(path):
+                raise FileNotFoundError("warm_start_from: no checkpoint at %s" % path)
+        if path is not None:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
             self._store['runtime'].load_state_dict(sd)
 
     def save_checkpoint(self):

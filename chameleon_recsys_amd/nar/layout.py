@@ -165,6 +165,14 @@ class ParamLayout:
             elif seen_nonreg:
                 raise AssertionError("regularised tensors must come first")
 
+    def fingerprint(self):
+        """Hash of (name, shape, offset) of every tensor of the flat buffer + cell type: stored in checkpoints."""
+        import hashlib
+        h = hashlib.sha1(("%s|%d|" % (self.cell, self.total)).encode())
+        for e in self.entries.values():
+            h.update(("%s:%s@%d;" % (e.name, "x".join(map(str, e.shape)), e.offset)).encode())
+        return h.hexdigest()
+
     # ------------------------------------------------------------------ descriptors
     def _desc(self, cols):
         d = np.zeros((len(cols), 5), dtype=np.int64)

@@ -149,6 +149,10 @@ class NARRuntime:
         meta = params['articles_metadata']
         self.ace = torch.from_numpy(ace).to(dev)
         self.created = torch.from_numpy(np.ascontiguousarray(meta['created_at_ts'], dtype=np.int64)).to(dev)
+        for n in L.meta_names:      # metadata columns live in ONE int64 table: a float-valued numerical article feature would be truncated
+            if acfg[n]['type'] == 'numerical' and not np.issubdtype(np.asarray(meta[n]).dtype, np.integer):
+                raise NotImplementedError("numerical (float) article metadata feature %r: only integer-valued article features are built "
+                                          "(the shipped G1 / Adressa configs have categorical metadata only)" % n)
         if L.meta_names:
             mc = np.stack([np.asarray(meta[n], dtype=np.int64) for n in L.meta_names])
         else:
@@ -248,9 +252,15 @@ class NARRuntime:
         if getattr(self, 'dp_gather_slots', None) is not None:
             m, v = self.dp_gather_slots(m, v)
         return {'flat': self.flat.cpu(), 'm': m.cpu(), 'v': v.cpu(), 'global_step': self.global_step,
-                'dp_mode': getattr(self, 'dp_mode', 'allreduce'), 'dp_world': self.dp_world}
+                'dp_mode': getattr(self, 'dp_mode', 'allreduce'), 'dp_world': self.dp_world, 'layout': self.layout.fingerprint()}
 
     def load_state_dict(self, sd):
+        """Restores weights + Adam slots; refuses a checkpoint written for another parameter layout (a changed feature config, cell
+        type or CAR / RNN width with the same element count would otherwise be restored into the wrong offsets)."""
+        if sd.get('layout') is not None and sd['layout'] != self.layout.fingerprint():
+            raise ValueError("checkpoint was written for a different parameter layout (feature config / rnn_cell / sizes changed)")
+        if tuple(sd['flat'].shape) != tuple(self.flat.shape):
+            raise ValueError("checkpoint holds %d parameters, the model %d" % (sd['flat'].numel(), self.flat.numel()))
         self.flat.copy_(sd['flat']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.global_step = int(sd['global_step'])
         self.weights_version += 1

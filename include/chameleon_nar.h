@@ -214,7 +214,8 @@ int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t
  * hook's flattening nar_model.py:1635-1646.  aci [B,T+1] = concat(item_clicked, label_last_item), event_ts [B,T] (both
  * already in HBM); buf_ids / buf_ts [buffer_size] newest first, zero padded; recent_pop [n_items] int32; pop_norm [n_items]
  * float32 = float32(max(recent_pop / (sum + 1), 1 / for_norm)) computed in float64; articles_pop [n_items] int64;
- * n_valid = device scalar (number of valid buffer entries).  Bit-identical to the reference class. */
+ * n_valid = device int32[2]: {rows retained in the buffer, clicks counted into recent_pop (the denominator of pop_norm is their
+ * number + 1, clicked_items_state.py:242-246)}.  Bit-identical to the reference class. */
 size_t cham_state_workspace_bytes(int B, int buffer_size);
 int cham_state_update(const int64_t* aci, const int64_t* event_ts, int B, int T, double buffer_hours, int64_t* buf_ids,
                       int64_t* buf_ts, int buffer_size, int32_t* recent_pop, float* pop_norm, int64_t* articles_pop, int n_items,

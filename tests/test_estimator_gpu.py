@@ -109,6 +109,19 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     res1 = est.evaluate(input_fn(files[4]))
     assert abs(res1['loss'] - res2['loss']) < 1e-6 and res1['hitrate_at_n'] == res2['hitrate_at_n']
     torch.cuda.synchronize()
+    # warm start (nar_trainer_gcom.py:450-459): a fresh model_dir starts from another job's checkpoint
+    from chameleon_recsys_amd.nar.estimator import Estimator, RunConfig
+    est3 = Estimator(est._model_fn, model_dir=str(tmp_path / "model_warm"), config=RunConfig(tf_random_seed=42), params=est.params,
+                     warm_start_from=str(tmp_path / "model"))
+    res3 = est3.evaluate(input_fn(files[4]))
+    assert est3.global_step == est.global_step and abs(res3['loss'] - res1['loss']) < 1e-6
+    # a checkpoint written for another parameter layout is refused (same flat size would otherwise load silently)
+    rt = est._store['runtime']
+    sd = rt.state_dict()
+    assert set(sd) >= {'flat', 'm', 'v', 'global_step', 'layout', 'dp_mode'}
+    sd['layout'] = 'deadbeef'
+    with pytest.raises(ValueError):
+        rt.load_state_dict(sd)
 
 
 def test_trainer_main_cli_end_to_end(gpu, tmp_path):
