@@ -20,6 +20,7 @@ _SIGNATURES = {
     "cham_norm_stats_from_rows": (c_int, [P, P, P, c_int, P, P]),
     "cham_row_weights": (c_int, [P, c_int, P, c_size_t, c_int, P, P, P, P]),
     "cham_item_assemble": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "cham_item_assemble_lds": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, c_int, P, c_int, P, P, P, P, P, P]),
     "cham_feature_bwd": (c_int, [P, P, c_int, c_int, P, P, P]),
     "cham_emb_grad_scan": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "cham_group_rows_workspace_bytes": (c_size_t, [c_int]),

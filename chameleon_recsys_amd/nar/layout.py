@@ -193,6 +193,24 @@ class ParamLayout:
                 out.append((kind, feat, c - sub, dim, ent.shape[0], ent.offset))
         return out
 
+    def item_segments(self):
+        """(segs [n, 6] int64, singles int32) for cham_item_assemble_lds: runs of item columns that come from ONE contiguous source
+        row - kind 0 ACE, 1 item embedding, 2 metadata embedding - as {kind, dst column, length, table offset, row pitch, feature}; the
+        remaining columns (one-hot bits, numerics, recency, novelty, zero padding) are listed in `singles`."""
+        segs, singles, c = [], [], 0
+        cols = self._item_cols
+        while c < len(cols):
+            kind, feat, sub, dim, ent = cols[c]
+            if kind == COL_ACE and sub == 0:
+                segs.append((0, c, dim, 0, dim, 0)); c += dim
+            elif kind == COL_ITEMEMB and sub == 0:
+                segs.append((1, c, dim, ent.offset, dim, 0)); c += dim
+            elif kind == COL_EMB and sub == 0:
+                segs.append((2, c, dim, ent.offset, dim, feat)); c += dim
+            else:
+                singles.append(c); c += 1
+        return (np.asarray(segs, dtype=np.int64).reshape(-1, 6), np.asarray(singles, dtype=np.int32))
+
     def ctx_emb_groups(self):
         return self._emb_groups(self._ctx_cols)
 

@@ -160,6 +160,11 @@ class NARRuntime:
         self.meta_cat = torch.from_numpy(np.ascontiguousarray(mc)).to(dev)
         self.ctx_desc = torch.from_numpy(L.ctx_descriptors()).to(dev)
         self.ctx_emb_groups, self.item_emb_groups = L.ctx_emb_groups(), L.item_emb_groups()
+        segs, singles = L.item_segments()
+        self.item_segs, self.n_item_segs = torch.from_numpy(np.ascontiguousarray(segs)).to(dev), int(segs.shape[0])
+        self.item_singles, self.n_item_singles = torch.from_numpy(np.ascontiguousarray(singles)).to(dev), int(singles.shape[0])
+        # item rows through LDS tiles (csrc/features.hip k_item_assemble_lds); CHAM_ITEM_ASSEMBLE_LDS=0: one thread per element
+        self.item_lds = os.environ.get("CHAM_ITEM_ASSEMBLE_LDS", "1") == "1" and L.Fi * 4 * 8 <= 64 * 1024
         self.item_desc = torch.from_numpy(L.item_descriptors()).to(dev)
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
@@ -773,10 +778,17 @@ class NARModuleModel:
                       "cham_norm_stats_from_rows")
         check(lib.cham_ctx_assemble(ptr(d['cat']), ptr(d['num']), BT, ptr(rt.ctx_desc), Fc, ptr(rt.flat), ptr(p('gamma_ctx')),
                                     ptr(p('beta_ctx')), ptr(pl.Xc_raw), ptr(pl.Xc_s), s), "cham_ctx_assemble")
-        check(lib.cham_item_assemble(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
-                                     ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
-                                     ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
-              "cham_item_assemble")
+        if rt.item_lds:
+            check(lib.cham_item_assemble_lds(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
+                                             ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.item_segs),
+                                             rt.n_item_segs, ptr(rt.item_singles) if rt.n_item_singles else None, rt.n_item_singles,
+                                             ptr(rt.flat), ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
+                  "cham_item_assemble_lds")
+        else:
+            check(lib.cham_item_assemble(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
+                                         ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
+                                         ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
+                  "cham_item_assemble")
         rt.refresh_shadows()
         drop = self.is_training and self.keep_prob < 1.0
         pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])

@@ -61,6 +61,15 @@ int cham_item_assemble(const int64_t* ids, int R, int g1_begin, int g2_begin, co
                        const float* ace, int ld_ace, const float* rec_raw, const float* nov_raw, const float* stats,
                        const int64_t* desc, int F, const float* params, const float* gamma, const float* beta, float* xraw,
                        float* xs, void* stream);
+/* the same item rows assembled through LDS tiles (csrc/features.hip k_item_assemble_lds): every row is a few contiguous source
+ * segments (ACE row, item-embedding row, metadata-embedding rows) copied with lane-contiguous loads into an LDS image and streamed
+ * out with 16-byte stores.  segs [n_segs][6] int64 = {kind 0 ACE / 1 item embedding / 2 metadata embedding, destination column,
+ * length, offset of the table in `params`, row pitch, metadata feature}; singles [n_singles] = columns no segment covers (one-hot
+ * bits, numerics, recency, novelty: decoded through `desc`).  F % 4 == 0. */
+int cham_item_assemble_lds(const int64_t* ids, int R, int g1_begin, int g2_begin, const int64_t* meta_cat, int n_items,
+                           const float* ace, int ld_ace, const float* rec_raw, const float* nov_raw, const float* stats,
+                           const int64_t* desc, int F, const int64_t* segs, int n_segs, const int32_t* singles, int n_singles,
+                           const float* params, const float* gamma, const float* beta, float* xraw, float* xs, void* stream);
 /* backward of the two above, scale/center part (nar_model.py:887-907): dgamma[c] = sum_r dxs[r,c] * xraw[r,c], dbeta[c] = sum_r dxs[r,c] */
 int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, void* stream);
 
@@ -71,7 +80,7 @@ int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* d
  *  - cham_emb_grad_scan: small tables (context / metadata embeddings), one workgroup per table row scanning the R source keys;
  *    key(r) = keysrc[r] (ids == NULL) or keysrc[ids[r]] (article metadata of item rows);
  *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows ranks the rows by (id, row) (depends on the
- *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key; ids >= 0, R < 2^20, dim <= 256. */
+ *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key; ids >= 0, R < 2^20, dim <= 512. */
 int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
                        const int64_t* ids, int cardinality, float* table_grad, void* stream);
 size_t cham_group_rows_workspace_bytes(int R);

@@ -74,6 +74,36 @@ def main():
             times.append(dt); adam_ms.append(e0.elapsed_time(e1))
     step_s = float(np.mean(times))
     adam_bytes = 28.0 * L.total
+    # ---- gather / scatter of the last micro-batch's item rows, stand-alone (HIP events): HBM-bound stages of the step
+    pl, lib = model._plan, rt.lib
+    RV, Fi, BT = 2 * pl.P + pl.pmax + 1, L.Fi, pl.P
+    s_ = torch.cuda.current_stream().cuda_stream
+    src_row_bytes = 4.0 * (L.D + sum(int(sg[2]) for sg in rt.item_segs.cpu().numpy() if sg[0] != 0))     # ACE + embedding rows read per item row
+    gather_bytes = RV * (src_row_bytes + 2 * 4.0 * Fi)                                                    # + raw and scaled rows written
+
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    pg, pb = rt.p('gamma_item'), rt.p('beta_item')
+    ms_lds = timed(lambda: check(lib.cham_item_assemble_lds(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
+                                                            ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.item_segs),
+                                                            rt.n_item_segs, ptr(rt.item_singles), rt.n_item_singles, ptr(rt.flat), ptr(pg), ptr(pb),
+                                                            ptr(pl.Xi_raw), ptr(pl.Xi_s), s_), "lds"))
+    ms_elem = timed(lambda: check(lib.cham_item_assemble(ptr(pl.ids_all), RV, BT, 2 * BT, ptr(rt.meta_cat), rt.n_items, ptr(rt.ace), L.D,
+                                                         ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
+                                                         ptr(pg), ptr(pb), ptr(pl.Xi_raw), ptr(pl.Xi_s), s_), "elementwise"))
+    grp = [g for g in rt.item_emb_groups if g[0] == 5][0]          # (kind, feat, c0, dim, rows, offset) of the item-embedding table
+    ms_group = timed(lambda: check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.group_ws), pl.group_ws.numel() * 4, s_), "group"))
+    ms_scatter = timed(lambda: check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, grp[2], grp[3], ptr(pg), ptr(pl.ids_all), ptr(pl.perm),
+                                                               rt.grads.data_ptr() + 4 * grp[5], s_), "grouped"))
+    scatter_bytes = RV * 4.0 * grp[3] * 2                           # read the rows' embedding-gradient columns, write one table row per distinct id (<= RV)
+    roof = lambda by, ms: dict(bound="hbm", algorithmic_bytes=by, ms=round(ms, 4), achieved_gbs=round(by / (ms * 1e-3) / 1e9, 1),
+                               peak_gbs=HBM_PEAK_GBS, frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     out = dict(workload="large-catalog stress (BASELINE.json configs[4])", n_items=args.n_items, ace_dim=args.ace_dim,
                batch=args.batch, negatives=args.neg, micro_batch_sessions=args.micro, params=int(L.total),
                item_embedding_dim=L.entries['items_embedding'].shape[1], setup_s=round(setup_s, 1),
@@ -81,7 +111,12 @@ def main():
                hbm_gb_allocated=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                adam=dict(bound="hbm", algorithmic_bytes=adam_bytes, ms=round(float(np.mean(adam_ms)), 3),
                          achieved_gbs=round(adam_bytes / (np.mean(adam_ms) * 1e-3) / 1e9, 1), peak_gbs=HBM_PEAK_GBS,
-                         frac=round(adam_bytes / (np.mean(adam_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)))
+                         frac=round(adam_bytes / (np.mean(adam_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+               item_rows_per_micro_batch=int(RV),
+               gather_lds_tiles=dict(kernel="k_item_assemble_lds (ACE / embedding rows -> LDS tile -> 16-byte row stores, raw + scaled)", **roof(gather_bytes, ms_lds)),
+               gather_one_thread_per_element=dict(kernel="k_item_assemble (round-1 form)", **roof(gather_bytes, ms_elem)),
+               embedding_gradient=dict(kernel="k_rank_keys + k_perm_from_rank (%.3f ms, integer ranking of the rows by id) + k_emb_grad_grouped "
+                                              "(deterministic segment sums, no float atomics)" % ms_group, **roof(scatter_bytes, ms_scatter)))
     print(json.dumps(out), flush=True)
 
 

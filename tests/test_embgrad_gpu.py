@@ -13,7 +13,7 @@ def _s():
 
 
 @pytest.mark.parametrize("R,n_items,dim,F,c0", [(10729, 46000, 117, 408, 288), (3000, 500, 44, 112, 8), (70, 1000, 256, 260, 4),
-                                                (23457, 5000000, 16, 96, 0)])
+                                                (23457, 5000000, 16, 96, 0), (4000, 3000, 378, 520, 140)])
 def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
