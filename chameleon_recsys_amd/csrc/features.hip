@@ -344,12 +344,12 @@ __global__ __launch_bounds__(NTH) void k_emb_grad_grouped(const float* __restric
     const bool cok = cb < ncb && sub < dim;
     float a = 0.f;
     int m = stripe;
-    for (; m + 3 * S < len; m += 4 * S) {
-        float x[4];
+    for (; m + 7 * S < len; m += 8 * S) {                 // 8 independent row loads in flight per wave
+        float x[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + u * S] * F + c0 + sub] : 0.f;
+        for (int u = 0; u < 8; ++u) x[u] = cok ? dxs[(size_t)rows[m + u * S] * F + c0 + sub] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a += x[u];
+        for (int u = 0; u < 8; ++u) a += x[u];
     }
     for (; m < len; m += S) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
     part[w][lane] = a;

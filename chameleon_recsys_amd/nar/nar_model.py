@@ -169,7 +169,6 @@ class NARRuntime:
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
-        import os
         self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
         self.aux_stream = torch.cuda.Stream(device=dev, priority=-1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane

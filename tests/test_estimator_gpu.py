@@ -105,6 +105,8 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     est2 = T.build_estimator(str(tmp_path / "model"), ace, meta, acfg, scfg)
     res2 = est2.evaluate(input_fn(files[4]))
     assert est2.global_step == est.global_step == len(cap.losses) + len(cap2.losses)
+    import copy
+    st_again = copy.deepcopy(st)       # (evaluation leaves articles_recent_pop_norm un-restored, like the reference: clicked_items_state.py:61-79)
     T.clicked_items_state = st
     res1 = est.evaluate(input_fn(files[4]))
     assert abs(res1['loss'] - res2['loss']) < 1e-6 and res1['hitrate_at_n'] == res2['hitrate_at_n']
@@ -113,6 +115,7 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     from chameleon_recsys_amd.nar.estimator import Estimator, RunConfig
     est3 = Estimator(est._model_fn, model_dir=str(tmp_path / "model_warm"), config=RunConfig(tf_random_seed=42), params=est.params,
                      warm_start_from=str(tmp_path / "model"))
+    T.clicked_items_state = st_again
     res3 = est3.evaluate(input_fn(files[4]))
     assert est3.global_step == est.global_step and abs(res3['loss'] - res1['loss']) < 1e-6
     # a checkpoint written for another parameter layout is refused (same flat size would otherwise load silently)
