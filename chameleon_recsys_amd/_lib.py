@@ -58,9 +58,6 @@ _SIGNATURES = {
     "cham_rows_gather": (c_int, [P, P, c_long, c_int, P, P]),
     "cham_rows_scatter": (c_int, [P, P, c_long, c_int, P, P]),
     "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
-    "cham_gemm_mulpred_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "cham_gemm_mulpred_bwd_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int,
-                                          P, c_size_t, P]),
     "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, c_float, P, P, P, P]),
     "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, c_float, P, P, P, P, P]),
     "cham_rank_items": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),

@@ -53,7 +53,6 @@ struct GemmParams {
     int accumulate;
     int kchunk; int splits; float* partial;
     int nbm, nbn;
-    float* aux; int aux_slots;      // EPI 7: per-(row tile, position group) column sums [nbm][aux_slots][N]
     int xcd_split;                  // split-K workgroup placement: one K-split per XCD (see the kernels' tile mapping)
 };
 
@@ -171,6 +170,10 @@ __host__ __device__ constexpr bool g_sched_hint_static() { return WM * WN <= 4 &
 static int g_pipe = 1;          // (the non-pipelined K loop was an A/B arm: neutral, removed; profiles/r01_notes.md item 9)
 
 // Shared epilogue of the fp32 and bf16 kernels (the 32x32 MFMA C/D layout is dtype independent).
+// (Round 2 tried the swapped-operand form - accumulator = C^T, one row and 4 x 4 consecutive columns per lane, 16-byte stores, as in
+// gemm_b16.hip: bit-identical results, 0-8 % SLOWER stand-alone on every G1 shape including the K <= 128 scorer GEMMs, because the
+// dword form already writes whole 128-byte lines (32 consecutive columns per instruction).  profiles/r02_notes.md item 3, which also
+// records the gfx950 store hazard found on the way.)
 // EPI: 0 = plain / accumulate, 1 = bias+leaky, 2 = bias+tanh, 3 = *leaky'(dref), 4 = *tanh'(dref), 5 = bias only,
 //      6 = split-K partial store
 template <int EPI, int TM, int TN>
@@ -265,108 +268,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx16 (&ac
 //     aux[...]   = sum over the rows of g inside this tile of dM[r, c] * z[r, c]      (-> dpred, finished by k_mulpred_finalize)
 // The column sums are deterministic: every wave row (64 rows) parks its dM*z values in LDS in turn, one thread per column walks
 // the rows in order and writes one value per (tile, position, column) - no float atomics.  N must be a multiple of BN.
-template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void mulpred_epilogue(const GemmParams& p, floatx16 (&acc)[TM][TN], float* __restrict__ lds, int tile_m,
-                                                 int m0, int n0, int wm0, int wn0, int kl, int fl) {
-    constexpr int QR = BM / WM, LDP = BN + 1;          // rows per wave row, LDS row stride
-    static_assert(TM * 32 == QR, "a wave row is TM MFMA tiles high");
-    const int limM = p.M - m0, NC = p.rs_div;
-    const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
-    const __amdgpu_buffer_rsrc_t zw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
-    const int g_first = m0 / NC;
-    const __amdgpu_buffer_rsrc_t pw = make_window(p.rs + (size_t)g_first * p.ldrs + n0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned col = (unsigned)(wn0 + j * 32 + fl);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {              // 8 elements (two blocks of 4 consecutive rows) at a time: the epilogue must stay
-                float z[8], pa[2], pb[2];              // under 128 VGPRs (2 workgroups per CU) - it is a latency / bandwidth-bound pass
-                unsigned offs[8];
-                int remb[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int rowb = wm0 + i * 32 + 8 * (2 * h + b) + 4 * kl;
-                    const int gb = (m0 + rowb) / NC;
-                    remb[b] = (m0 + rowb) - gb * NC;
-                    const bool okb = rowb < limM;
-                    const unsigned po = okb ? ((unsigned)(gb - g_first) * (unsigned)p.ldrs + col) * 4u : OOB_OFF;
-                    pa[b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pw, po, 0, 0));                   // pred of the block's first row
-                    // ... of the next position, only when one of the block's (valid) rows belongs to it
-                    const bool cross = okb && remb[b] + 3 >= NC && rowb + (NC - remb[b]) < limM;
-                    pb[b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pw, cross ? po : OOB_OFF, p.ldrs * 4, 0));
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = rowb + k;
-                        const bool ok = row < limM;
-                        offs[b * 4 + k] = ok ? ((unsigned)row * (unsigned)p.ldc + col) * 4u : OOB_OFF;
-                        z[b * 4 + k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zw, ok ? ((unsigned)row * (unsigned)p.ldr + col) * 4u : OOB_OFF, 0, 0));
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = (2 * h + b) * 4 + k;
-                        const float v = acc[i][j][e], zz = z[b * 4 + k];
-                        const float pr = (remb[b] + k >= NC) ? pb[b] : pa[b];       // (NC >= 4 rows never span three positions; NC < 4: below)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * pr * (1.f - zz * zz)), cw, offs[b * 4 + k], 0, 0);
-                        acc[i][j][e] = v * zz;             // (z = 0 beyond the last row: OOB loads return 0)
-                    }
-                __builtin_amdgcn_sched_barrier(0);     // (the scheduler would hoist every load of the tile to the top and spill)
-            }
-        }
-    // ---- per-position column sums of dM * z
-    const int tid = threadIdx.x, wave_m = wm0 / QR;
-    float run = 0.f;
-    int cur_g = g_first, nxt = (g_first + 1) * NC, grow = m0;        // walker state (threads < BN), carried across the wave rows
-    for (int q = 0; q < WM; ++q) {
-        if (wave_m == q) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        lds[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl) * LDP + wn0 + j * 32 + fl] = acc[i][j][e];
-        }
-        __syncthreads();
-        if (tid < BN) {
-#pragma unroll 1
-            for (int r0 = 0; r0 < QR; r0 += 16) {
-                float v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = lds[(r0 + k) * LDP + tid];      // 16 independent reads in flight
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (grow == nxt && grow < p.M) {     // first row of the next position (rows beyond M add zeros to the last one)
-                        p.aux[((size_t)tile_m * p.aux_slots + (cur_g - g_first)) * p.N + n0 + tid] = run;
-                        ++cur_g; nxt += NC; run = 0.f;
-                    }
-                    run += v[k];
-                    ++grow;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < BN) p.aux[((size_t)tile_m * p.aux_slots + (cur_g - g_first)) * p.N + n0 + tid] = run;
-}
-
-// dpred[g, c] = (sum of the tiles' partial column sums of position g) * (1 - pred[g, c]^2)
-__global__ __launch_bounds__(256) void k_mulpred_finalize(const float* __restrict__ aux, int slots, int N, int NC, int BM,
-                                                          const float* __restrict__ pred, int ldp, float* __restrict__ dpred, int ldd) {
-    const int g = blockIdx.x;
-    const int t0 = (g * NC) / BM, t1 = (g * NC + NC - 1) / BM;
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float v = 0.f;
-        for (int t = t0; t <= t1; ++t) v += aux[((size_t)t * slots + (g - (t * BM) / NC)) * N + c];
-        const float pr = pred[(size_t)g * ldp + c];
-        dpred[(size_t)g * ldd + c] = v * (1.f - pr * pr);
-    }
-}
-
 // EPI: see gemm_epilogue
 // ABL (ablation bits, probe builds only - tests/probe_gemm.hip): 1 = no global loads / LDS writes inside the K loop,
 // 2 = no barrier inside the K loop, 4 = no LDS fragment reads, 8 = minimal epilogue.  0 in the product library.
@@ -403,7 +304,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: SGPR tile offsets)
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
     floatx16 acc[TM][TN];
@@ -519,24 +420,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
         return;
     }
 
-    if constexpr (EPI == 7) {
-        mulpred_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, smem, tile_m, m0, n0, wm0, wn0, kl, fl);
-        return;
-    } else {
-        gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
-    }
+    gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE, int ABL = 0, bool RS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
     gemm_f32_body<BM, BN, WM, WN, BK, AK, BKC, EPI, PIPE, ABL, RS>(p);
 }
-// the fused-epilogue instance is a latency / bandwidth-bound pass: capped at 128 VGPRs so that two workgroups share a CU
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, 4) void gemm_f32_kernel_occ2(GemmParams p) {
-    gemm_f32_body<BM, BN, WM, WN, BK, AK, BKC, EPI, true, 0, false>(p);
-}
-
 
 // =====================================================================================================================
 // bf16-input variant (BASELINE config 3: "bf16 compute, fp32 master weights + fp32 softmax / loss / Adam").
@@ -695,7 +585,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmParams p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: SGPR tile offsets)
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
     floatx16 acc[TM][TN];
@@ -878,47 +768,6 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 
 static int g_variant = -1;     // -1 = automatic
 extern "C" void cham_gemm_set_variant(int v) { g_variant = v; }
-// C[M,N] = (A[M,K] B[N,K]^T) (.) pred[row / NC] (.) (1 - Z^2);  dpred[g] = (sum_{rows of g} (A B^T) (.) Z) (.) (1 - pred[g]^2)
-// = the scorer's first-layer dgrad + the backward of `cand (.) pred` + the CAR tanh derivative in one pass (see mulpred_epilogue).
-extern "C" size_t cham_gemm_mulpred_bwd_workspace_bytes(int M, int N, int NC) {
-    if (M <= 0 || N <= 0 || NC <= 0) return 0;
-    return (size_t)((M + 255) / 256) * (size_t)(256 / NC + 2) * (size_t)N * sizeof(float);
-}
-extern "C" int cham_gemm_mulpred_bwd_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                                         const float* Z, int ldz, const float* pred, int ldp, int NC, float* dpred, int lddp,
-                                         float* workspace, size_t workspace_bytes, void* stream) {
-    if (!A || !B || !C || !Z || !pred || !dpred || !workspace || M <= 0 || N <= 0 || K <= 0 || NC <= 0) return -CHAM_ERR_ARG;
-    if ((lda & 3) || (ldb & 3) || (K & 3) || (N % 128) || (M % NC) || NC < 4) return -CHAM_ERR_ARG;    // (4 consecutive rows span <= 2 positions)
-    if (workspace_bytes < cham_gemm_mulpred_bwd_workspace_bytes(M, N, NC)) return -CHAM_ERR_ARG;
-    if ((size_t)lda * 4 * 256 >= WINDOW_BYTES || (size_t)ldb * 4 * 256 >= WINDOW_BYTES || (size_t)ldc * 4 * 256 >= WINDOW_BYTES ||
-        (size_t)ldz * 4 * 256 >= WINDOW_BYTES || (size_t)ldp * 4 * (256 / NC + 2) >= WINDOW_BYTES)
-        return -CHAM_ERR_ARG;
-    GemmParams p;
-    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.bias = nullptr; p.act = 0; p.dref = Z; p.ldr = ldz; p.dact = 0;
-    p.rs = pred; p.ldrs = ldp; p.rs_div = NC; p.accumulate = 0; p.partial = nullptr;
-    p.kchunk = ((K + 31) / 32) * 32; p.splits = 1;
-    p.aux = workspace; p.aux_slots = 256 / NC + 2; p.xcd_split = 0;
-    p.nbm = (M + 255) / 256; p.nbn = N / 128;
-    hipStream_t st = (hipStream_t)stream;
-    using LA = TileLoader<256, 16, true, 512>;
-    using LB = TileLoader<128, 16, true, 512>;
-    size_t smem = (size_t)2 * 16 * (LA::LD + LB::LD) * sizeof(float);
-    const size_t need = (size_t)64 * 129 * sizeof(float);          // one wave row of dM*z values
-    if (smem < need) smem = need;
-    auto k = gemm_f32_kernel_occ2<256, 128, 4, 2, 16, true, true, 7>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
-    hipLaunchKernelGGL(k_mulpred_finalize, dim3(M / NC), dim3(256), 0, st, workspace, p.aux_slots, N, NC, 256, pred, ldp, dpred, lddp);
-    CHAM_CHECK_LAUNCH();
-    return CHAM_OK;
-}
-
 template <bool AK, bool BKC>
 static int launch_by_shape(GemmParams& p, hipStream_t st) {
     if (p.N > 64) {
@@ -1013,7 +862,7 @@ static int gemm_dispatch(int precision, const float* A, int lda, int transA, con
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.act = act; p.dref = dref; p.ldr = ldr; p.dact = dact;
     p.rs = rowscale; p.ldrs = ldrs; p.rs_div = rs_div > 0 ? rs_div : 1;
-    p.accumulate = accumulate; p.partial = workspace; p.aux = nullptr; p.aux_slots = 0; p.xcd_split = 0;
+    p.accumulate = accumulate; p.partial = workspace; p.xcd_split = 0;
     int splits = 1;
     if (splits_hint != 1 && workspace) {
         // long-reduction / small-output shapes (wgrad): fill >= ~1024 workgroups

@@ -131,9 +131,10 @@ template <int ACT> __device__ __forceinline__ float b16_act(float v) {
 }
 
 // EPI: 0 plain (fp32 out: optional accumulate), 1 bias+leaky, 2 bias+tanh, 3 x leaky'(dref), 4 x tanh'(dref), 5 bias, 6 split-K partial
-template <int BM, int BN, int WM, int WN, bool AK, bool BKC, int EPI, bool OUTF32>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_b16_kernel(B16Params p) {
-    constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
+// MINW: __launch_bounds__ second argument = waves per SIMD the register allocation must leave room for (1 = no constraint)
+template <int BM, int BN, int WM, int WN, int BK, int MINW, bool AK, bool BKC, int EPI, bool OUTF32>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_b16_kernel(B16Params p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
     using LA = Stage16<BM, BK, AK, NTH>;
     using LB = Stage16<BN, BK, BKC, NTH>;
     constexpr int ASZ = AK ? BM * LA::LD : BK * LA::LD, BSZ = BKC ? BN * LB::LD : BK * LB::LD;
@@ -295,15 +296,14 @@ extern "C" void cham_gemm_b16_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_b16_launches[i]; if (reset && i < 5) g_b16_launches[i] = 0; }
 }
 
-template <int BM, int BN, int WM, int WN, bool AK, bool BKC, int EPI, bool OUTF32>
+template <int BM, int BN, int WM, int WN, int BK, int MINW, bool AK, bool BKC, int EPI, bool OUTF32>
 static int b16_launch_epi(B16Params& p, hipStream_t st) {
-    constexpr int BK = 32;
     using LA = Stage16<BM, BK, AK, WM * WN * 64>;
     using LB = Stage16<BN, BK, BKC, WM * WN * 64>;
     constexpr int ASZ = AK ? BM * LA::LD : BK * LA::LD, BSZ = BKC ? BN * LB::LD : BK * LB::LD;
     const size_t smem = (size_t)2 * (ASZ + BSZ) * 2;
     g_b16_launches[5] = OUTF32; g_b16_launches[6] = EPI; g_b16_launches[7] = p.splits;
-    auto k = gemm_b16_kernel<BM, BN, WM, WN, AK, BKC, EPI, OUTF32>;
+    auto k = gemm_b16_kernel<BM, BN, WM, WN, BK, MINW, AK, BKC, EPI, OUTF32>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -315,7 +315,7 @@ static int b16_launch_epi(B16Params& p, hipStream_t st) {
     return CHAM_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool AK, bool BKC>
+template <int BM, int BN, int WM, int WN, int BK, int MINW, bool AK, bool BKC>
 static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStream_t st) {
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
@@ -324,7 +324,7 @@ static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStrea
         if (p.splits > 1) {
             static const bool tile_major = getenv("CHAM_GEMM_SPLIT_TILE_MAJOR") != nullptr;
             p.xcd_split = (p.splits % 8 == 0 && !tile_major) ? 1 : 0;
-            const int rc = b16_launch_epi<BM, BN, WM, WN, AK, BKC, 6, true>(p, st);
+            const int rc = b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 6, true>(p, st);
             if (rc != CHAM_OK) return rc;
             const size_t n4 = (size_t)p.M * p.N / 4;
             int blocks = (int)((n4 + 255) / 256);
@@ -334,22 +334,22 @@ static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStrea
             CHAM_CHECK_LAUNCH();
             return CHAM_OK;
         }
-        return b16_launch_epi<BM, BN, WM, WN, AK, BKC, 0, true>(p, st);
+        return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, true>(p, st);
     }
     if (p.splits > 1 || p.accumulate) return -CHAM_ERR_ARG;
     if (p.dref) {
         if (p.bias || act != ACT_NONE || out_f32) return -CHAM_ERR_ARG;
-        if (dact == ACT_LEAKY) return b16_launch_epi<BM, BN, WM, WN, AK, BKC, 3, false>(p, st);
-        if (dact == ACT_TANH) return b16_launch_epi<BM, BN, WM, WN, AK, BKC, 4, false>(p, st);
+        if (dact == ACT_LEAKY) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 3, false>(p, st);
+        if (dact == ACT_TANH) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 4, false>(p, st);
         return -CHAM_ERR_ARG;
     }
     if (p.bias) {
-        if (act == ACT_LEAKY) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, AK, BKC, 1, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, AK, BKC, 1, false>(p, st);
-        if (act == ACT_TANH) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, AK, BKC, 2, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, AK, BKC, 2, false>(p, st);
-        return out_f32 ? b16_launch_epi<BM, BN, WM, WN, AK, BKC, 5, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, AK, BKC, 5, false>(p, st);
+        if (act == ACT_LEAKY) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 1, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 1, false>(p, st);
+        if (act == ACT_TANH) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 2, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 2, false>(p, st);
+        return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 5, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 5, false>(p, st);
     }
     if (act != ACT_NONE) return -CHAM_ERR_ARG;
-    return out_f32 ? b16_launch_epi<BM, BN, WM, WN, AK, BKC, 0, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, AK, BKC, 0, false>(p, st);
+    return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, false>(p, st);
 }
 
 template <bool AK, bool BKC>
@@ -362,14 +362,20 @@ static int b16_by_shape(B16Params& p, int act, int dact, int out_f32, hipStream_
         // 785 vs 707 TFLOP/s stand-alone); the NT epilogues push that instance past 256 VGPRs and it loses (425 vs 653)
         if (v == 1 && !AK && p.splits > 1) v = 2;
         if (g_b16_variant >= 0) v = g_b16_variant;
-        ++g_b16_launches[v];
-        if (v == 1) return b16_launch_cfg<256, 128, 4, 2, AK, BKC>(p, act, dact, out_f32, st);
-        if (v == 2) return b16_launch_cfg<256, 128, 2, 2, AK, BKC>(p, act, dact, out_f32, st);
-        return b16_launch_cfg<128, 128, 2, 2, AK, BKC>(p, act, dact, out_f32, st);
+        ++g_b16_launches[v < 3 ? v : 2];
+        if (v == 1) return b16_launch_cfg<256, 128, 4, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
+        if (v == 2) return b16_launch_cfg<256, 128, 2, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
+#ifdef CHAM_B16_TUNING      // experimental instances (tests/bench_gemm_b16.py; build with -DCHAM_B16_TUNING)
+        if (v == 3) return b16_launch_cfg<256, 128, 2, 2, 32, 2, AK, BKC>(p, act, dact, out_f32, st);       // 128x64 per wave, <= 256 VGPRs
+        if (v == 4) return b16_launch_cfg<256, 128, 4, 2, 64, 1, AK, BKC>(p, act, dact, out_f32, st);       // BK = 64
+        if (v == 5) return b16_launch_cfg<256, 256, 4, 2, 32, 2, AK, BKC>(p, act, dact, out_f32, st);       // 256x256, 128x64 per wave
+        if (v == 6) return b16_launch_cfg<256, 256, 4, 2, 64, 1, AK, BKC>(p, act, dact, out_f32, st);       // 256x256, BK = 64
+#endif
+        return b16_launch_cfg<128, 128, 2, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
     }
-    if (p.N > 32) { ++g_b16_launches[3]; return b16_launch_cfg<256, 64, 4, 1, AK, BKC>(p, act, dact, out_f32, st); }
+    if (p.N > 32) { ++g_b16_launches[3]; return b16_launch_cfg<256, 64, 4, 1, 32, 1, AK, BKC>(p, act, dact, out_f32, st); }
     ++g_b16_launches[4];
-    return b16_launch_cfg<256, 32, 4, 1, AK, BKC>(p, act, dact, out_f32, st);
+    return b16_launch_cfg<256, 32, 4, 1, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
 }
 
 // C[M,N] (+)= epi(op(A) op(B)) with bf16 operands resident in HBM.

@@ -187,12 +187,9 @@ class NARRuntime:
         # - measured neutral (16.95-17.13 ms both ways; 64 splits 17.6 ms): experiment switch, default off
         self.tail_on_side = os.environ.get("CHAM_TAIL_ON_SIDE", "0") == "1"
         self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
-        # fused scorer-dgrad + mulpred epilogue (cham_gemm_mulpred_bwd_f32): correct and deterministic but slower than the two-pass
-        # form so far (1.2-1.5 ms vs 0.27 + 0.60 ms; profiles/r01_notes.md item 19) - experiment switch, default off
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
         self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
-        self.fuse_mulpred = os.environ.get("CHAM_FUSE_MULPRED", "0") == "1"
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
             self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
@@ -340,24 +337,6 @@ class NARRuntime:
         out = (ctypes.c_longlong * 8)()
         self.lib.cham_gemm_b16_launch_counts(out, 0)
         return list(out)
-
-    def gemm_mulpred_bwd(self, dS1, Ws1, dZ2c, Z2c, pred, dpred, Rc, C, K, NC):
-        """Scorer layer-1 dgrad fused with the backward of `cand (.) pred` and the CAR tanh (csrc/gemm.hip mulpred_epilogue).
-        Returns False when the fused instance does not apply (bf16 mode, workspace too small) - the caller runs the two-pass form."""
-        ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
-        if self.gemm_dtype != 'f32' or not self.fuse_mulpred or C % 128 or NC < 4 or \
-                self.lib.cham_gemm_mulpred_bwd_workspace_bytes(Rc, C, NC) > ws.numel() * 4:
-            return False
-        prof = self.profile
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        check(self.lib.cham_gemm_mulpred_bwd_f32(ptr(dS1), K, ptr(Ws1), K, ptr(dZ2c), C, Rc, C, K, ptr(Z2c), C, ptr(pred), C, NC,
-                                                 ptr(dpred), C, ptr(ws), ws.numel() * 4, _stream()), "cham_gemm_mulpred_bwd_f32")
-        if prof is not None:
-            e1.record()
-            prof.append(dict(M=Rc, N=C, K=K, transA=0, transB=1, splits=1, act=0, dref=True, ev=(e0, e1)))
-        return True
 
     def colsum(self, X, ld, R, F, out, w=None, accumulate=0, b16=False):
         ws = self.colsum_ws_side if torch.cuda.current_stream() == self.side_stream else self.colsum_ws
@@ -953,11 +932,10 @@ class NARModuleModel:
             Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
-        fused = (not b16) and (not (on and rt.split_mulpred and BT >= 256)) and \
-            rt.gemm_mulpred_bwd(pl.dS1, p('Ws1'), dZ2c, Z2c, pl.pred, pl.dpred, Rc, C, 128, NC)
+        fused = False      # (round 1's fused scorer-dgrad + mulpred epilogue measured slower than the two passes and was removed in round 2)
         if b16:
             rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
-        elif not fused:
+        else:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         with side(e_start, e_dS1):
             if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)

@@ -196,13 +196,6 @@ int cham_rows_scatter(const void* src, const int32_t* pos, long n_rows, int word
 
 /* --- K5 scoring tail + sampled softmax + masked NLL: nar_model.py:478-517, 639-667 */
 int cham_mulpred_bwd(float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* stream);
-/* the same backward fused into the scorer's first-layer dgrad GEMM (nar_model.py:478-486 backward of `cand * pred`, :395 tanh'):
- * C[M,N] = (A[M,K] B[N,K]^T) * pred[row / NC] * (1 - Z^2);  dpred[g] = (sum over the NC rows of position g of (A B^T) * Z) * (1 - pred[g]^2).
- * N % 128 == 0, M % NC == 0, NC >= 4; workspace >= cham_gemm_mulpred_bwd_workspace_bytes(M, N, NC); deterministic (no float atomics) */
-size_t cham_gemm_mulpred_bwd_workspace_bytes(int M, int N, int NC);
-int cham_gemm_mulpred_bwd_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                              const float* Z, int ldz, const float* pred, int ldp, int NC, float* dpred, int lddp,
-                              float* workspace, size_t workspace_bytes, void* stream);
 /* novelty_reg_factor > 0 adds the novelty regulariser of nar_model.py:673-683 to the per-click loss:
  * - factor * sum_n softmax(s_neg / tau)_n * (-log2 pop_norm[neg_ids[n]])  (neg_ids [BT,N], pop_norm [n_items], nov_aux [BT,3]
  * scratch carried from forward to backward; all three may be NULL when the factor is 0) */

@@ -42,14 +42,17 @@ def bench(name, M, N, K, mode, variant, **kw):
     lib.cham_gemm_b16_set_variant(-1)
 
 
-for v in (0, 1, 2):
+variants = [int(x) for x in os.environ.get("B16_VARIANTS", "0,1,2").split(",")]
+for v in variants:
     bench("CAR fwd NT bias+tanh", R, 1024, 1024, 'nt', v, bias=True, act=2)
     bench("CAR dgrad NT x leaky'", R, 1024, 1024, 'nt', v, dref=True, dact=1)
     bench("W2 wgrad TN split-K", 1024, 1024, R, 'tn', v, out_f32=1, splits=0)
-    bench("scorer L1 fwd NT K=1024 N=128", R, 128, 1024, 'nt', v, bias=True, act=1)
-    bench("scorer L1 dgrad NT K=128", R, 1024, 128, 'nt', v)
-    bench("Ws1 wgrad TN", 1024, 128, R, 'tn', v, out_f32=1, splits=0)
-bench("scorer L2 fwd NT N=64", R, 64, 128, 'nt', -1, bias=True, act=1)
-bench("scorer L3 fwd NT N=32", R, 32, 64, 'nt', -1, bias=True, act=1)
-bench("scorer L2 dgrad", R, 128, 64, 'nt', -1, dref=True, dact=1)
-bench("scorer L3 dgrad", R, 64, 32, 'nt', -1, dref=True, dact=1)
+    if v <= 2:
+        bench("scorer L1 fwd NT K=1024 N=128", R, 128, 1024, 'nt', v, bias=True, act=1)
+        bench("scorer L1 dgrad NT K=128", R, 1024, 128, 'nt', v)
+        bench("Ws1 wgrad TN", 1024, 128, R, 'tn', v, out_f32=1, splits=0)
+if os.environ.get("B16_SMALL", "1") == "1":
+    bench("scorer L2 fwd NT N=64", R, 64, 128, 'nt', -1, bias=True, act=1)
+    bench("scorer L3 fwd NT N=32", R, 32, 64, 'nt', -1, bias=True, act=1)
+    bench("scorer L2 dgrad", R, 128, 64, 'nt', -1, dref=True, dact=1)
+    bench("scorer L3 dgrad", R, 64, 32, 'nt', -1, dref=True, dact=1)

@@ -130,47 +130,6 @@ def test_bf16_rowscale(gpu):
     assert _run(gpu, 256, 128, 51 * 40, transA=1, rowscale=51, splits=0, bf16=True) < 5e-5
 
 
-@pytest.mark.parametrize("G,NC,N,K", [(37, 11, 128, 128), (300, 51, 256, 128), (5, 201, 128, 64), (1, 51, 1024, 128), (700, 4, 128, 32)])
-def test_fused_mulpred_backward_gemm(gpu, G, NC, N, K):
-    """cham_gemm_mulpred_bwd_f32: C = (A B^T) * pred[row / NC] * (1 - Z^2) and dpred[g] = (sum_rows (A B^T) * Z) * (1 - pred^2) - the
-    scorer layer-1 dgrad fused with the `cand * pred` / tanh backward - against float64; position groups straddle the 256-row
-    tiles and the 64-row wave rows for every NC here; deterministic (two runs bit-equal)."""
-    from chameleon_recsys_amd import _lib
-    from chameleon_recsys_amd._lib import check, ptr
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(G * 7 + NC)
-    M = G * NC
-    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
-    Z, pred = torch.tanh(torch.randn(M, N, generator=g)), torch.tanh(torch.randn(G, N, generator=g))
-    dM = A.double() @ B.double().t()
-    grp = torch.arange(M) // NC
-    C_ref = dM * pred.double()[grp] * (1 - Z.double() ** 2)
-    dp_ref = torch.zeros(G, N, dtype=torch.float64).index_add_(0, grp, dM * Z.double()) * (1 - pred.double() ** 2)
-    dA, dB, dZ, dP = A.to(gpu), B.to(gpu), Z.to(gpu), pred.to(gpu)
-    need = lib.cham_gemm_mulpred_bwd_workspace_bytes(M, N, NC)
-    ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=gpu)
-    outs = []
-    for _ in range(2):
-        C = torch.full((M, N), float('nan'), device=gpu)
-        dp = torch.full((G, N), float('nan'), device=gpu)
-        ws.fill_(float('nan'))
-        check(lib.cham_gemm_mulpred_bwd_f32(ptr(dA), K, ptr(dB), K, ptr(C), N, M, N, K, ptr(dZ), N, ptr(dP), N, NC, ptr(dp), N,
-                                            ptr(ws), ws.numel() * 4, torch.cuda.current_stream().cuda_stream), "fused")
-        torch.cuda.synchronize()
-        outs.append((C.cpu(), dp.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    C, dp = outs[0][0].double(), outs[0][1].double()
-    assert float((C - C_ref).abs().max()) < 2e-5 * max(1.0, float(C_ref.abs().max()))
-    assert float((dp - dp_ref).abs().max()) < 2e-5 * max(1.0, float(dp_ref.abs().max()))
-    # argument checks
-    assert lib.cham_gemm_mulpred_bwd_f32(ptr(dA), K, ptr(dB), K, ptr(C), N, M - 1, N, K, ptr(dZ), N, ptr(dP), N, NC, ptr(dp), N,
-                                         ptr(ws), ws.numel() * 4, None) == -22                      # M not a multiple of NC
-    assert lib.cham_gemm_mulpred_bwd_f32(ptr(dA), K, ptr(dB), K, ptr(C), N, M, N, K, ptr(dZ), N, ptr(dP), N, NC, ptr(dp), N,
-                                         ptr(ws), 16, None) == -22                                  # workspace too small
-    assert lib.cham_gemm_mulpred_bwd_f32(ptr(dA), K, ptr(dB), K, ptr(C), N, 3 * G, N, K, ptr(dZ), N, ptr(dP), N, 3, ptr(dp), N,
-                                         ptr(ws), ws.numel() * 4, None) == -22                      # NC < 4
-
-
 # ---- the instances the benchmarked step actually runs on (VERDICT r01 weak #1) ---------------------------------------------------------
 # launch_by_shape sends a GEMM to the 256x128 tile when M*N >= 2^20 and the grid has >= 256 workgroups, to 256x256 when
 # additionally (NT or TN) K >= 512, M >= 1024, N >= 512.  The cases below are the G1-shape step's GEMMs at 72 sessions (69 768
