@@ -30,6 +30,7 @@ ADRESSA = dict(n_items=13000, ace_dim=250, seq_len=30, batch=256, neg=100, neg_f
                C=1024, H=256, dataset='adressa', rnn_cell='gru', rnn_num_layers=2, softmax_temperature=0.2, lr=3e-4,
                reg_weight_decay=1e-4)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+X3_MATRIX_PEAK_TFLOPS = 2500.0 / 6    # fp32 GEMM as six bf16-plane products per fp32 product (csrc/gemm_x3.hip): the bf16 dense peak / 6
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PFLOP/s headline includes 2:1 sparsity)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 
@@ -88,6 +89,10 @@ def gemm_symbol(r):
     if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
         return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
+        bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
+        rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
+        return "void gemm_x3_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
     bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
     rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
     if r['bf16']:
@@ -98,7 +103,7 @@ def gemm_symbol(r):
 EPI_NAMES = {0: "plain", 1: "bias+leaky", 2: "bias+tanh", 3: "x leaky'", 4: "x tanh'", 5: "bias", 6: "split-K partials (+ reduce kernel)"}
 
 
-def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, state="device"):
+def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, state="device", gemm_dtype="f32"):
     """SURVEY 8d's metric: sessions/sec through the drop-in boundary - GZIP TFRecord session files -> input_fn
     (datasets.prepare_dataset_iterator: C++ codec + prefetch) -> Estimator.train -> nar_module_model_fn -> hooks, host buffers
     handed over every step (H2D copies included), >= 50 warm-up steps excluded, steady state over >= 200 steps (the checkpoint
@@ -125,7 +130,7 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
                 '--train_total_negative_samples', str(cfg['neg']), '--train_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
                 '--eval_total_negative_samples', str(cfg['neg']), '--eval_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
                 '--content_embedding_scale_factor', '6.0', '--disable_eval_benchmarks', '--model_dir', os.path.join(d, 'model'),
-                '--clicked_items_state', state]
+                '--clicked_items_state', state, '--gemm_dtype', gemm_dtype]
         T.FLAGS = T.define_flags().parse_args(argv)
         meta_df, ace = T.load_acr_module_resources(csv, pkl)
         ace = T.l2_normalize_rows(ace) * np.float32(6.0)
@@ -224,7 +229,7 @@ def main():
                     help="g1 = BASELINE.json configs[1] (the headline); adressa = configs[3] (2-layer GRU, 100 negatives); tiny = configs[0]")
     ap.add_argument("--length-dist", default="full", choices=["full", "g1"],
                     help="full: every session has seq_len clicks (no padded rows); g1: G1-like ragged lengths")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32_native", "bf16"],
                     help="f32: exact fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16-rounded GEMM operands, fp32 accumulate/"
                          "storage/softmax/loss/Adam (BASELINE configs[2] arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -373,18 +378,21 @@ def main():
         mode = "NN" if not r['transA'] and not r['transB'] else ("TN (wgrad)" if r['transA'] else
                                                                  ("NT (dgrad)" if r['dref'] or not r['bias'] else "NT (forward, transposed weight shadow)"))
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
-            sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else "fp32", mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
+            sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else
+            ("fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])
 
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else FP32_MATRIX_PEAK_TFLOPS
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if e['r'].get('x3') else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
                 "mfma_peak_tflops": peak, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4)}
     DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
     n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
+    dom_x3 = bool(dom['r'] and dom['r'].get('x3'))
+    dom_peak = X3_MATRIX_PEAK_TFLOPS if dom_x3 else FP32_MATRIX_PEAK_TFLOPS
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
     traffic, traffic_src = None, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
@@ -436,18 +444,25 @@ def main():
         out = {
             "metric": "NAR training sessions/sec", "value": round(Bg * args.steps / dt, 2), "unit": "sessions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": {"g1": "G1-shape synthetic (BASELINE.json configs[1])", "tiny": "G1-tiny synthetic (configs[0])",
                                     "adressa": "Adressa-shape synthetic (BASELINE.json configs[3])"}[args.config],
                        "n_items": cfg['n_items'], "ace_dim": cfg['ace_dim'], "seq_len": cfg['seq_len'],
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
+                       "gemm": {"f32": "fp32 storage / accumulate / epilogues; GEMMs with N > 64 split each fp32 operand into three bf16 planes and "
+                                       "accumulate six plane products on v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py), "
+                                       "N <= 64 on v_mfma_f32_32x32x2_f32",
+                                "f32_native": "every GEMM on v_mfma_f32_32x32x2_f32",
+                                "bf16": "bf16-resident candidate-row matrices, fp32 accumulate"}[args.dtype],
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",
-                         "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved": round(achieved, 2), "peak": round(dom_peak, 1), "unit": "TFLOP/s",
+                         "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 plane products per fp32 product; algorithmic fp32 FLOPs in `achieved` "
+                                       "(the native fp32 MFMA peak is %.1f)" % FP32_MATRIX_PEAK_TFLOPS) if dom_x3 else "fp32 dense MFMA peak",
+                         "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": round(n_nn / nprof, 2), "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),
                          "algorithmic_gflop_per_launch": round(fl_nn / max(1, n_nn) / 1e9, 3),
                          "algorithmic_bytes_per_launch": round(dom['bytes'] / max(1, n_nn)),
@@ -466,12 +481,12 @@ def main():
             out["roofline"].update(traffic=None, traffic_source=None)
         if ragged is not None:
             out["g1_like_session_lengths"] = ragged
-        if world == 1 and not args.no_boundary_leg and args.config == "g1" and args.dtype == "f32":
+        if world == 1 and not args.no_boundary_leg and args.config == "g1" and args.dtype in ("f32", "f32_native"):
             # SURVEY 8d's metric proper (input pipeline + H2D + hooks inside the clock), same workload as the headline and its
             # G1-like-session-lengths variant
-            out["through_boundary"] = through_boundary(cfg, args.length_dist, seed=args.seed, state=args.state)
+            out["through_boundary"] = through_boundary(cfg, args.length_dist, seed=args.seed, state=args.state, gemm_dtype=args.dtype)
             if ragged is not None:
-                out["through_boundary_g1_like_session_lengths"] = through_boundary(cfg, "g1", seed=args.seed, state=args.state)
+                out["through_boundary_g1_like_session_lengths"] = through_boundary(cfg, "g1", seed=args.seed, state=args.state, gemm_dtype=args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

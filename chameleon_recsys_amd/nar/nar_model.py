@@ -142,8 +142,13 @@ class NARRuntime:
         # 'f32': exact fp32 MFMA (BASELINE config 2, the default); 'bf16': operands of every Dense / matmul rounded to bf16 on
         # the fly, fp32 accumulation, fp32 storage / softmax / loss / Adam (BASELINE config 3)
         self.gemm_dtype = params.get('gemm_dtype', 'f32')
-        if self.gemm_dtype not in ('f32', 'bf16'):
-            raise ValueError("gemm_dtype must be 'f32' or 'bf16'")
+        # 'f32': fp32 operands; the wide GEMMs (N > 64) run as six bf16-plane products per fp32 product on the bf16 matrix cores
+        # (csrc/gemm_x3.hip, fp32-grade error, 6/16 of the native fp32 matrix time), the narrow ones on v_mfma_f32_32x32x2_f32.
+        # 'f32_native': every GEMM on the native fp32 MFMA (csrc/gemm.hip) - the reference arm of the parity tests.
+        # 'bf16': BASELINE config 3 (bf16-resident candidate-row matrices, fp32 accumulate).
+        if self.gemm_dtype not in ('f32', 'f32_native', 'bf16'):
+            raise ValueError("gemm_dtype must be 'f32', 'f32_native' or 'bf16'")
+        self.x3 = self.gemm_dtype == 'f32' and os.environ.get("CHAM_GEMM_X3", "1") == "1" 
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -289,11 +294,13 @@ class NARRuntime:
             ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
         prof = self.profile
         bf16 = self.gemm_dtype == 'bf16' and not force_f32
+        x3 = self.x3 and not force_f32
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0 = self._tile_counts()
+            x0 = self._tile_counts_x3() if x3 else None
             e0.record()       # torch's current stream == the stream the kernel is launched on (_stream())
-        fn = self.lib.cham_gemm_bf16 if bf16 else self.lib.cham_gemm_f32
+        fn = self.lib.cham_gemm_bf16 if bf16 else (self.lib.cham_gemm_f32x3 if x3 else self.lib.cham_gemm_f32)
         check(fn(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
                                      ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
                                      ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
@@ -301,13 +308,25 @@ class NARRuntime:
             e1.record()
             c1 = self._tile_counts()
             tile = next((i for i in range(13) if c1[i] != c0[i]), -1)
-            prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c1[15]), act=act, dref=dref is not None, dact=dact,
-                             bias=bias is not None, rowscale=rowscale is not None, bf16=bf16, tile=tile, epi=int(c1[14]), ev=(e0, e1)))
+            rec = dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c1[15]), act=act, dref=dref is not None, dact=dact,
+                       bias=bias is not None, rowscale=rowscale is not None, bf16=bf16, tile=tile, epi=int(c1[14]), ev=(e0, e1))
+            if x3:
+                x1 = self._tile_counts_x3()
+                xt = next((i for i in range(3) if x1[i] != x0[i]), -1)
+                if xt >= 0:          # ran on a bf16x3 instance (otherwise: delegated to the native kernels, recorded above)
+                    rec.update(x3=True, tile=xt, epi=int(x1[6]), splits=int(x1[7]))
+            prof.append(rec)
 
     def _tile_counts(self):
         import ctypes
         out = (ctypes.c_longlong * 16)()
         self.lib.cham_gemm_launch_counts(out, 0)
+        return list(out)
+
+    def _tile_counts_x3(self):
+        import ctypes
+        out = (ctypes.c_longlong * 8)()
+        self.lib.cham_gemm_f32x3_launch_counts(out, 0)
         return list(out)
 
     def gemm_b16(self, A, lda, transA, B, ldb, transB, C, ldc, out_f32, M, N, K, bias=None, act=ACT_NONE, dref=None, ldr=0,

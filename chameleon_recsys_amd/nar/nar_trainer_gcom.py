@@ -87,7 +87,9 @@ def define_flags():
     # ---- extensions of this implementation (not in the reference's flag set)
     a('--rnn_cell', default='ugrnn', choices=['ugrnn', 'gru'], help="recurrent cell: 'ugrnn' = the reference's tf.contrib.rnn.UGRNNCell "
       "(nar_model.py:1317), 'gru' = its commented-out GRUCell alternative (:1315)")
-    a('--gemm_dtype', default='f32', choices=['f32', 'bf16'], help="f32: exact fp32 MFMA; bf16: bf16-rounded GEMM operands, fp32 accumulate")
+    a('--gemm_dtype', default='f32', choices=['f32', 'f32_native', 'bf16'],
+      help="f32: fp32 operands and fp32-grade error, wide GEMMs as six bf16-plane products on the bf16 matrix cores; f32_native: every "
+           "GEMM on the native fp32 MFMA; bf16: bf16-resident candidate-row matrices, fp32 accumulate")
     a('--clicked_items_state', default='host', choices=['host', 'device'], help="keep the recent-clicks state in host numpy (reference "
       "class) or in HBM (bit-identical, no host round trip per step)")
     return ap

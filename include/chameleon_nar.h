@@ -115,6 +115,18 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
                    int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
                    int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 
+/* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip): identical contract, fp32 storage and fp32-grade error; every operand is split
+ * into three bf16 planes (a = a_h + a_m + a_l, exact) while staged into LDS and six plane products are accumulated in fp32 on
+ * v_mfma_f32_32x32x16_bf16 (the dropped terms are < 2^-25 |a b|).  6/16 of the native fp32 matrix time on gfx950.  N <= 64 is
+ * delegated to cham_gemm_f32.  An infinite operand yields NaN where cham_gemm_f32 yields inf. */
+int cham_gemm_f32x3(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
+                    int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
+                    int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+/* test / tuning aids: tile variant (0 = 128x128, 2 = 256x128, 4 = 256x256, -1 = automatic); launches since the last reset -
+ * out8[0..2] = those tiles, out8[3] = delegated to cham_gemm_f32, out8[6] / out8[7] = epilogue variant / K-splits of the last launch */
+void cham_gemm_f32x3_set_variant(int variant);
+void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
+
 /* bf16-RESIDENT GEMMs of the bf16 configuration (csrc/gemm_b16.hip): the matrices with one row per candidate live in HBM as bf16
  * (weights: a bf16 shadow of the fp32 master copy); fp32 accumulation / bias / activation.
  *   transA = 0, transB = 1 (NT): A [M, lda], B [N, ldb] bf16, k contiguous; C bf16 (out_f32 = 0) or fp32 [M, ldc];

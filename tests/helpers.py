@@ -72,8 +72,10 @@ def _significant(m_ref, floor, global_max=0.0):
     return a > max(floor * max(float(a.max()), 1e-30), 1e-4 * global_max)
 
 
-def assert_adam_state_close(model, orc, lr, n_steps=1, m_tol=5e-3, w_tol=0.2, floor=1e-2):
-    """HIP runtime vs oracle after n_steps optimizer steps: first moments (all entries), weights (entries with significant m)."""
+def assert_adam_state_close(model, orc, lr, n_steps=1, m_tol=5e-3, w_tol=0.2, floor=1e-2, sig_every_step=None):
+    """HIP runtime vs oracle after n_steps optimizer steps: first moments (all entries), weights (entries with significant m - and,
+    over several steps, a gradient above the noise floor in EVERY step: `sig_every_step` from `grad_significance`; the very first
+    Adam step moves an entry by lr * sign(g) however small |g| is)."""
     L = model.rt.layout
     m_hip = L.unpack(model.rt.m.cpu().numpy())
     w_hip = model.rt.logical_weights()
@@ -86,6 +88,8 @@ def assert_adam_state_close(model, orc, lr, n_steps=1, m_tol=5e-3, w_tol=0.2, fl
         worst_m = max(worst_m, em / scale)
         assert em < m_tol * scale + 2e-6, "Adam m of %s: %g of max" % (k, em / scale)
         sig = _significant(mr, floor, gmax)
+        if sig_every_step is not None:
+            sig = sig & sig_every_step[k]
         if sig.any():
             dw = float(np.abs(w_hip[k] - orc.w[k].detach().numpy())[sig].max())
             worst_w = max(worst_w, dw / (lr * n_steps))
@@ -94,6 +98,16 @@ def assert_adam_state_close(model, orc, lr, n_steps=1, m_tol=5e-3, w_tol=0.2, fl
     assert checked > 0
     print("adam state: worst m err %.2e of max, worst |dw| %.3f lr*steps over %d significant entries" % (worst_m, worst_w, checked))
     return worst_w
+
+
+def grad_significance(grads, floor=1e-2, acc=None):
+    """Running AND over optimizer steps of `this step's gradient is above floor x the tensor's max |g|` (oracle gradients)."""
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    out = {}
+    for k, v in grads.items():
+        sig = _significant(v.numpy(), floor, gmax)
+        out[k] = sig if acc is None else (acc[k] & sig)
+    return out
 
 
 def assert_flat_close(layout, flat_a, m_a, flat_b, m_b, lr, n_steps=1, m_tol=2e-5, w_tol=0.2, floor=1e-2):

@@ -7,8 +7,9 @@ choice needs a grid of >= 256 workgroups) x 1024 select the 256x128 NN, 256x256 
 
 Tolerances: negatives bit-exact; logits / probabilities / loss 1e-3 (north_star).  Gradients: at 63 M PreCAR outputs a handful of
 leaky-ReLU pre-activations lie within an fp32 ulp of zero and take the other branch in two correct evaluations (the count is
-printed), so the per-tensor check is the relative L2 error (< 1e-3; a flipped element moves it by ~1e-5) plus a max-error bound
-(3e-4 of the tensor's max without flips, 2e-2 with)."""
+printed); the gradient comparison runs the oracle on the HIP path's branches for those elements, so the per-tensor bounds are
+tight whatever the luck of the flips: relative L2 error < 1e-4, max error < 2e-4 of the tensor's max (measured: 1.9e-5 / 2.4e-5 on
+the worst tensor, 1e-6 on the CAR kernels, the same for the native fp32 MFMA and the bf16x3 GEMMs)."""
 import ctypes
 
 import numpy as np
@@ -17,7 +18,7 @@ import torch
 
 from chameleon_recsys_amd.nar import synthetic
 from tests import helpers as H
-from tests.test_step_gpu import _kink_flips
+from tests.test_step_gpu import _kink_flips, hip_leaky_signs
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
@@ -29,7 +30,7 @@ def tile_counts(lib, reset=False):
     return list(out)
 
 
-def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-3, grad_max=3e-4, grad_max_flips=2e-2):
+def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, grad_max=2e-4):
     buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
     model.feed_state(pop, buf)
     model.forward(model.upload_batch(f, l))
@@ -46,8 +47,18 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-3, 
     assert abs(out['loss'][1] - float(ref['xe_loss'])) < logit_tol
     assert abs(out['loss'][2] - float(ref['reg_loss'])) < 1e-5
     flips = _kink_flips(model, orc, mask)
-    ref['xe_loss'].backward()
     orc.debug_taps = None
+    if flips:
+        # a handful of the 63 M leaky-ReLU pre-activations lie within an fp32 ulp of zero and take the other branch in the two
+        # evaluations; which ones is luck, and one on a high-gradient element moves a small tensor's gradient by ~1e-3.  The
+        # gradient comparison therefore re-runs the oracle on the HIP path's branches (NAROracle._leaky_site): values move by < 1e-7,
+        # gradients become comparable at the no-flip tolerance.
+        orc.leaky_signs = hip_leaky_signs(model, mask)
+        ref2 = orc.forward(f, l, buf, pop, 'train')
+        orc.leaky_signs = None
+        assert float(np.abs(ref2['logits'].detach().numpy() - ref['logits'].detach().numpy())[mask].max()) < 1e-5
+        ref = ref2
+    ref['xe_loss'].backward()
     model.backward()
     torch.cuda.synchronize()
     g = model.rt.logical_grads()
@@ -67,10 +78,11 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-3, 
         mx = float(np.abs(d).max()) / scale
         worst[k] = (l2, mx)
         assert l2 < grad_l2, "grad %s: relative L2 error %g (max err %g of max, %d kink flips)" % (k, l2, mx, flips)
-        assert mx < (grad_max if flips == 0 else grad_max_flips) + 2e-5 / scale, \
-            "grad %s: max err %g of max |g| = %g (%d kink flips)" % (k, mx, scale, flips)
-    print("kink flips %d, logits err %.2e, worst grad L2 %.2e / max %.2e" % (
-        flips, e_logit, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
+        assert mx < grad_max + 2e-5 / scale, "grad %s: max err %g of max |g| = %g (%d kink flips, oracle on the HIP branches)" % (k, mx, scale, flips)
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:3]
+    print("kink flips %d, logits err %.2e, worst grad L2 %.2e / max %.2e; top: %s" % (
+        flips, e_logit, max(v[0] for v in worst.values()), max(v[1] for v in worst.values()),
+        ", ".join("%s %.2e/%.2e" % (k, v[0], v[1]) for k, v in top)))
     return flips
 
 
@@ -79,19 +91,32 @@ def _g1_params(B, **over):
                                     for_norm=2000, C=1024, H=255, **over)
 
 
-@pytest.mark.parametrize("length_dist", ["full", "g1"])
-def test_step_parity_g1_shape(gpu, length_dist):
-    """BASELINE configs[1] shape, 72 sessions: forward + full backward vs the dense oracle, on the big-tile GEMM instances."""
+def x3_counts(lib, reset=False):
+    out = (ctypes.c_longlong * 8)()
+    lib.cham_gemm_f32x3_launch_counts(out, int(reset))
+    return list(out)
+
+
+@pytest.mark.parametrize("length_dist,gemm_dtype", [("full", "f32"), ("full", "f32_native"), ("g1", "f32")])
+def test_step_parity_g1_shape(gpu, length_dist, gemm_dtype):
+    """BASELINE configs[1] shape, 72 sessions: forward + full backward vs the dense oracle, on the big-tile GEMM instances - the
+    default arithmetic (wide GEMMs as bf16x3 plane products, csrc/gemm_x3.hip) and every GEMM on the native fp32 MFMA, same tolerances."""
     B = 72
-    p = _g1_params(B)
+    p = _g1_params(B, gemm_dtype=gemm_dtype)
     batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B)
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p, seed=7)
     lib = model.rt.lib
     tile_counts(lib, reset=True)
+    x3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
     c = tile_counts(lib)
-    if length_dist == "full":
+    x = x3_counts(lib)
+    if gemm_dtype == "f32":
+        # CAR forward / dgrad / wgrad, scorer layer 1 (row scale) + its wgrad and dgrad on the 256x128 bf16x3 instance; nothing wide on
+        # the native kernels
+        assert x[1] >= (6 if length_dist == "full" else 1) and c[1] == 0 and c[2] == 0, (x, c)
+    elif length_dist == "full":
         # CAR forward NN + scorer layer 1 (row scale) + scorer layer-1 dgrad on 256x128, CAR dgrad NT + W2 wgrad TN split-K on
         # 256x256: the instances the bench's step runs on
         assert c[1] >= 3 and c[2] >= 2, "expected the 256x128 and 256x256 instances to run: %r" % (c,)
@@ -107,17 +132,21 @@ def test_training_curve_g1_shape(gpu):
     batches = synthetic.make_batches(5, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B)
     st = H.warm_state(p, batches[:2])
     model, orc = H.make_pair(p, seed=9)
+    sig = None
     for i, (f, l) in enumerate(batches[2:5]):
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         model.feed_state(pop, buf)
         loss = model.train_step(model.upload_batch(f, l)).cpu().numpy()
-        ref = orc.train_step(f, l, buf, pop)
+        ref = orc.train_step(f, l, buf, pop, return_grads=True)
+        sig = H.grad_significance(ref['grads'], acc=sig)
         assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy())
         assert abs(loss[0] - float(ref['total_loss'])) < LOGIT_TOL, (i, loss, float(ref['total_loss']))
         H.update_state(st, f, l)
-    # (Adam moves a weight whose gradient is roundoff by +-lr per step in either direction: after three steps the two runs' weights
-    # differ by ~lr on such entries and the gradients of small tensors by a fraction of a percent)
-    H.assert_adam_state_close(model, orc, p['lr'], n_steps=3, m_tol=2e-2, w_tol=0.1)
+    # Adam moves a weight by ~lr * sign(g) in its first steps however small |g| is: an entry whose gradient is roundoff in ANY of the
+    # three steps differs by up to 2 lr between two correct runs.  Weights are compared where the gradient was above the noise floor
+    # in every step (w_tol: a kink flip - see compare_step_large - on a high-gradient element moves an entry by ~0.2 lr per step; a
+    # wrong sign, slot or row is >= 1.0).
+    H.assert_adam_state_close(model, orc, p['lr'], n_steps=3, m_tol=2e-2, w_tol=0.25, sig_every_step=sig)
 
 
 def test_step_parity_adressa_shape(gpu):
@@ -130,10 +159,10 @@ def test_step_parity_adressa_shape(gpu):
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p, seed=2)
     lib = model.rt.lib
-    tile_counts(lib, reset=True)
+    x3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
-    c = tile_counts(lib)
-    assert c[1] >= 3 and c[2] >= 2, c
+    x = x3_counts(lib)
+    assert x[1] >= 6, x
 
 
 def test_step_parity_g1_shape_bf16(gpu):

@@ -8,15 +8,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, accumulate=0, splits=1, seed=0, bf16=False):
+def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0, rowscale=0, accumulate=0, splits=1, seed=0, bf16=False,
+         x3=False, scale=1.0):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
-    A = torch.randn((K, M) if transA else (M, K), generator=g)
+    A = torch.randn((K, M) if transA else (M, K), generator=g) * scale
     B = torch.randn((N, K) if transB else (K, N), generator=g)
-    C0 = torch.randn(M, N, generator=g)
-    bias_t = torch.randn(N, generator=g) if bias else None
+    C0 = torch.randn(M, N, generator=g) * scale
+    bias_t = torch.randn(N, generator=g) * scale if bias else None
     ref_t = torch.randn(M, N, generator=g) if dref else None
     rs_div = rowscale if rowscale else 1
     rs_rows = (A.shape[0] + rs_div - 1) // rs_div
@@ -48,14 +49,13 @@ def _run(gpu, M, N, K, transA=0, transB=0, bias=False, act=0, dref=False, dact=0
     dref_t = ref_t.to(gpu) if dref else None
     drs = rs_t.to(gpu) if rowscale else None
     ws = torch.empty(32 << 20, dtype=torch.float32, device=gpu) if splits != 1 else None
-    rc = (lib.cham_gemm_bf16 if bf16 else lib.cham_gemm_f32)(ptr(dA), A.shape[1], transA, ptr(dB), B.shape[1], transB, ptr(dC), N, M, N, K, ptr(dbias), act,
+    rc = (lib.cham_gemm_bf16 if bf16 else (lib.cham_gemm_f32x3 if x3 else lib.cham_gemm_f32))(ptr(dA), A.shape[1], transA, ptr(dB), B.shape[1], transB, ptr(dC), N, M, N, K, ptr(dbias), act,
                            ptr(dref_t), N, dact, ptr(drs), A.shape[1], rs_div, accumulate, ptr(ws),
                            (32 << 20) * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream)
     check(rc, "gemm")
     torch.cuda.synchronize()
     out = dC.cpu().double()
-    scale = max(1.0, float(R.abs().max()))
-    err = float((out - R).abs().max()) / scale
+    err = float((out - R).abs().max()) / max(scale, float(R.abs().max()))
     return err
 
 
@@ -180,19 +180,19 @@ class _BigCase:
         self._refs[bf16] = R
         return R
 
-    def run(self, lib, variant, bf16=False, splits=1):
+    def run(self, lib, variant, bf16=False, splits=1, x3=False):
         from chameleon_recsys_amd._lib import check, ptr
         d = self.dev
         C = torch.full((self.M, self.N), float('nan'), device=self.gpu)
         ws = torch.empty(32 << 20, dtype=torch.float32, device=self.gpu) if splits != 1 else None
-        lib.cham_gemm_set_variant(variant)
+        (lib.cham_gemm_f32x3_set_variant if x3 else lib.cham_gemm_set_variant)(variant)
         try:
-            rc = (lib.cham_gemm_bf16 if bf16 else lib.cham_gemm_f32)(
+            rc = (lib.cham_gemm_bf16 if bf16 else (lib.cham_gemm_f32x3 if x3 else lib.cham_gemm_f32))(
                 ptr(d['A']), self.A.shape[1], self.tA, ptr(d['B']), self.B.shape[1], self.tB, ptr(C), self.N, self.M, self.N, self.K,
                 ptr(d['bias']), self.act, ptr(d['ref']), self.N, self.dact, ptr(d['rs']), self.A.shape[1], self.rs_div, 0, ptr(ws),
                 (32 << 20) * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream)
         finally:
-            lib.cham_gemm_set_variant(-1)
+            (lib.cham_gemm_f32x3_set_variant if x3 else lib.cham_gemm_set_variant)(-1)
         check(rc, "gemm")
         torch.cuda.synchronize()
         R = self.reference(bf16)

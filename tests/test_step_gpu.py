@@ -67,6 +67,22 @@ def _kink_flips(model, orc, mask):
     return n
 
 
+def hip_leaky_signs(model, mask):
+    """The branch the HIP path took at every leaky-ReLU output (valid positions), in the form NAROracle.leaky_signs expects."""
+    pl = model._plan
+    B, T, NC, P = pl.B, pl.T, pl.NC, pl.P
+    valid = torch.from_numpy(np.asarray(mask, bool))
+    out = {}
+    for name, hip in (('S1', pl.S1), ('S2', pl.S2), ('S3', pl.S3)):
+        h = pl.full_rows(hip, NC).float().cpu().reshape(B, T, NC, -1) > 0
+        out[name] = [(h[:, :, 0], valid[:, :, None]), (h[:, :, 1:], valid[:, :, None, None])]
+    zin = pl.full_rows(pl.Z1[:P]).float().cpu().reshape(B, T, -1) > 0
+    zc = pl.full_rows(pl.Z1[P:P + P * NC], NC).float().cpu().reshape(B, T, NC, -1) > 0
+    out['Z1'] = [(zin, valid[:, :, None]), (zc[:, :, 0], valid[:, :, None]), (zc[:, :, 1:], valid[:, :, None, None])]
+    out['FC1'] = [(pl.full_rows(pl.FC1).float().cpu().reshape(B, T, -1) > 0, valid[:, :, None])]
+    return out
+
+
 def test_step_parity_tiny_warm_state(gpu):
     p = H.tiny_params()
     batches = synthetic.make_batches(7, 64, 8, 1000, p['session_features_config'], length_dist='g1')
