@@ -344,8 +344,8 @@ static inline int gemm_plan(GemmParams& p, const float* A, int lda, int transA, 
     }
     p.splits = splits;
     int kchunk = (K + splits - 1) / splits;
-    kchunk = ((kchunk + 31) / 32) * 32;                  // multiple of every BK
-    if (kchunk == 0) kchunk = 32;
+    kchunk = ((kchunk + 63) / 64) * 64;                  // multiple of every BK (and of gemm_x3.hip's four-tile unrolled body)
+    if (kchunk == 0) kchunk = 64;
     p.kchunk = kchunk;
     p.splits = (K + kchunk - 1) / kchunk;
     if (p.splits < 1) p.splits = 1;

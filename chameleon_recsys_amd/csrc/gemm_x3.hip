@@ -18,7 +18,7 @@
 #include "gemm_shared.h"
 #include <stdlib.h>
 
-// ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 2 = no global
+// ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 2 = no global
 // loads in the loop, 4 = no fragment ds_reads in the loop, 8 = one MFMA pass instead of six, 16 = no LDS writes in the loop
 #ifndef X3_ABL
 #define X3_ABL 0
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
 
     struct Frags { bf16x8 a[3][TM], b[3][TN]; };
     Frags F0, F1;
-    typename LA::Regs RA0, RA1;
-    typename LB::Regs RB0, RB1;
+    typename LA::Regs RA[4];
+    typename LB::Regs RB[4];
 
     auto gload = [&](typename LA::Regs& ra, typename LB::Regs& rb, int t) {          // global -> registers, tile t
         const int k0 = kbeg + t * BK;
@@ -280,23 +280,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     };
     // smallest terms first; every pass walks all TM x TN accumulators, so dependent MFMAs are TM * TN instructions apart
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-    auto phase = [&](const Frags& fc, Frags& fn, typename LA::Regs& rac, typename LB::Regs& rbc, typename LA::Regs& ran,
-                     typename LB::Regs& rbn, int t) {
+    // Phase t: MFMAs on tile t; fragments of tile t + 1 read; tile t + 2 split (register set `c`) and written to LDS; tile t + 5
+    // requested from memory into register set `l` (the set phase t - 1 finished splitting).  The operands stream from HBM - the
+    // workgroups that share an A panel walk K in step, so every request sees a miss, ~2 us under load, longer than a phase: one
+    // phase of distance left the waves parked at vmcnt for a third of their cycles (SQ_WAIT_ANY, profiles/r02_notes.md).
+    constexpr bool BRING = !BKC && !AK;          // B streams from HBM too (wgrad: both operands run along the rows); a weight matrix is L2 resident
+    auto phase = [&](const Frags& fc, Frags& fn, typename LA::Regs& rac, typename LB::Regs& rbc, typename LA::Regs& ral,
+                     typename LB::Regs& rbl, int t) {
         const int cur = t & 1;
-        // One MFMA, then one element of the split (a dependent chain of ~6 VALU instructions, 24 issue cycles - the MFMA holds the
-        // matrix pipe for 32) and at most one memory instruction, pinned slice by slice.  Left to itself the scheduler issues the
-        // fragment reads, the MFMAs and the split in three bursts; every wave of the workgroup is in the same place after the
-        // barrier, so a burst of 8 x 12 ds_read_b128 (768 LDS cycles) holds all of them at the LDS queue before their first MFMA and
-        // the phase costs the SUM of its streams (measured: scripts/ab_x3.py, profiles/r02_notes.md).  Trickled out one request per
-        // two MFMAs the LDS, the texture path and the matrix pipe run side by side.
         typename LA::Conv ca;
         typename LB::Conv cb;
         constexpr int NEA = LA::NE, NEB = LB::NE, NMF = 6 * TM * TN, NFR = 3 * (TM + TN);
         constexpr int NGA = LA::NV * LA::NL, NGB = LB::NV * LB::NL;
-        static_assert(NEA + NEB + 2 <= NMF && 2 * NFR <= NMF && 2 * (NGA + NGB) + 1 <= NMF, "the streams must fit under the MFMAs of one phase");
-        const int kn = kbeg + (t + 3) * BK;
-        const __amdgpu_buffer_rsrc_t awn = make_window(abase + (size_t)(t + 3) * astep), bwn = make_window(bbase + (size_t)(t + 3) * bstep);
-        if constexpr (RS) { if (!(X3_ABL & 2)) la.load_scale(ran, rsw, kn, m0, p.ldrs, p.rs_div, kend - kn); }
+        // slices: one MFMA each, plus - fragment reads in the first NFR slices (they must have landed by the barrier), the global
+        // requests in the first NGA + NGB, B's split / LDS write, then A's
+        constexpr int SB_W = NEB, SA_0 = NEB + 1, SA_W = SA_0 + NEA;
+        static_assert(SA_W < NMF && NFR <= NMF && NGA + NGB + 1 <= NMF, "the streams must fit under the MFMAs of one phase");
+        const int kn = kbeg + (t + 5) * BK, knb = kbeg + (t + (BRING ? 5 : 3)) * BK;
+        const __amdgpu_buffer_rsrc_t awn = make_window(abase + (size_t)(t + 5) * astep);
+        const __amdgpu_buffer_rsrc_t bwn = make_window(bbase + (size_t)(t + (BRING ? 5 : 3)) * bstep);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 6; ++s)
@@ -305,48 +307,77 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int m = (s * TM + i) * TN + j;
-                    if (!(X3_ABL & 8) || s == 0)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[PA[s]][i], fc.b[PB[s]][j], acc[i][j], 0, 0, 0);
-                    if (!(X3_ABL & 16)) {
-                        if (m < NEA) la.convert_one(rac, ca, m);
-                        else if (m < NEA + NEB) lb.convert_one(rbc, cb, m - NEA);
-                        if (m == NEA) la.write(ca, As + cur * ASZ);
-                        if (m == NEA + NEB) lb.write(cb, Bs + cur * BSZ);
+                    if ((!(X3_ABL & 8) || s == 0) && (!(X3_ABL & 128) || wave < WM * WN / 2)) {
+                        if (X3_ABL & 64)       // probe: accumulators pinned to the AccVGPR file
+                            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fc.a[PA[s]][i]), "v"(fc.b[PB[s]][j]));
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[PA[s]][i], fc.b[PB[s]][j], acc[i][j], 0, 0, 0);
                     }
-                    if (!(X3_ABL & 4) && (m & 1) == 0 && m / 2 < NFR) {          // fragment m / 2 of tile t + 1
-                        const int f = m / 2, q = f / (TM + TN), r = f % (TM + TN);
+                    if (!(X3_ABL & 2) && (!(X3_ABL & 128) || wave >= WM * WN / 2)) {     // one global float4 of tile t + 5 per slice
+                        if (m < NGA) la.load_one(ral, awn, kend - kn, m);
+                        if (BRING) { if (m >= NGA && m < NGA + NGB) lb.load_one(rbl, bwn, kend - knb, m - NGA); }
+                        else { if (m > SB_W && m <= SB_W + NGB) lb.load_one(rbc, bwn, kend - knb, m - SB_W - 1); }          // reload the set just split
+                        if constexpr (RS) { if (m == NGA + NGB) la.load_scale(ral, rsw, kn, m0, p.ldrs, p.rs_div, kend - kn); }
+                    }
+                    if (!(X3_ABL & 4) && (!(X3_ABL & 128) || wave >= WM * WN / 2) && m < NFR) {          // fragment m of tile t + 1
+                        const int q = m / (TM + TN), r = m % (TM + TN);
                         constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
                         if (r < TM) fn.a[QA[q]][r] = x3_frag<AK, LA::LD>(As + (cur ^ 1) * ASZ + QA[q] * APL, wm0 + r * 32, lane);
                         else fn.b[QB[q]][r - TM] = x3_frag<BKC, LB::LD>(Bs + (cur ^ 1) * BSZ + QB[q] * BPL, wn0 + (r - TM) * 32, lane);
                     }
-                    if (!(X3_ABL & 2) && (m & 1) == 1 && m / 2 < NGA + NGB) {     // one global float4 of tile t + 3
-                        const int g = m / 2;
-                        if (g < NGA) la.load_one(ran, awn, kend - kn, g);
-                        else lb.load_one(rbn, bwn, kend - kn, g - NGA);
+                    if (!(X3_ABL & 16) && (!(X3_ABL & 128) || wave >= WM * WN / 2)) {
+                        if (m < NEB) lb.convert_one(rbc, cb, m);
+                        else if (m >= SA_0 && m < SA_0 + NEA) la.convert_one(rac, ca, m - SA_0);
+                        if (m == SB_W) lb.write(cb, Bs + cur * BSZ);
+                        if (m == SA_W) la.write(ca, As + cur * ASZ);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        // LDS-only barrier: __syncthreads() may also drain vmcnt, i.e. wait for the global loads of tile t + 3 issued a moment ago -
-        // the very latency the register staging exists to hide.  This wave's ds_writes / ds_reads are complete at lgkmcnt(0).
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // LDS-only barrier: __syncthreads() may also drain vmcnt, i.e. wait for the global requests in flight - the very latency the
+        // register staging exists to hide.  This wave's ds_writes / ds_reads are complete at lgkmcnt(0).
+        // (builtins, not inline asm: the compiler's wait-count pass must SEE the drain, or it keeps believing the fragment reads are
+        // pending and puts lgkmcnt(n) waits in front of next phase's MFMAs - which then also wait for that phase's young requests)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), vmcnt / expcnt untouched
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         __builtin_amdgcn_sched_barrier(0);
     };
 
     if (nk > 0) {
-        gload(RA0, RB0, 0);
-        gload(RA1, RB1, 1);
-        la.store3(RA0, As); lb.store3(RB0, Bs);
-        la.store3(RA1, As + ASZ); lb.store3(RB1, Bs + BSZ);
-        gload(RA0, RB0, 2);
+        gload(RA[0], RB[0], 0);
+        gload(RA[1], RB[1], 1);
+        la.store3(RA[0], As); lb.store3(RB[0], Bs);
+        la.store3(RA[1], As + ASZ); lb.store3(RB[1], Bs + BSZ);
+        if (BRING) {
+            gload(RA[2], RB[2], 2);
+            gload(RA[3], RB[3], 3);
+            gload(RA[0], RB[0], 4);
+        } else {          // B: one register set, tile 2 now, tile t + 3 reloaded in phase t
+            gload(RA[2], RB[0], 2);
+            la.load(RA[3], make_window(abase + (size_t)3 * astep), kend - (kbeg + 3 * BK));
+            la.load_scale(RA[3], rsw, kbeg + 3 * BK, m0, p.ldrs, p.rs_div, kend - (kbeg + 3 * BK));
+            la.load(RA[0], make_window(abase + (size_t)4 * astep), kend - (kbeg + 4 * BK));
+            la.load_scale(RA[0], rsw, kbeg + 4 * BK, m0, p.ldrs, p.rs_div, kend - (kbeg + 4 * BK));
+        }
         __syncthreads();
         fread(F0, 0);
         __syncthreads();          // every wave holds tile 0 in registers before phase 0 overwrites LDS buffer 0
-        for (int kt = 0; kt < nk; kt += 2) {
-            phase(F0, F1, RA0, RB0, RA1, RB1, kt);
-            phase(F1, F0, RA1, RB1, RA0, RB0, kt + 1);
+        for (int kt = 0; kt < nk; kt += 4) {          // tile i lives in register set i % 4
+            // (no early exit: up to three trailing phases multiply staged zeros - gemm_plan makes the K chunk a multiple of 64, so only
+            // a ragged last chunk or a K that is not a multiple of 64 pays for them; exits in the middle of the unrolled body made the
+            // compiler keep a second copy of the accumulators)
+            phase(F0, F1, RA[2], RB[BRING ? 2 : 0], RA[1], RB[BRING ? 1 : 0], kt);
+            phase(F1, F0, RA[3], RB[BRING ? 3 : 0], RA[2], RB[BRING ? 2 : 0], kt + 1);
+            phase(F0, F1, RA[0], RB[0], RA[3], RB[BRING ? 3 : 0], kt + 2);
+            phase(F1, F0, RA[1], RB[BRING ? 1 : 0], RA[0], RB[0], kt + 3);
         }
     }
-    const int kl = lane >> 5, fl = lane & 31;
+    // (the lane id goes through an opaque move: otherwise the epilogue's per-lane offsets are computed above the K loop and held in
+    // VGPRs through it - the loop has none to spare)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kl = lane_e >> 5, fl = lane_e & 31;
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
