@@ -192,6 +192,9 @@ class NARRuntime:
         # - measured neutral (16.95-17.13 ms both ways; 64 splits 17.6 ms): experiment switch, default off
         self.tail_on_side = os.environ.get("CHAM_TAIL_ON_SIDE", "0") == "1"
         self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
+        # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
+        # per-CU matrix kernels that only time-slice the chip when they overlap
+        self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
         self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
@@ -1015,6 +1018,7 @@ class NARModuleModel:
                 rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
             else:
                 rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
+        e_cdgrad = mark()
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
         with side(e_dZ2c):
@@ -1071,6 +1075,8 @@ class NARModuleModel:
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
                     elif not swap:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
+                        if on and rt.w2_after_dgrad:
+                            rt.side_stream.wait_event(e_cdgrad)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
                         rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
