@@ -356,12 +356,15 @@ def main():
     for r in prof:
         if r['tile'] < 0:
             continue
-        e = by_sym.setdefault(gemm_symbol(r), dict(n=0, ms=0.0, flop=0.0, bytes=0.0, r=r))
+        e = by_sym.setdefault(gemm_symbol(r), dict(n=0, ms=0.0, flop=0.0, bytes=0.0, r=r, shapes={}))
         if r['M'] * r['N'] * r['K'] > e['r']['M'] * e['r']['N'] * e['r']['K']:
             e['r'] = r
+        t_ms = r['ev'][0].elapsed_time(r['ev'][1])
         e['n'] += 1
-        e['ms'] += r['ev'][0].elapsed_time(r['ev'][1])
+        e['ms'] += t_ms
         e['flop'] += 2.0 * r['M'] * r['N'] * r['K']
+        sh = e['shapes'].setdefault((r['M'], r['N'], r['K']), [0, 0.0])
+        sh[0] += 1; sh[1] += t_ms
         # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
         # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
         if r.get('b16'):
@@ -388,7 +391,12 @@ def main():
         peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if e['r'].get('x3') else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
-                "mfma_peak_tflops": peak, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4)}
+                "mfma_peak_tflops": round(peak, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4),
+                # one symbol can serve launches of very different shapes (e.g. the CAR dgrad and a K = 64 scorer dgrad): per shape
+                "by_shape": [{"M": m, "N": n_, "K": k, "launches_per_step": round(c / nprof, 2), "avg_launch_ms": round(t / c, 4),
+                              "tflops": round(2.0 * m * n_ * k / (t / c * 1e-3) / 1e12, 2),
+                              "frac_of_mfma_peak": round(2.0 * m * n_ * k / (t / c * 1e-3) / 1e12 / peak, 4)}
+                             for (m, n_, k), (c, t) in sorted(e['shapes'].items(), key=lambda kv: -kv[1][1])[:3]]}
     DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
     n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
     dom_x3 = bool(dom['r'] and dom['r'].get('x3'))
