@@ -195,6 +195,13 @@ class NARRuntime:
         # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
         # per-CU matrix kernels that only time-slice the chip when they overlap
         self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
+        # three more schedule arms suggested by the kernel trace of the plane-product build, each measured neutral or slower (A/B in one
+        # gpurun call, ms/step: all off 12.95 | scorer layer-1 wgrad only after its dgrad dM 13.16 -> +0.06 | the small PreCAR-backward
+        # GEMMs on the native fp32 kernels so that they co-reside with the W2 wgrad: +0.22 | b2 column sum before the W2 wgrad: -0.03):
+        # default off
+        self.ws1_after_dm = os.environ.get("CHAM_WS1_AFTER_DM", "0") == "1"
+        self.precar_bwd_native = os.environ.get("CHAM_PRECAR_BWD_NATIVE", "0") == "1"
+        self.b2_early = os.environ.get("CHAM_B2_EARLY", "0") == "1"
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
         self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
@@ -959,7 +966,8 @@ class NARModuleModel:
             rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
         else:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
-        with side(e_start, e_dS1):
+        e_side0 = mark() if (on and rt.x3 and rt.ws1_after_dm) else e_dS1
+        with side(e_start, e_side0):
             if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
                 rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
@@ -1075,10 +1083,13 @@ class NARModuleModel:
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
                     elif not swap:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
+                        if rt.b2_early:          # (needs dZ2 only: runs while this lane waits for the CAR dgrad)
+                            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                         if on and rt.w2_after_dgrad:
                             rt.side_stream.wait_event(e_cdgrad)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
-                        rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+                        if not rt.b2_early:
+                            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
@@ -1110,12 +1121,13 @@ class NARModuleModel:
             else:
                 check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
                       "cham_combine_bwd")
+            nat = rt.precar_bwd_native
             if not drop:
-                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0, force_f32=nat)
                 rt.colsum(pl.dU, C, BT, C, g('b1'))
-                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
-                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
-                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
+                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0, force_f32=nat)
+                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1, force_f32=nat)
+                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1, force_f32=nat)
             # scale/center + embedding tables (fixed summation order: the step is bit-reproducible)
             check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), st), "cham_feature_bwd")
             check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(g('gamma_item')), ptr(g('beta_item')), st), "cham_feature_bwd")
