@@ -15,14 +15,14 @@
 // [row][k] bf16, row stride BK + 8 = 24 elements (48 B = 3 x 16-B slots, coprime with the 16 slots of a bank row), planes and the
 // two pipeline buffers behind each other: 2 x 3 x (BM + BN) x 48 B = 110.6 KB for 256x128, 73.7 KB for 128x128.
 // Inf / NaN: an infinite operand gives NaN (inf - inf in the split) where fp32 would give inf; finite data is unaffected.
-#include "gemm_shared.h"
-#include <stdlib.h>
-
 // ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 2 = no global
 // loads in the loop, 4 = no fragment ds_reads in the loop, 8 = one MFMA pass instead of six, 16 = no LDS writes in the loop
 #ifndef X3_ABL
 #define X3_ABL 0
 #endif
+#include "gemm_shared.h"
+#include <stdlib.h>
+
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
