@@ -15,7 +15,7 @@
 // [row][k] bf16, row stride BK + 8 = 24 elements (48 B = 3 x 16-B slots, coprime with the 16 slots of a bank row), planes and the
 // two pipeline buffers behind each other: 2 x 3 x (BM + BN) x 48 B = 110.6 KB for 256x128, 73.7 KB for 128x128.
 // Inf / NaN: an infinite operand gives NaN (inf - inf in the split) where fp32 would give inf; finite data is unaffected.
-// ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 2 = no global
+// ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 512 = no s_barrier in the loop (wrong results, timing only), 1024 = no lgkmcnt(0) either, 2 = no global
 // loads in the loop, 4 = no fragment ds_reads in the loop, 8 = one MFMA pass instead of six, 16 = no LDS writes in the loop
 #ifndef X3_ABL
 #define X3_ABL 0
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
         // (builtins, not inline asm: the compiler's wait-count pass must SEE the drain, or it keeps believing the fragment reads are
         // pending and puts lgkmcnt(n) waits in front of next phase's MFMAs - which then also wait for that phase's young requests)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), vmcnt / expcnt untouched
-        __builtin_amdgcn_s_barrier();
+        if (!(X3_ABL & 1024)) __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), vmcnt / expcnt untouched
+        if (!(X3_ABL & 512)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         __builtin_amdgcn_sched_barrier(0);
     };
