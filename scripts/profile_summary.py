@@ -40,7 +40,8 @@ def main():
             out.append("| %s | %.0f sessions/s, %.3f ms/step (`%s`) |" % (label, x["value"], x["ms_per_step"], os.path.basename(fn)))
     out.append("\n## rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ragged-leg` (`%s_kernel_stats.csv`)\n" % tag)
     rows = list(csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))))
-    steps = 16.0      # 3 warm-up + 10 timed + 3 roofline-leg steps
+    # optimizer steps in the profiled run = launches of the Adam kernel (warm-up + timed + host-enqueue + roofline-leg steps)
+    steps = float(next((int(x["Calls"]) for x in rows if x["Name"].startswith("k_adam_tf")), 16))
     tot = sum(float(x["TotalDurationNs"]) for x in rows)
     out.append("Sum of kernel time %.2f ms/step over %d kernel symbols (lanes overlap: wall time per step is lower).\n" % (tot / 1e6 / steps, len(rows)))
     out.append("| kernel | launches/step | ms/step | avg us | share |\n|---|---|---|---|---|")
