@@ -173,3 +173,35 @@ def test_tf_adam_two_steps_closed_form():
         assert np.abs(orc.m[k].numpy() - m2).max() < 1e-6 * max(1e-3, np.abs(m2).max())
         # torch.optim.Adam would give a different step: eps inside the corrected denominator (the two differ where |g| ~ eps)
     assert orc.global_step == 2
+
+
+def test_leaky_site_branch_override_is_leaky_relu_with_pinned_branches():
+    """NAROracle._leaky_site (the hook the GPU gradient-parity tests use to run the oracle on the HIP path's branches): without an
+    override it is tf.nn.leaky_relu; with one, the value changes only where the pinned branch disagrees with the sign (and then by
+    0.8 |x|, i.e. nothing for the |x| ~ 1e-7 elements it is used on) and the gradient factor is the pinned one; elements outside
+    `valid` keep their own branch."""
+    orc, p = _oracle('ugrnn')
+    x = torch.tensor([[-2.0, -1e-7, 1e-7, 3.0], [0.5, -0.5, 2e-7, -2e-7]], requires_grad=True)
+    y = orc._leaky_site('Z1', x)
+    assert torch.equal(y, torch.nn.functional.leaky_relu(x, 0.2))
+    sign = torch.tensor([[False, True, False, True], [False, False, False, True]])          # flips at [0,1] [0,2] [1,0] [1,3]; agrees elsewhere
+    valid = torch.tensor([[True], [False]])                                                   # second row: override ignored
+    orc.leaky_signs = {'Z1': [(sign, valid)]}
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = orc._leaky_site('Z1', x2)
+    y2.sum().backward()
+    assert orc.leaky_signs['Z1'] == []                                                        # consumed in call order
+    assert torch.equal(x2.grad[0], torch.tensor([0.2, 1.0, 0.2, 1.0]))                        # pinned branches on the valid row
+    assert torch.equal(x2.grad[1], torch.tensor([1.0, 0.2, 1.0, 0.2]))                        # own branches on the other
+    assert float((y2 - y.detach()).abs().max()) < 1e-6 and torch.equal(y2[1], y.detach()[1])
+    orc.leaky_signs = None
+    assert torch.equal(orc._leaky_site('Z1', x.detach()), torch.nn.functional.leaky_relu(x.detach(), 0.2))
+
+
+def test_grad_significance_is_a_running_and_over_steps():
+    g1 = {'a': torch.tensor([1.0, 1e-6, 0.5]), 'b': torch.tensor([0.0, 0.0])}
+    g2 = {'a': torch.tensor([1e-6, 1.0, 0.5]), 'b': torch.tensor([0.0, 0.0])}
+    s1 = H.grad_significance(g1)
+    s2 = H.grad_significance(g2, acc=s1)
+    assert s1['a'].tolist() == [True, False, True] and s2['a'].tolist() == [False, False, True]
+    assert not s2['b'].any()
