@@ -260,37 +260,6 @@ struct TileLoaderBF {
             }
         }
     }
-    // fp32 -> three bf16 planes (split3), plane p at S + p * plane_stride; same [row][k] image per plane
-    __device__ __forceinline__ void store3(__bf16* __restrict__ S, int plane_stride) const {
-        const int tid = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int u = tid + i * NTH;
-            if (NU % NTH != 0 && u >= NU) continue;
-            if (XK) {
-                const int fr = u / (BK / 8), kc = u % (BK / 8);
-                bf16x8 h, m, l;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { __bf16 x, y, z; split3(__uint_as_float(comp(r[i][j >> 2], j & 3)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
-                __bf16* d = S + fr * LDK + kc * 8;
-                *reinterpret_cast<bf16x8*>(d) = h;
-                *reinterpret_cast<bf16x8*>(d + plane_stride) = m;
-                *reinterpret_cast<bf16x8*>(d + 2 * plane_stride) = l;
-            } else {
-                const int kb = u / (BF / 4), f4 = u % (BF / 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bf16x8 h, m, l;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { __bf16 x, y, z; split3(__uint_as_float(comp(r[i][j], c)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
-                    __bf16* d = S + (f4 * 4 + c) * LDK + kb * 8;
-                    *reinterpret_cast<bf16x8*>(d) = h;
-                    *reinterpret_cast<bf16x8*>(d + plane_stride) = m;
-                    *reinterpret_cast<bf16x8*>(d + 2 * plane_stride) = l;
-                }
-            }
-        }
-    }
 };
 
 
