@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: 256 sessions per GPU per step (global batch 256 x N); strong: global batch 256 sharded over the N GPUs "
                          "(SURVEY 8e / BASELINE configs[2]: 32 rows per GPU at N = 8)")
+    ap.add_argument("--no-native-arm", action="store_true",
+                    help="skip the comparison leg of --dtype f32: the same steps with every GEMM on the native fp32 MFMA")
     ap.add_argument("--no-ragged-leg", action="store_true",
                     help="skip the secondary G1-like-session-lengths leg (profiling runs: keeps per-symbol averages to the headline leg)")
     ap.add_argument("--state", default="device", choices=["device", "host"],
@@ -444,6 +446,28 @@ def main():
                   "valid_positions_of_padded": round(float(sum(d['P'] for d in rdev)) / float(sum(d['B'] * d['T'] for d in rdev)), 4),
                   "padded_T": [int(d['T']) for d in rdev]}
 
+    # ---- comparison leg (default fp32 arithmetic only): the SAME runtime, weights and batches with the plane-product GEMMs switched off,
+    # i.e. every GEMM on v_mfma_f32_32x32x2_f32 - so the line carries both arms measured in one run
+    native_arm = None
+    if args.dtype == "f32" and getattr(rt, 'x3', False) and not args.no_native_arm:
+        rt.x3 = False
+        n_arm = max(5, min(args.steps, 10))
+        for i in range(3):
+            one_step(args.warmup + args.steps + 200 + i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_arm):
+            one_step(args.warmup + args.steps + 203 + i)
+        barrier()
+        adt = time.perf_counter() - t0
+        rt.x3 = True
+        if world > 1:
+            tt = torch.tensor([adt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            adt = float(tt.item())
+        native_arm = {"gemm": "every GEMM on v_mfma_f32_32x32x2_f32 (--dtype f32_native), same runtime / weights / batches", "steps": n_arm,
+                      "value": round(Bg * n_arm / adt, 2), "unit": "sessions/s", "ms_per_step": round(adt / n_arm * 1e3, 3)}
+
     if rank == 0:
         L = rt.layout
         T = cfg['seq_len'] - 1
@@ -489,6 +513,8 @@ def main():
             out["roofline"].update(traffic=None, traffic_source=None)
         if ragged is not None:
             out["g1_like_session_lengths"] = ragged
+        if native_arm is not None:
+            out["native_fp32_mfma_arm"] = native_arm
         if world == 1 and not args.no_boundary_leg and args.config == "g1" and args.dtype in ("f32", "f32_native"):
             # SURVEY 8d's metric proper (input pipeline + H2D + hooks inside the clock), same workload as the headline and its
             # G1-like-session-lengths variant
