@@ -195,6 +195,7 @@ class NARRuntime:
         # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
         # per-CU matrix kernels that only time-slice the chip when they overlap
         self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
+        self.side_critical_first = os.environ.get("CHAM_SIDE_CRITICAL_FIRST", "1") == "1"
         # three more schedule arms suggested by the kernel trace of the plane-product build, each measured neutral or slower (A/B in one
         # gpurun call, ms/step: all off 12.95 | scorer layer-1 wgrad only after its dgrad dM 13.16 -> +0.06 | the small PreCAR-backward
         # GEMMs on the native fp32 kernels so that they co-reside with the W2 wgrad: +0.22 | b2 column sum before the W2 wgrad: -0.03):
@@ -967,24 +968,36 @@ class NARModuleModel:
         else:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         e_side0 = mark() if (on and rt.x3 and rt.ws1_after_dm) else e_dS1
-        with side(e_start, e_side0):
-            if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
-                rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
-                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
+        def scorer_small_wgrads():       # layers 2-4: short split-K GEMMs + column sums, nothing but Adam (and the early DP bucket) waits for them
+            if b16:
                 rt.gemm_b16(pl.S1, 128, 1, pl.dS2, 64, 0, g('Ws2'), 64, 1, 128, 64, Rc, splits=0)
                 rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'), b16=True)
                 rt.gemm_b16(pl.S2, 64, 1, pl.dS3, 32, 0, g('Ws3'), 32, 1, 64, 32, Rc, splits=0)
                 rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'), b16=True)
                 rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds, b16=True)
             else:
-                rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
-                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
                 rt.gemm(pl.S1, pl.dS2, g('Ws2'), 128, 64, Rc, 128, 64, 64, transA=1, splits=0)
                 rt.colsum(pl.dS2, 64, Rc, 64, g('bs2'))
                 rt.gemm(pl.S2, pl.dS3, g('Ws3'), 64, 32, Rc, 64, 32, 32, transA=1, splits=0)
                 rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
                 rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
             rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
+        # Side lane, "critical chain first" (CHAM_SIDE_CRITICAL_FIRST, default on): with short sessions the CAR GEMMs shrink and the
+        # main lane ends up waiting for the clicked-row gradient that comes out of the side lane's FC -> recurrent -> CAR chain (0.4 ms
+        # of a 3.4 ms step in the kernel trace of the G1-like bench leg).  So that chain is enqueued ahead of every weight / bias
+        # gradient it does not need; those follow behind it.
+        # (bf16 configuration with full-length sessions: 6.26 vs 6.17 ms - the deferred gradients then land beside the W2 wgrad - so there it
+        # is used for compacted, i.e. ragged, batches only: 2.23 vs 2.35 ms; fp32: 13.0 = 13.0 ms full-length, 2.95 vs 3.11 ms G1-like lengths)
+        crit_first = on and rt.side_critical_first and (not b16 or pos is not None)
+        with side(e_start, e_side0):
+            if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
+                rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
+                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
+            else:
+                rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
+                rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
+            if not crit_first:
+                scorer_small_wgrads()
         # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
         # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
         # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
@@ -1031,16 +1044,22 @@ class NARModuleModel:
         last = L.L - 1
         with side(e_dZ2c):
             ss = _stream()
-            rt.gemm(pl.FC1d if drop else pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
-            rt.colsum(pl.dpred, C, BT, C, g('bf2'))
+            rnn_y = (lambda l: pl.rnn_drop[l]) if drop else (lambda l: pl.rnn_out[l])     # what the next layer / FC1 consumed
+
+            def fc_wgrads():
+                rt.gemm(pl.FC1d if drop else pl.FC1, pl.dpred, g('Wf2'), 512, C, BT, 512, C, C, transA=1, splits=0)
+                rt.colsum(pl.dpred, C, BT, C, g('bf2'))
+                rt.gemm(pl.rnn_c if pos is not None else rnn_y(last), pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
+                rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
+                if crit_first:
+                    scorer_small_wgrads()
+                if rt.dp_early_bucket is not None and not self._accumulating:
+                    rt.dp_early_bucket(rt.grads)     # data parallel: [Wf1 .. Ws4] gradients are final - their all-reduce starts now
             rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
             if drop:                     # (mask and leaky' are both element-wise factors: the order does not matter)
                 dropout(pl.dFC1, pl.dFC1, BT, 512, 512, 19, 19, 1, pos)
-            rnn_y = (lambda l: pl.rnn_drop[l]) if drop else (lambda l: pl.rnn_out[l])     # what the next layer / FC1 consumed
-            rt.gemm(pl.rnn_c if pos is not None else rnn_y(last), pl.dFC1, g('Wf1'), Hp, 512, BT, Hp, 512, 512, transA=1, splits=0)
-            rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
-            if rt.dp_early_bucket is not None and not self._accumulating:
-                rt.dp_early_bucket(rt.grads)     # data parallel: [Wf1 .. Ws4] gradients are final - their all-reduce starts now
+            if not crit_first:
+                fc_wgrads()
             if pos is not None:          # d rnn_out back into the [B, T] layout (zero at padded steps)
                 rt.gemm(pl.dFC1, p('Wf1'), pl.drnn_c, BT, Hp, 512, 512, 512, Hp, transB=1)
                 pl.drnn.zero_()
@@ -1075,6 +1094,8 @@ class NARModuleModel:
                     # 256 workgroups fill every CU's register file for 4 ms) - the main lane's PreCAR backward waits for it ...
                     rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
                     e_dZ1in = mark()
+                    if crit_first:
+                        fc_wgrads()
                     if b16:
                         # ... and the CAR layer-2 weight gradient: the candidate rows (bf16, TN) + the clicked-input rows (fp32), runs beside it
                         rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0)
