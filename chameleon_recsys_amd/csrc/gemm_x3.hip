@@ -14,7 +14,8 @@
 // Storage, windows, tile swizzle, split-K placement and the epilogue are those of gemm.hip (gemm_shared.h).  LDS image per plane:
 // [row][k] bf16, row stride BK + 8 = 24 elements (48 B = 3 x 16-B slots, coprime with the 16 slots of a bank row), planes and the
 // two pipeline buffers behind each other: 2 x 3 x (BM + BN) x 48 B = 110.6 KB for 256x128, 73.7 KB for 128x128.
-// Inf / NaN: an infinite operand gives NaN (inf - inf in the split) where fp32 would give inf; finite data is unaffected.
+// Inf / NaN: an infinite operand gives NaN (inf - inf in the split) where fp32 would give inf; operands below 2^-100 lose their lowest
+// plane to bf16's subnormal range (absolute error <= 2^-133 per element); everything else is exact (tests/test_split3_cpu.py).
 // ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 512 = no s_barrier in the loop (wrong results, timing only), 1024 = no lgkmcnt(0) either, 2 = no global
 // loads in the loop, 4 = no fragment ds_reads in the loop, 8 = one MFMA pass instead of six, 16 = no LDS writes in the loop
 #ifndef X3_ABL
