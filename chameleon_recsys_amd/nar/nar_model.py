@@ -28,7 +28,16 @@ class ModeKeys:                       # tf.estimator.ModeKeys
     PREDICT = 'infer'
 
 
+# Raw handle (hipStream_t as an int) of torch's current stream.  torch.cuda.current_stream() builds a Python Stream object (~8 us);
+# a step makes ~100 launches, and with short sessions the host's enqueue time is what bounds the boundary throughput - the private
+# C getters cost ~0.3 us.  (Fallback if a torch build lacks them.)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -175,6 +184,7 @@ class NARRuntime:
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
         self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
+        self._side_raw = self.side_stream.cuda_stream
         self.aux_stream = torch.cuda.Stream(device=dev, priority=-1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
@@ -302,7 +312,7 @@ class NARRuntime:
              dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False):
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
+            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
         prof = self.profile
         bf16 = self.gemm_dtype == 'bf16' and not force_f32
         x3 = self.x3 and not force_f32
@@ -345,7 +355,7 @@ class NARRuntime:
         """bf16-resident GEMM (csrc/gemm_b16.hip): NT (transA=0, transB=1) or TN (transA=1, transB=0)."""
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if torch.cuda.current_stream() == self.side_stream else self.gemm_ws
+            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
         prof = self.profile
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -369,7 +379,7 @@ class NARRuntime:
         return list(out)
 
     def colsum(self, X, ld, R, F, out, w=None, accumulate=0, b16=False):
-        ws = self.colsum_ws_side if torch.cuda.current_stream() == self.side_stream else self.colsum_ws
+        ws = self.colsum_ws_side if _stream() == self._side_raw else self.colsum_ws
         check((self.lib.cham_colsum_b16 if b16 else self.lib.cham_colsum)(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws),
                                                                            ws.numel() * 4, _stream()), "cham_colsum")
 
