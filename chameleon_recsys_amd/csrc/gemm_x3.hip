@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
-// launch counters: [0] 128x128, [1] 256x128, [2] 256x256, [3] delegated to the native fp32 kernels (N <= 64), [6] EPI and [7] K-splits
+// launch counters: [0] 128x128, [1] 256x128, [3] delegated to the native fp32 kernels (N <= 64), [6] EPI and [7] K-splits
 // of the last launch
 static long long g_x3_launches[8];
 extern "C" void cham_gemm_f32x3_launch_counts(long long* out8, int reset) {

@@ -122,8 +122,8 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
 int cham_gemm_f32x3(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
                     int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,
                     int rs_div, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
-/* test / tuning aids: tile variant (0 = 128x128, 2 = 256x128, 4 = 256x256, -1 = automatic); launches since the last reset -
- * out8[0..2] = those tiles, out8[3] = delegated to cham_gemm_f32, out8[6] / out8[7] = epilogue variant / K-splits of the last launch */
+/* test / tuning aids: tile variant (0 = 128x128 / 4 waves, 2 = 256x128 / 8 waves, -1 = automatic); launches since the last reset -
+ * out8[0] / out8[1] = those tiles, out8[3] = delegated to cham_gemm_f32, out8[6] / out8[7] = epilogue variant / K-splits of the last launch */
 void cham_gemm_f32x3_set_variant(int variant);
 void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
 
