@@ -7,17 +7,20 @@
 // bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result carries the same kind of
 // error as the native fp32 MFMA path (fp32 accumulation rounding; tests/test_gemm_x3_gpu.py measures both against float64 on the
 // same operands).  Why: gfx950's fp32 matrix rate is 1/16 of its bf16 rate (157 vs 2 500 TFLOP/s dense), so six bf16 products cost
-// 6/16 of one fp32 product - an fp32-accurate GEMM with a 417 TFLOP/s ceiling instead of 157.  The K loop is matrix-core bound:
-// per 16 k of a 256x128 tile every wave issues 24 MFMAs (768 cycles) against 3 global float4 loads, 36 split conversions and 12
-// ds_read_b128 per lane.
+// 6/16 of one fp32 product - an fp32-accurate GEMM with a 417 TFLOP/s ceiling instead of 157.  Per 16 k of a 256x128 tile every wave
+// issues 24 MFMAs (768 matrix-pipe cycles) and ~117 other instructions (3 global float4 loads, the split of 12 elements, 12
+// ds_read_b128, 5 LDS writes); measured 184-194 TFLOP/s stand-alone at the CAR shapes = 0.44-0.47 of the ceiling, 1.5x the native
+// fp32 MFMA kernels (profiles/r02_notes.md item 4 for what bounds it).
 //
 // Storage, windows, tile swizzle, split-K placement and the epilogue are those of gemm.hip (gemm_shared.h).  LDS image per plane:
 // [row][k] bf16, row stride BK + 8 = 24 elements (48 B = 3 x 16-B slots, coprime with the 16 slots of a bank row), planes and the
 // two pipeline buffers behind each other: 2 x 3 x (BM + BN) x 48 B = 110.6 KB for 256x128, 73.7 KB for 128x128.
 // Inf / NaN: an infinite operand gives NaN (inf - inf in the split) where fp32 would give inf; operands below 2^-100 lose their lowest
 // plane to bf16's subnormal range (absolute error <= 2^-133 per element); everything else is exact (tests/test_split3_cpu.py).
-// ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library): 1 = no split arithmetic (raw bits stored), 64 = accumulators in AccVGPRs (inline asm), 128 = role split (waves 0-3 only MFMAs, waves 4-7 only the other streams), 512 = no s_barrier in the loop (wrong results, timing only), 1024 = no lgkmcnt(0) either, 2 = no global
-// loads in the loop, 4 = no fragment ds_reads in the loop, 8 = one MFMA pass instead of six, 16 = no LDS writes in the loop
+// Ablation bits for probe builds (scripts/ab_x3.sh; 0 in the product library; results are wrong with most of them, timing only):
+//   1 no split arithmetic (raw bits stored) | 2 no global loads in the loop | 4 no fragment ds_reads | 8 one MFMA pass instead of six
+//   16 no split / LDS writes | 64 accumulators pinned to AccVGPRs (inline asm) | 128 role split: waves 0-3 only MFMAs, waves 4-7 only
+//   the other streams | 512 no s_barrier in the loop | 1024 no lgkmcnt(0) before it
 #ifndef X3_ABL
 #define X3_ABL 0
 #endif
