@@ -127,6 +127,27 @@ int cham_gemm_f32x3(const float* A, int lda, int transA, const float* B, int ldb
 void cham_gemm_f32x3_set_variant(int variant);
 void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
 
+/* fp32-grade GEMM over operands that already live in HBM as THREE bf16 PLANES (csrc/gemm_p3.hip, round 3): the same six plane products
+ * as cham_gemm_f32x3, but the split is done once by the kernel that produces the matrix (cham_combine_fwd_p3, cham_mulpred_bwd_p3,
+ * cham_split3 for weights) and the K loop is MFMAs + fragment reads + LDS-DMA only.  Replaces the CAR layer-2 matmul over the
+ * B*T*(1+N) candidate rows (nar_model.py:374-405, tf.layers.Dense `CAR_representation`) and its two autodiff twins.
+ *   A, B: plane 0 (bf16); planes `*_plane_stride` ELEMENTS apart (h, m, l).
+ *   tn = 0 (NT): A [M, lda], B [N, ldb], k contiguous, K % 16 == 0; epilogue + bias and act (CHAM_ACT_NONE / CHAM_ACT_TANH), or
+ *     x leaky'(saved activation) with dref_h = the h plane [M, ldr] of that activation and dact = CHAM_ACT_LEAKY.
+ *   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N]; M % 256 == 0, N % 256 == 0, any K; split-K through `workspace`
+ *     (splits_hint: 1 none, 0 automatic, n at most n; fixed-order reduction); accumulate adds to C.
+ * Returns -EINVAL for a shape it does not take (the caller keeps cham_gemm_f32x3 for those).  Leading dimensions and plane strides
+ * % 8 == 0, 16-byte aligned bases.  cham_gemm_p3_launch_counts: out8[0] / out8[1] = NT / TN launches since the last reset, out8[6] /
+ * out8[7] = epilogue variant / K-splits of the last launch. */
+int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, const void* B, long long b_plane_stride, int ldb, int tn, float* C,
+                 int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr, int dact, int accumulate,
+                 float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+void cham_gemm_p3_launch_counts(long long* out8, int reset);
+/* split3 of an fp32 matrix X [R, Cc] (row stride ld) into bf16 planes: dst[q][r][c] (planes plane_stride elements apart, row stride
+ * ldd) and / or dstT[q][c][r] (the transposed matrix); either may be NULL.  a = h + m + l exactly (tests/test_split3_cpu.py). */
+int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
+                int lddT, void* stream);
+
 /* bf16-RESIDENT GEMMs of the bf16 configuration (csrc/gemm_b16.hip): the matrices with one row per candidate live in HBM as bf16
  * (weights: a bf16 shadow of the fp32 master copy); fp32 accumulation / bias / activation.
  *   transA = 0, transB = 1 (NT): A [M, lda], B [N, ldb] bf16, k contiguous; C bf16 (out_f32 = 0) or fp32 [M, ldc];
