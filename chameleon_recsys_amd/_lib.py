@@ -39,7 +39,10 @@ _SIGNATURES = {
     "cham_gemm_p3": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                              P, c_size_t, c_int, P]),
     "cham_gemm_p3_launch_counts": (None, [P, c_int]),
+    "cham_gemm_p3_set_variant": (None, [c_int]),
     "cham_split3": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P]),
+    "cham_combine_fwd_p3": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
+    "cham_mulpred_bwd_p3": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P]),
     "cham_gemm_b16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                               P, c_size_t, c_int, P]),
     "cham_gemm_b16_set_variant": (None, [c_int]),

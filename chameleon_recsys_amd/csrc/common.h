@@ -84,6 +84,32 @@ __device__ __forceinline__ void st4(__bf16* p, const float4& v) {
     *reinterpret_cast<bf16x4_t*>(p) = b;
 }
 
+// a = h + m + l with h = bf16(a), m = bf16(a - h), l = bf16(a - h - m) (round to nearest even; the two subtractions are exact in fp32):
+// three 8-bit significands cover fp32's 24, so the sum is exact up to the last bit (gemm_x3.hip, gemm_p3.hip; tests/test_split3_cpu.py)
+// (The compiler SLP-packs pairs of the subtractions into v_pk_add_f32, a costly filler beside MFMAs per MI355X_MICROARCH.md; forcing
+// scalar v_sub_f32 through inline asm also un-pairs the v_cvt_pk_bf16_f32 conversions and measured 1-3 % slower: profiles/r02_notes.md.)
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)a;
+    float r = a - (float)h;
+    m = (__bf16)r;
+    r -= (float)m;
+    l = (__bf16)r;
+}
+
+// 4 consecutive elements of a row -> the three planes of a plane-resident matrix (planes `ps` elements apart): 8-byte stores
+__device__ __forceinline__ void st4_planes(__bf16* p, long long ps, const float4& v) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t h, m, l;
+    __bf16 a, b, c;
+    split3(v.x, a, b, c); h[0] = a; m[0] = b; l[0] = c;
+    split3(v.y, a, b, c); h[1] = a; m[1] = b; l[1] = c;
+    split3(v.z, a, b, c); h[2] = a; m[2] = b; l[2] = c;
+    split3(v.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
+    *reinterpret_cast<bf16x4_t*>(p) = h;
+    *reinterpret_cast<bf16x4_t*>(p + ps) = m;
+    *reinterpret_cast<bf16x4_t*>(p + 2 * ps) = l;
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -31,6 +31,7 @@
 //   check (one descriptor per plane: out-of-range pieces arrive as zeros).
 // Epilogues: plain, + bias -> tanh (CAR forward), x leaky'(h plane of the saved activation) (CAR dgrad), split-K partial (wgrad).
 #include "gemm_shared.h"
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -80,6 +81,37 @@ __device__ __forceinline__ void p3_dma_stage(unsigned lds0, unsigned va, unsigne
         : "memory");
 }
 
+// one request (the staggered pipeline issues one per MFMA pass)
+__device__ __forceinline__ void p3_dma_one(unsigned lds, unsigned voff, const u32x4& r) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r) : "memory");
+}
+
+// one MFMA pass: acc[i][j] += X[i] * Y[j] over the wave's 4 x 2 tiles, with `aux` (this pass's DMA request and fragment reads) placed
+// after the first MFMA for wave group 0 and after the fifth for group 1: the two waves of a SIMD are released by the same barrier and
+// would otherwise stop issuing MFMAs for their memory instructions at the same moment, leaving the matrix pipe idle.
+template <int G, typename AuxF>
+__device__ __forceinline__ void p3_pass(floatx16 (&acc)[4][2], const bf16x8 (&X)[4], const bf16x8 (&Y)[2], AuxF&& aux) {
+    constexpr int SPLIT = G == 0 ? 1 : 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (i * 2 + j == SPLIT) {
+                __builtin_amdgcn_sched_barrier(0);
+                aux();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <bool TN>
 __device__ __forceinline__ bf16x8 p3_frag(const unsigned char* __restrict__ s) {
     if constexpr (!TN) {
@@ -106,7 +138,7 @@ __device__ __forceinline__ void p3_barrier() {
 }
 
 // EPI: 0 plain, 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias, 6 split-K partial
-template <bool TN, int EPI>
+template <bool TN, int EPI, int VAR>
 __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TNN = 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     const unsigned wave_off = (unsigned)wave * 1024u;
     bf16x8 AH[TM], AM[TM], AL[TM], BH[TNN], BMf[TNN], BL[TNN];
 
-    if (nk > 0) {
+    if (VAR == 0 && nk > 0) {          // first version: all six requests at the top of a step, both wave groups in lockstep
         p3_dma_stage(lds_base + wave_off, va, vb, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
         va += stepa; vb += stepb;
         p3_dma_stage(lds_base + P3_STAGE + wave_off, va, vb, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
@@ -278,6 +310,86 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
     }
 
+    if (VAR == 1 && nk > 0) {
+        // Staggered pipeline.  Stage s: its A slabs are requested in P3..P5 of step s - 3 (into the slot of stage s - 3, whose last
+        // fragment reads precede that step's barrier), its B slabs in P0..P2 of step s - 2; its early fragments are read after the
+        // barrier of step s - 1, before which every wave has waited for them: s_waitcnt vmcnt(6) - the six younger requests (A of
+        // stage s + 1, B of stage s + 1) stay in flight.  One request and a few fragment reads per pass, at different points of the
+        // pass for the two waves of a SIMD (p3_pass).
+        unsigned vaN = va, vbN = vb;
+        p3_dma_stage(lds_base + wave_off, vaN, vbN, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
+        vaN += stepa; vbN += stepb;
+        p3_dma_stage(lds_base + P3_STAGE + wave_off, vaN, vbN, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
+        vaN += stepa; vbN += stepb;
+        p3_dma_one(lds_base + 2 * P3_STAGE + 0 * P3_SLAB + wave_off, vaN, ra[0]);
+        p3_dma_one(lds_base + 2 * P3_STAGE + 1 * P3_SLAB + wave_off, vaN, ra[1]);
+        p3_dma_one(lds_base + 2 * P3_STAGE + 2 * P3_SLAB + wave_off, vaN, ra[2]);
+        vaN += stepa;
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        p3_barrier();
+        {   // early fragments of stage 0
+            const unsigned char* S = p3_smem;
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<TN>(S + 3 * P3_SLAB + fb[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) AL[i] = p3_frag<TN>(S + 2 * P3_SLAB + fa[i]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<TN>(S + 5 * P3_SLAB + fb[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) AM[i] = p3_frag<TN>(S + 1 * P3_SLAB + fa[i]);
+        }
+        auto run = [&](auto GG) {
+            constexpr int G = decltype(GG)::value;
+            int cur = 0;
+            for (int i = 0; i < nk; ++i) {
+                const int nxt = cur == P3_RING - 1 ? 0 : cur + 1, nx2 = nxt == P3_RING - 1 ? 0 : nxt + 1;
+                const unsigned char* Sc = p3_smem + cur * P3_STAGE;
+                const unsigned char* Sn = p3_smem + nxt * P3_STAGE;
+                const unsigned lb = lds_base + (unsigned)nx2 * P3_STAGE + wave_off;      // B slabs of stage i + 2
+                const unsigned la = lds_base + (unsigned)cur * P3_STAGE + wave_off;      // A slabs of stage i + 3
+                __builtin_amdgcn_sched_barrier(0);
+                p3_pass<G>(acc, AL, BH, [&] {
+                    p3_dma_one(lb + 3 * P3_SLAB, vbN, rb[0]);
+#pragma unroll
+                    for (int ii = 0; ii < TM; ++ii) AH[ii] = p3_frag<TN>(Sc + 0 * P3_SLAB + fa[ii]);
+                });
+                p3_pass<G>(acc, AM, BH, [&] {
+                    p3_dma_one(lb + 4 * P3_SLAB, vbN, rb[1]);
+#pragma unroll
+                    for (int j = 0; j < TNN; ++j) BMf[j] = p3_frag<TN>(Sc + 4 * P3_SLAB + fb[j]);
+                });
+                p3_pass<G>(acc, AH, BH, [&] {
+                    p3_dma_one(lb + 5 * P3_SLAB, vbN, rb[2]);
+                });
+                vbN += stepb;
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                p3_barrier();
+                p3_pass<G>(acc, AH, BL, [&] {
+                    p3_dma_one(la + 0 * P3_SLAB, vaN, ra[0]);
+#pragma unroll
+                    for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<TN>(Sn + 3 * P3_SLAB + fb[j]);
+#pragma unroll
+                    for (int ii = 0; ii < TM; ++ii) AL[ii] = p3_frag<TN>(Sn + 2 * P3_SLAB + fa[ii]);
+                });
+                p3_pass<G>(acc, AM, BMf, [&] {
+                    p3_dma_one(la + 1 * P3_SLAB, vaN, ra[1]);
+#pragma unroll
+                    for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<TN>(Sn + 5 * P3_SLAB + fb[j]);
+                });
+                p3_pass<G>(acc, AH, BMf, [&] {
+                    p3_dma_one(la + 2 * P3_SLAB, vaN, ra[2]);
+#pragma unroll
+                    for (int ii = 0; ii < TM; ++ii) AM[ii] = p3_frag<TN>(Sn + 1 * P3_SLAB + fa[ii]);
+                });
+                vaN += stepa;
+                cur = nxt;
+            }
+        };
+        if (wave < 4) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
+    }
+
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int kl = lane_e >> 5, fl = lane_e & 31;
@@ -349,11 +461,14 @@ extern "C" void cham_gemm_p3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_p3_launches[i]; if (reset) g_p3_launches[i] = 0; }
 }
 
-template <bool TN, int EPI>
-static int p3_launch(P3Params& p, hipStream_t st) {
+static int g_p3_variant = 1;      // 1 = staggered pipeline (default), 0 = first version (A/B arm of tests/bench_gemm_p3.py)
+extern "C" void cham_gemm_p3_set_variant(int v) { g_p3_variant = v; }
+
+template <bool TN, int EPI, int VAR>
+static int p3_launch_var(P3Params& p, hipStream_t st) {
     g_p3_launches[6] = EPI; g_p3_launches[7] = p.splits;
     constexpr int smem = P3_RING * P3_STAGE;
-    auto k = gemm_p3_kernel<TN, EPI>;
+    auto k = gemm_p3_kernel<TN, EPI, VAR>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -363,6 +478,10 @@ static int p3_launch(P3Params& p, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+template <bool TN, int EPI>
+static int p3_launch(P3Params& p, hipStream_t st) {
+    return g_p3_variant == 0 ? p3_launch_var<TN, EPI, 0>(p, st) : p3_launch_var<TN, EPI, 1>(p, st);
 }
 
 // C[M,N] = epi(sum of six plane products) - see the header.  A, B: plane 0 (bf16), planes `*_plane_stride` elements apart.

@@ -148,18 +148,6 @@ __device__ __forceinline__ void mul4(u32x4& a, const u32x4& b) {
     a.z = __float_as_uint(__uint_as_float(a.z) * __uint_as_float(b.z)); a.w = __float_as_uint(__uint_as_float(a.w) * __uint_as_float(b.w));
 }
 __device__ __forceinline__ unsigned comp(const u32x4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
-// a = h + m + l with h = bf16(a), m = bf16(a - h), l = bf16(a - h - m) (round to nearest even; the two subtractions are exact in fp32):
-// three 8-bit significands cover fp32's 24, so the sum is exact up to the last bit (gemm_x3.hip)
-// (The compiler SLP-packs pairs of the subtractions into v_pk_add_f32, a costly filler beside MFMAs per MI355X_MICROARCH.md; forcing
-// scalar v_sub_f32 through inline asm also un-pairs the v_cvt_pk_bf16_f32 conversions and measured 1-3 % slower: profiles/r02_notes.md.)
-__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)a;
-    float r = a - (float)h;
-    m = (__bf16)r;
-    r -= (float)m;
-    l = (__bf16)r;
-}
-
 // One operand tile [BF x BK] staged as bf16.  XK: unit = 8 consecutive k of one row (2 float4).  !XK: unit = an 8(k) x 4(f)
 // block (8 float4 from 8 consecutive stored rows), transposed in registers into 4 x (8 bf16 along k).
 template <int BF, int BK, bool XK, int NTH, bool RS>

@@ -143,10 +143,21 @@ int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, const void* B
                  int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr, int dact, int accumulate,
                  float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 void cham_gemm_p3_launch_counts(long long* out8, int reset);
+/* A/B aid (tests/bench_gemm_p3.py): 1 = staggered pipeline (default), 0 = the first version (all requests of a stage at the top of a step) */
+void cham_gemm_p3_set_variant(int variant);
 /* split3 of an fp32 matrix X [R, Cc] (row stride ld) into bf16 planes: dst[q][r][c] (planes plane_stride elements apart, row stride
  * ldd) and / or dstT[q][c][r] (the transposed matrix); either may be NULL.  a = h + m + l exactly (tests/test_split3_cpu.py). */
 int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
                 int lddT, void* stream);
+
+/* producers of plane-resident matrices (csrc/scorer.hip): the candidate rows of the PreCAR output leaky(U[b,t] + V[item])
+ * (nar_model.py:356-405) and the gradient at the CAR tanh (autodiff of nar_model.py:478-495: dM * pred * (1 - Z2^2)) written as three
+ * bf16 planes `plane_stride` elements apart; cham_mulpred_bwd_p3 also writes dpred_pre (as cham_mulpred_bwd) and, when col_part !=
+ * NULL, col_part[bt] = the sum of position bt's 1 + N gradient rows (the b2 bias gradient = column sum of col_part). */
+int cham_combine_fwd_p3(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                        long long plane_stride, void* stream);
+int cham_mulpred_bwd_p3(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,
+                        long long plane_stride, float* col_part, void* stream);
 
 /* bf16-RESIDENT GEMMs of the bf16 configuration (csrc/gemm_b16.hip): the matrices with one row per candidate live in HBM as bf16
  * (weights: a bf16 shadow of the fp32 master copy); fp32 accumulation / bias / activation.

@@ -55,7 +55,8 @@ def main():
     res = {}
     for name, p3, x3, out, ref in cases:
         Rf = ref(); scale = float(Rf.abs().max())
-        for tag, fn in (("planes in HBM (p3)", p3), ("split on the fly (x3)", x3)):
+        for tag, fn in (("planes in HBM (p3)", p3), ("p3, first version", p3), ("split on the fly (x3)", x3)):
+            lib.cham_gemm_p3_set_variant(0 if tag == "p3, first version" else 1)
             out().zero_()
             fn(); torch.cuda.synchronize()
             err = float((out().double() - Rf).abs().max()) / scale
