@@ -89,6 +89,8 @@ def gemm_symbol(r):
     if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
         return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
+        return "void gemm_p3_kernel<%s, %d, 0>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
         rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
@@ -369,7 +371,10 @@ def main():
         sh[0] += 1; sh[1] += t_ms
         # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
         # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
-        if r.get('b16'):
+        if r.get('p3'):       # operands as three bf16 planes (6 B per element), fp32 output, the dgrad reads the activation's h plane
+            e['bytes'] += 6.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
+                (4.0 * r['N'] if r['bias'] else 0)
+        elif r.get('b16'):
             e['bytes'] += 2.0 * (r['M'] * r['K'] + r['K'] * r['N'] + (r['M'] * r['N'] if r['dref'] else 0)) + \
                 (4.0 if (r['out_f32'] or r['epi'] == 6) else 2.0) * r['M'] * r['N'] + (4.0 * r['N'] if r['bias'] else 0)
         else:
@@ -384,13 +389,15 @@ def main():
                                                                  ("NT (dgrad)" if r['dref'] or not r['bias'] else "NT (forward, transposed weight shadow)"))
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
             sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else
-            ("fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
+            ("fp32-grade (operands resident in HBM as three bf16 planes written by their producers, six bf16 MFMA products per fp32 product, "
+             "fp32 accumulate, LDS-DMA staging)" if r.get('p3') else
+             "fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])
 
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if e['r'].get('x3') else FP32_MATRIX_PEAK_TFLOPS)
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3')) else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
                 "mfma_peak_tflops": round(peak, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4),
@@ -401,7 +408,7 @@ def main():
                              for (m, n_, k), (c, t) in sorted(e['shapes'].items(), key=lambda kv: -kv[1][1])[:3]]}
     DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
     n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
-    dom_x3 = bool(dom['r'] and dom['r'].get('x3'))
+    dom_x3 = bool(dom['r'] and (dom['r'].get('x3') or dom['r'].get('p3')))
     dom_peak = X3_MATRIX_PEAK_TFLOPS if dom_x3 else FP32_MATRIX_PEAK_TFLOPS
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
     traffic, traffic_src = None, None
@@ -483,9 +490,10 @@ def main():
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
-                       "gemm": {"f32": "fp32 storage / accumulate / epilogues; GEMMs with N > 64 split each fp32 operand into three bf16 planes and "
-                                       "accumulate six plane products on v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py), "
-                                       "N <= 64 on v_mfma_f32_32x32x2_f32",
+                       "gemm": {"f32": "fp32 accumulate / epilogues; GEMMs with N > 64 as six bf16-plane products per fp32 product on "
+                                       "v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py, tests/test_gemm_p3_gpu.py) - the three candidate-row "
+                                       "CAR GEMMs over planes their producers wrote to HBM (csrc/gemm_p3.hip), the others split while staged "
+                                       "(csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32",
                                 "f32_native": "every GEMM on v_mfma_f32_32x32x2_f32",
                                 "bf16": "bf16-resident candidate-row matrices, fp32 accumulate"}[args.dtype],
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),

@@ -157,7 +157,11 @@ class NARRuntime:
         # 'bf16': BASELINE config 3 (bf16-resident candidate-row matrices, fp32 accumulate).
         if self.gemm_dtype not in ('f32', 'f32_native', 'bf16'):
             raise ValueError("gemm_dtype must be 'f32', 'f32_native' or 'bf16'")
-        self.x3 = self.gemm_dtype == 'f32' and os.environ.get("CHAM_GEMM_X3", "1") == "1" 
+        self.x3 = self.gemm_dtype == 'f32' and os.environ.get("CHAM_GEMM_X3", "1") == "1"
+        # plane-resident CAR GEMMs (csrc/gemm_p3.hip): the candidate rows of Z1 and dZ2 live in HBM as three bf16 planes written by
+        # their producers, W2 / W2^T get plane shadows once per step; same six plane products as gemm_x3.hip.  CHAM_GEMM_P3=0: the
+        # on-the-fly split for those three GEMMs too (A/B arm; also what shapes gemm_p3 does not take fall back to)
+        self.p3 = self.x3 and os.environ.get("CHAM_GEMM_P3", "1") == "1" and self.layout.C % 256 == 0
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -231,6 +235,10 @@ class NARRuntime:
                 r, c = L.entries[name].shape
                 self.shadow[name] = torch.zeros(r, c, dtype=torch.bfloat16, device=dev)
                 self.shadow[name + 'T'] = torch.zeros(c, r, dtype=torch.bfloat16, device=dev)
+        if self.p3:
+            C_ = L.C
+            self.w2p = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)       # planes of W2 as stored (CAR dgrad)
+            self.w2tp = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)      # planes of W2^T (CAR forward)
         self._plans = {}
         self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
         self.plan_bytes_budget = 128 << 30        # of the 288 GB: activations of the cached shapes
@@ -261,14 +269,19 @@ class NARRuntime:
         self.weights_version += 1
 
     def refresh_shadows(self):
-        """bf16 shadows of the candidate-row GEMM weights, once per weight version (one small launch per weight)."""
+        """bf16 shadows (bf16 configuration) / bf16 plane shadows of W2 (plane-resident CAR GEMMs) of the candidate-row GEMM weights,
+        once per weight version (one small launch per weight)."""
         key = (self.global_step, self.weights_version)
-        if not self.b16 or key == self._shadow_key:
+        if not (self.b16 or self.p3) or key == self._shadow_key:
             return
-        for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
-            r, c = self.layout.entries[name].shape
-            check(self.lib.cham_cast_b16(ptr(self.p(name)), r, c, ptr(self.shadow[name]), ptr(self.shadow[name + 'T']), _stream()),
-                  "cham_cast_b16")
+        if self.p3:
+            C = self.layout.C
+            check(self.lib.cham_split3(ptr(self.p('W2')), C, C, C, ptr(self.w2p), C * C, C, ptr(self.w2tp), C * C, C, _stream()), "cham_split3")
+        if self.b16:
+            for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
+                r, c = self.layout.entries[name].shape
+                check(self.lib.cham_cast_b16(ptr(self.p(name)), r, c, ptr(self.shadow[name]), ptr(self.shadow[name + 'T']), _stream()),
+                      "cham_cast_b16")
         self._shadow_key = key
 
     def state_dict(self):
@@ -372,6 +385,26 @@ class NARRuntime:
                              bias=bias is not None, rowscale=False, bf16=True, b16=True, out_f32=int(c1[5]), tile=tile, epi=int(c1[6]),
                              ev=(e0, e1)))
 
+    def gemm_p3(self, A, a_ps, lda, B, b_ps, ldb, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
+                accumulate=0, splits=1):
+        """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K)."""
+        ws = None
+        if splits != 1:
+            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(self.lib.cham_gemm_p3(ptr(A), a_ps, lda, ptr(B), b_ps, ldb, tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h), ldr, dact,
+                                    accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_p3")
+        if prof is not None:
+            e1.record()
+            import ctypes
+            c = (ctypes.c_longlong * 8)()
+            self.lib.cham_gemm_p3_launch_counts(c, 0)
+            prof.append(dict(M=M, N=N, K=K, transA=tn, transB=0 if tn else 1, splits=int(c[7]), act=act, dref=dref_h is not None, dact=dact,
+                             bias=bias is not None, rowscale=False, bf16=False, p3=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
+
     def _tile_counts_b16(self):
         import ctypes
         out = (ctypes.c_longlong * 8)()
@@ -457,6 +490,11 @@ class StepPlan:
             self.Z2 = f32(Rall, C)
             self.dZ2 = f32(Rall, C)
             self.dZ1 = f32(Rall, C)
+        self.p3 = rt.p3
+        if rt.p3:     # plane-resident operands of the three candidate-row CAR GEMMs (planes Rc * C elements apart) + b2 partial sums
+            self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
+            self.p3_ps = Rc * C
+            self.b2part = f32(BT, C)
         # RNN
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
         NG = L.NG
@@ -506,6 +544,17 @@ class StepPlan:
             self.rnn_drop = [f32(self.BT, L.Hp) for _ in range(L.L)]
             need = rt.lib.cham_combine_bwd_workspace_bytes(Fw, self.B * self.T, self.N, self.pmax)
             self.drop_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+
+    def cand_Z1(self, P=None):
+        """Candidate rows of the PreCAR output of the last step as fp32 [P * NC, C] (tests): the fp32 matrix, or the sum of its planes."""
+        P = self.P if P is None else P
+        n = P * self.NC
+        if getattr(self, 'used_p3', False):
+            z = self.Z1p[:, :n].float()
+            return z[0] + z[1] + z[2]
+        if self.Z1.shape[0] == self.BT and hasattr(self, 'Z1c'):
+            return self.Z1c[:n].float()
+        return self.Z1[P:P + n]
 
     def use_sampler_set(self, k):
         self._samp_cur = k
@@ -733,6 +782,7 @@ class NARModuleModel:
         B, T, N = d['B'], d['T'], self.negative_samples
         pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
         self._plan, self._d = pl, d
+        pl.used_p3 = False
         torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
         # BT = rows of the row-wise stages = the P valid positions (all B*T when nothing is padded); BTf = the [B, T] layout
@@ -882,11 +932,17 @@ class NARModuleModel:
             rt.gemm_b16(pl.S2, 64, 0, sh['Ws3T'], 64, 1, pl.S3, 32, 0, Rc, 32, 64, bias=p('bs3'), act=ACT_LEAKY)
             softmax_fwd = lib.cham_score_softmax_fwd_b16
         else:
+            use_p3 = pl.used_p3 = rt.p3 and not drop and Rc > 0
             if drop:
                 rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
+            elif use_p3:      # candidate rows straight into three bf16 planes (no fp32 copy)
+                check(lib.cham_combine_fwd_p3(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, s), "cham_combine_fwd_p3")
             else:
                 check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
-            rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+            if use_p3:
+                rt.gemm_p3(pl.Z1p, pl.p3_ps, C, rt.w2tp, C * C, C, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
+            else:
+                rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
             rt.join()
             # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
             Z2c = pl.Z2[BT:Rall]
@@ -927,7 +983,8 @@ class NARModuleModel:
         sh = rt.shadow
         drop = self._drop
         dropout = drop['fn'] if drop else None
-        swap = on and rt.tail_on_side and not b16 and not drop
+        use_p3 = getattr(pl, 'used_p3', False)
+        swap = on and rt.tail_on_side and not b16 and not drop and not use_p3
 
         def mark():                      # event on the current stream
             if not on:
@@ -1011,7 +1068,7 @@ class NARModuleModel:
         # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
         # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
         # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
-        half = BT // 2 if (on and rt.split_mulpred and BT >= 256 and not b16) else BT
+        half = BT // 2 if (on and rt.split_mulpred and BT >= 256 and not b16 and not use_p3) else BT
         if fused:
             half = BT
 
@@ -1019,7 +1076,10 @@ class NARModuleModel:
             check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(
                 ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N, ptr(pl.dpred[g0:g1]),
                 _stream()), "cham_mulpred_bwd")
-        if not fused:
+        if use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
+            check(lib.cham_mulpred_bwd_p3(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part), s),
+                  "cham_mulpred_bwd_p3")
+        elif not fused:
             mulpred(0, half)
         e_halfB = None
         if half < BT:
@@ -1040,8 +1100,10 @@ class NARModuleModel:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
         if b16:
             rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY)
+        if use_p3:      # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
+            rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
-            if r1 <= r0 or b16:
+            if r1 <= r0 or b16 or use_p3:
                 continue
             if ev is not None:
                 main_wait(ev)
@@ -1111,6 +1173,15 @@ class NARModuleModel:
                         rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
+                        rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
+                    elif use_p3:
+                        # ... and the CAR layer-2 weight gradient: the candidate rows from their planes (TN, split-K), the clicked-input
+                        # rows (fp32) added by the on-the-fly kernel; b2 from the per-position partial sums of k_mulpred_bwd_p3
+                        if on and rt.w2_after_dgrad:
+                            rt.side_stream.wait_event(e_cdgrad)
+                        rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=0)
+                        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
+                        rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
                     elif not swap:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it

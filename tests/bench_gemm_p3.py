@@ -53,17 +53,22 @@ def main():
          lambda: Wg, lambda: A.double().t() @ D.double()),
     ]
     res = {}
+    only = os.environ.get("P3_ONLY")          # PMC passes (scripts/p3_pmc.sh): only the default plane kernel, few launches
     for name, p3, x3, out, ref in cases:
         Rf = ref(); scale = float(Rf.abs().max())
-        for tag, fn in (("planes in HBM (p3)", p3), ("p3, first version", p3), ("split on the fly (x3)", x3)):
-            lib.cham_gemm_p3_set_variant(0 if tag == "p3, first version" else 1)
+        for tag, fn in (("planes in HBM (p3)", p3), ("p3, staggered arm", p3), ("split on the fly (x3)", x3)):
+            if only and tag != "planes in HBM (p3)":
+                continue
+            lib.cham_gemm_p3_set_variant(1 if tag == "p3, staggered arm" else 0)
             out().zero_()
             fn(); torch.cuda.synchronize()
             err = float((out().double() - Rf).abs().max()) / scale
-            ms = timed(fn)
+            ms = timed(fn, 3 if only else 10)
             tf = flops / ms / 1e9
             print("%-26s %-22s: %7.3f ms %6.1f TFLOP/s (%.3f of 416.7)  max err / max|ref| %.2e" % (name, tag, ms, tf, tf / 416.7, err), flush=True)
             res[(name, tag)] = ms
+    if only:
+        return
     # the producers' side of the bargain: splitting a [R, C] matrix once (what k_combine_fwd_cand / k_mulpred_bwd add to their stores)
     P = torch.empty(3, R, C, dtype=torch.bfloat16, device=dev)
     ms = timed(lambda: check(lib.cham_split3(ptr(A), R, C, C, ptr(P), R * C, C, None, 0, 0, st), "split3"), 5)

@@ -97,10 +97,19 @@ def x3_counts(lib, reset=False):
     return list(out)
 
 
-@pytest.mark.parametrize("length_dist,gemm_dtype", [("full", "f32"), ("full", "f32_native"), ("g1", "f32")])
-def test_step_parity_g1_shape(gpu, length_dist, gemm_dtype):
+def p3_counts(lib, reset=False):
+    out = (ctypes.c_longlong * 8)()
+    lib.cham_gemm_p3_launch_counts(out, int(reset))
+    return list(out)
+
+
+@pytest.mark.parametrize("length_dist,gemm_dtype,p3", [("full", "f32", True), ("full", "f32", False), ("full", "f32_native", False), ("g1", "f32", True)])
+def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, p3):
     """BASELINE configs[1] shape, 72 sessions: forward + full backward vs the dense oracle, on the big-tile GEMM instances - the
-    default arithmetic (wide GEMMs as bf16x3 plane products, csrc/gemm_x3.hip) and every GEMM on the native fp32 MFMA, same tolerances."""
+    default arithmetic (wide GEMMs as bf16 plane products: the three candidate-row CAR GEMMs over planes resident in HBM,
+    csrc/gemm_p3.hip, the rest split while staged, csrc/gemm_x3.hip), the same with every plane-product GEMM split on the fly
+    (CHAM_GEMM_P3=0), and every GEMM on the native fp32 MFMA - same tolerances."""
+    monkeypatch.setenv("CHAM_GEMM_P3", "1" if p3 else "0")
     B = 72
     p = _g1_params(B, gemm_dtype=gemm_dtype)
     batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B)
@@ -109,10 +118,18 @@ def test_step_parity_g1_shape(gpu, length_dist, gemm_dtype):
     lib = model.rt.lib
     tile_counts(lib, reset=True)
     x3_counts(lib, reset=True)
+    p3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
     c = tile_counts(lib)
     x = x3_counts(lib)
-    if gemm_dtype == "f32":
+    c3 = p3_counts(lib)
+    assert model.rt.p3 == (p3 and gemm_dtype == "f32")
+    if p3:
+        # CAR forward + dgrad (NT) and the W2 weight gradient (TN, split-K) on the plane-resident kernel; scorer layer 1 (row scale),
+        # its wgrad and dgrad on the 256x128 on-the-fly instance; nothing wide on the native kernels
+        assert c3[0] == 2 and c3[1] == 1 and c[1] == 0 and c[2] == 0, (c3, x, c)
+        assert x[1] >= (3 if length_dist == "full" else 1), x
+    elif gemm_dtype == "f32":
         # CAR forward / dgrad / wgrad, scorer layer 1 (row scale) + its wgrad and dgrad on the 256x128 bf16x3 instance; nothing wide on
         # the native kernels
         assert x[1] >= (6 if length_dist == "full" else 1) and c[1] == 0 and c[2] == 0, (x, c)
@@ -160,9 +177,10 @@ def test_step_parity_adressa_shape(gpu):
     model, orc = H.make_pair(p, seed=2)
     lib = model.rt.lib
     x3_counts(lib, reset=True)
+    p3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
-    x = x3_counts(lib)
-    assert x[1] >= 6, x
+    x, c3 = x3_counts(lib), p3_counts(lib)
+    assert c3[0] == 2 and c3[1] == 1 and x[1] >= 3, (c3, x)
 
 
 def test_step_parity_g1_shape_bf16(gpu):

@@ -93,7 +93,7 @@ def variant(request):
     lib = _lib.load()
     lib.cham_gemm_p3_set_variant(request.param)
     yield request.param
-    lib.cham_gemm_p3_set_variant(1)
+    lib.cham_gemm_p3_set_variant(0)
 
 
 def test_split3_kernel_is_bit_exact_and_sums_back(gpu):

@@ -59,7 +59,7 @@ def _kink_flips(model, orc, mask):
     zin, zpos, zneg = taps['Z1']
     C = zin.shape[-1]
     Zin = pl.full_rows(pl.Z1[:P]).cpu().numpy()
-    Zc = pl.full_rows(pl.Z1[P:P + P * NC], NC).cpu().numpy()
+    Zc = pl.full_rows(pl.cand_Z1(P), NC).cpu().numpy()
     n += int(((Zin.reshape(B, T, C) > 0) != (zin.numpy() > 0))[mask].sum())
     zc = torch.cat([zpos.unsqueeze(2), zneg], 2).numpy()
     n += int(((Zc.reshape(B, T, NC, C) > 0) != (zc > 0))[mask].sum())
@@ -77,7 +77,7 @@ def hip_leaky_signs(model, mask):
         h = pl.full_rows(hip, NC).float().cpu().reshape(B, T, NC, -1) > 0
         out[name] = [(h[:, :, 0], valid[:, :, None]), (h[:, :, 1:], valid[:, :, None, None])]
     zin = pl.full_rows(pl.Z1[:P]).float().cpu().reshape(B, T, -1) > 0
-    zc = pl.full_rows(pl.Z1[P:P + P * NC], NC).float().cpu().reshape(B, T, NC, -1) > 0
+    zc = pl.full_rows(pl.cand_Z1(P), NC).float().cpu().reshape(B, T, NC, -1) > 0
     out['Z1'] = [(zin, valid[:, :, None]), (zc[:, :, 0], valid[:, :, None]), (zc[:, :, 1:], valid[:, :, None, None])]
     out['FC1'] = [(pl.full_rows(pl.FC1).float().cpu().reshape(B, T, -1) > 0, valid[:, :, None])]
     return out
