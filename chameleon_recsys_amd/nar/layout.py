@@ -115,7 +115,9 @@ class ParamLayout:
         if ifc['article_content_embeddings']:
             item_cols += [(COL_ACE, 0, s, self.D, None) for s in range(self.D)]
         if ifc['item_clicked_embeddings']:
-            E = get_embedding_size(n_items)
+            # (items_embedding_size: test aid - the embedding width of a larger catalog on a small one, tests/test_config5_parity_gpu.py;
+            # the reference always derives it from the vocabulary size, nar_model.py:911-919)
+            E = int(ifc.get('items_embedding_size') or get_embedding_size(n_items))
             e = Entry('items_embedding', (n_items, E), True, 'xavier')
             emb.append(e)
             item_cols += [(COL_ITEMEMB, 0, s, E, e) for s in range(E)]

@@ -111,7 +111,7 @@ def param_specs(params):
     if ifc['article_content_embeddings']:
         f_item += D
     if ifc['item_clicked_embeddings']:
-        E = get_embedding_size(n_items)
+        E = int(ifc.get('items_embedding_size') or get_embedding_size(n_items))      # (override: test aid, see nar/layout.py)
         specs['items_embedding'] = ((n_items, E), 'xavier', True)  # nar_model.py:911-919
         f_item += E
     f_item += int(ifc['recency']) + int(ifc['novelty'])

@@ -1,0 +1,64 @@
+"""HIP path vs the CPU oracle at the SHAPE of BASELINE.json configs[4] (large-catalog stress: 128-d ACE, 200 negatives per click, item
+embedding width floor(8 * 5e6^0.25) = 378, nar_model.py:25-26, 911-919), scaled to a catalog and batch the dense oracle finishes in
+seconds: 50 000 articles (the embedding WIDTH of the 5 M-article table forced through the `items_embedding_size` test aid), 16 sessions.
+What only this shape exercises: the softmax / ranking kernels over 201 candidates (four passes of a 64-lane wave), the 4 000-slot
+candidate pool (20 * N, nar_model.py:1297-1300) and its slot scatter, the grouped item-embedding gradient at 378 columns, feature
+rows of 616 columns - once as a whole batch (full-length and ragged sessions) and once through train_step_microbatched, the form
+scripts/stress_large_catalog.py runs.  Tolerances as tests/test_g1shape_parity_gpu.py."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from chameleon_recsys_amd.nar import synthetic
+from tests import helpers as H
+from tests.test_g1shape_parity_gpu import LOGIT_TOL, compare_step_large, p3_counts, x3_counts
+
+pytestmark = pytest.mark.gpu
+
+N_ITEMS, ACE_DIM, NEG, EMB = 50000, 128, 200, 378
+
+
+def _c5_params(B, **over):
+    ifc = dict(recency=True, novelty=True, article_content_embeddings=True, item_clicked_embeddings=True, items_embedding_size=EMB)
+    return synthetic.default_params(N_ITEMS, ACE_DIM, seq_len=20, batch_size=B, neg=NEG, neg_from_buffer=3000, buffer_size=20000,
+                                    for_norm=2000, C=1024, H=255, internal_features_config=ifc, **over)
+
+
+@pytest.mark.parametrize("length_dist", ["full", "g1"])
+def test_step_parity_config5_shape(gpu, length_dist):
+    B = 16
+    p = _c5_params(B)
+    batches = synthetic.make_batches(4, B, 20, N_ITEMS, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B, seed=11)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=5)
+    L = model.rt.layout
+    assert L.entries['items_embedding'].shape == (N_ITEMS, EMB) and L.D == ACE_DIM and L.f_item == 37 + ACE_DIM + EMB + 2
+    lib = model.rt.lib
+    x3_counts(lib, reset=True); p3_counts(lib, reset=True)
+    compare_step_large(model, orc, *batches[3], st)
+    pl = model._plan
+    assert pl.NC == NEG + 1 and pl.pmax == 20 * NEG and pl.pool.numel() == 4000
+    c3, x = p3_counts(lib), x3_counts(lib)
+    assert c3[0] == 2 and c3[1] == 1, (c3, x)          # the three candidate-row CAR GEMMs ran on the plane-resident kernel
+    if length_dist == "full":
+        assert pl.P == B * 19 and x[1] >= 3, (pl.P, x)  # 61 104 candidate rows: the 256x128 on-the-fly instance for scorer layer 1 & co
+
+
+def test_microbatched_step_config5_shape_matches_oracle(gpu):
+    """One optimizer step over 16 sessions processed as two micro-batches of 8 (every shard sees the GLOBAL pool, max timestamp and
+    loss denominator; gradients accumulate; one Adam) against the oracle's whole-batch step: loss, Adam first moments, weights."""
+    B = 16
+    p = _c5_params(B)
+    batches = synthetic.make_batches(4, B, 20, N_ITEMS, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=12)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=6)
+    f, l = batches[3]
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    model.feed_state(pop, buf)
+    loss = model.train_step_microbatched(f, l, 8).cpu().numpy()
+    ref = orc.train_step(f, l, buf, pop, return_grads=True)
+    assert abs(float(loss[0]) - float(ref['total_loss'])) < LOGIT_TOL, (loss, float(ref['total_loss']))
+    sig = H.grad_significance(ref['grads'])
+    H.assert_adam_state_close(model, orc, p['lr'], n_steps=1, m_tol=2e-2, w_tol=0.25, sig_every_step=sig)
