@@ -102,6 +102,70 @@ def gemm_symbol(r):
     return "void gemm_f32_kernel<%d, %d, %d, %d, 16, %s, %s, %d, true, 0, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
 
 
+def child_arm(args, extra):
+    """This script as a child process for another configuration; returns its headline, its G1-like-lengths leg and its roofline entry."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 20))), "--warmup", str(args.warmup),
+           "--seed", str(args.seed), "--no-cpu-baseline", "--no-boundary-leg", "--no-native-arm", "--no-arms"] + extra
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-400:])}
+        d = json.loads(lines[-1])
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+    rf = d["roofline"]
+    arm = {"command": " ".join(["python", "bench.py"] + cmd[2:]), "workload": d["config"]["workload"], "dtype": d["dtype"], "gemm": d["config"]["gemm"],
+           "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
+           "sessions_per_gpu_per_step": d["config"]["sessions_per_gpu_per_step"],
+           "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms",
+                                               "algorithmic_gflop_per_launch", "algorithmic_bytes_per_launch", "all_gemm_ms_per_step")},
+           "top_gemms": [{k: g.get(k) for k in ("kernel", "avg_launch_ms", "ms_per_step", "tflops", "frac_of_mfma_peak", "mfma_peak_tflops",
+                                                 "algorithmic_GBps", "frac_of_hbm_peak")} for g in rf.get("top_gemms", [])]}
+    if "g1_like_session_lengths" in d:
+        arm["g1_like_session_lengths"] = {k: d["g1_like_session_lengths"][k] for k in ("value", "unit", "ms_per_step")}
+    return arm
+
+
+def dp_self_exchange(rt):
+    """The gradient exchange of the data-parallel step on RCCL with the ONE GPU of a --gpus 1 run: a process group of one rank on the
+    "nccl" backend, the flat gradient buffer all-reduced in the step's two buckets ([Wf1 .. Ws4] first, the rest after it), HIP-event
+    timed on the stream the collectives run on.  Not a scaling number (one rank exchanges with itself): it shows RCCL loaded,
+    stream-ordered and what the fixed cost of the two calls is.  tests/test_dp_rccl_gpu.py drives every exchange mode this way."""
+    import torch
+    import torch.distributed as dist
+    own = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            own = True
+        L = rt.layout
+        a, b = L.entries['Wf1'].offset, L.entries['Ws4'].offset + L.entries['Ws4'].size
+        g = rt.grads.clone()
+        ref = g.clone()
+        def exchange():
+            dist.all_reduce(g[a:b]); dist.all_reduce(g[:a]); dist.all_reduce(g[b:])
+        for _ in range(3):
+            exchange()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            exchange()
+        e1.record(); torch.cuda.synchronize()
+        out = {"backend": dist.get_backend(), "world": 1, "bytes": int(g.numel() * 4), "buckets": [int((b - a) * 4), int((g.numel() - (b - a)) * 4)],
+               "ms": round(e0.elapsed_time(e1) / n, 4), "unchanged": bool(torch.equal(g, ref))}
+    except Exception as ex:          # (never fail the bench line over this leg)
+        out = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if own and dist.is_initialized():
+        dist.destroy_process_group()
+    return out
+
+
 EPI_NAMES = {0: "plain", 1: "bias+leaky", 2: "bias+tanh", 3: "x leaky'", 4: "x tanh'", 5: "bias", 6: "split-K partials (+ reduce kernel)"}
 
 
@@ -244,6 +308,9 @@ def main():
                     help="skip the comparison leg of --dtype f32: the same steps with every GEMM on the native fp32 MFMA")
     ap.add_argument("--no-ragged-leg", action="store_true",
                     help="skip the secondary G1-like-session-lengths leg (profiling runs: keeps per-symbol averages to the headline leg)")
+    ap.add_argument("--no-arms", action="store_true",
+                    help="skip the bf16_arm (BASELINE configs[2] arithmetic) and adressa_arm (configs[3]) legs of the default g1 / f32 run: "
+                         "each is this script run as a child process with its own roofline entry")
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
@@ -529,6 +596,13 @@ def main():
             out["through_boundary"] = through_boundary(cfg, args.length_dist, seed=args.seed, state=args.state, gemm_dtype=args.dtype)
             if ragged is not None:
                 out["through_boundary_g1_like_session_lengths"] = through_boundary(cfg, "g1", seed=args.seed, state=args.state, gemm_dtype=args.dtype)
+        if world == 1 and not args.no_boundary_leg:
+            out["dp_self_exchange_ms"] = dp_self_exchange(rt)
+        if world == 1 and not args.no_arms and args.config == "g1" and args.dtype == "f32" and args.length_dist == "full":
+            # the other configurations BASELINE.json names, timed in the same invocation (children of this process, one after the
+            # other, this process idle meanwhile): configs[2]'s arithmetic on one GPU, configs[3]'s shape
+            out["bf16_arm"] = child_arm(args, ["--dtype", "bf16"])
+            out["adressa_arm"] = child_arm(args, ["--config", "adressa", "--no-ragged-leg"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

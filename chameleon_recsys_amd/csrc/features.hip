@@ -21,13 +21,29 @@ enum { COL_ZERO = 0, COL_OHE = 1, COL_EMB = 2, COL_NUM = 3, COL_ACE = 4, COL_ITE
 // descriptor = 5 x int64: kind, feat, sub, dim, param_offset
 #define DESC_W 5
 
-__device__ __forceinline__ float recency_raw(int64_t ref_ts, int64_t created) {
+float g_cham_ln_elapsed_base = logf(1.3f), g_cham_ln_pop_base = logf(2.0f), g_cham_inv_log2_pop_base = 1.0f;
+extern "C" int cham_set_log_bases(float elapsed_days_smooth_log_base, float popularity_smooth_log_base) {
+    if (!(elapsed_days_smooth_log_base > 0.f) || elapsed_days_smooth_log_base == 1.f || !(popularity_smooth_log_base > 0.f) ||
+        popularity_smooth_log_base == 1.f)
+        return -CHAM_ERR_ARG;
+    g_cham_ln_elapsed_base = logf(elapsed_days_smooth_log_base);
+    g_cham_ln_pop_base = logf(popularity_smooth_log_base);
+    g_cham_inv_log2_pop_base = popularity_smooth_log_base == 2.0f ? 1.0f : (float)(1.0 / log2((double)popularity_smooth_log_base));
+    return CHAM_OK;
+}
+
+__device__ __forceinline__ float recency_raw(int64_t ref_ts, int64_t created, float ln_base) {
     // nar_model.py:1055-1060: int64 -> float32 BEFORE the subtraction; then log_{1.3}(1+x) (:33-34, 1074)
     const float d = ((float)ref_ts - (float)created) / 86400000.0f;
-    return logf(fmaxf(d, 0.f) + 1.0f) / logf(1.3f);
+    return logf(fmaxf(d, 0.f) + 1.0f) / ln_base;
 }
-__device__ __forceinline__ float novelty_raw(float pop_norm) {
-    return -(logf(pop_norm) / logf(2.0f));      // nar_model.py:1147-1148
+__device__ __forceinline__ float novelty_raw(float pop_norm, float ln_base) {
+    return -(logf(pop_norm) / ln_base);      // nar_model.py:1147-1148
+}
+// a numerical article-metadata column (nar_model.py:755-757 'numerical' -> expand_dims): integer-valued features are stored as such in
+// the int64 metadata table, float-valued ones as their float32 bit pattern (descriptor sub-field 1; nar/layout.py)
+__device__ __forceinline__ float meta_num(int64_t m, int is_float_bits) {
+    return is_float_bits ? __int_as_float((int)m) : (float)m;
 }
 __device__ __forceinline__ float norm_apply(float x, const float* st) {
     // st = {mean, sd, zmin, zmax}  (nar_model.py:1031-1037, 1007-1008)
@@ -59,23 +75,23 @@ __global__ __launch_bounds__(256) void k_ctx_assemble(const int64_t* __restrict_
 // raw (un-normalised) recency / novelty per item row
 __global__ __launch_bounds__(256) void k_item_dynamic_raw(const int64_t* __restrict__ ids, const int64_t* __restrict__ ref_ts, int R,
                                                           const int64_t* __restrict__ created, const float* __restrict__ pop_norm,
-                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw) {
+                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw, float ln_e, float ln_p) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
     const int64_t id = ids[r];
-    rec_raw[r] = recency_raw(ref_ts[r], created[id]);
-    nov_raw[r] = novelty_raw(pop_norm[id]);
+    rec_raw[r] = recency_raw(ref_ts[r], created[id], ln_e);
+    nov_raw[r] = novelty_raw(pop_norm[id], ln_p);
 }
 
 // same, for the "last N recent clicks" used as normalisation population (nar_model.py:1066-1071, 1156-1158)
 __global__ __launch_bounds__(256) void k_last_dynamic_raw(const int64_t* __restrict__ last_ids, int n, int64_t max_ts,
                                                           const int64_t* __restrict__ created, const float* __restrict__ pop_norm,
-                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw) {
+                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw, float ln_e, float ln_p) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const int64_t id = last_ids[r];
-    rec_raw[r] = recency_raw(max_ts, created[id]);
-    nov_raw[r] = novelty_raw(pop_norm[id]);
+    rec_raw[r] = recency_raw(max_ts, created[id], ln_e);
+    nov_raw[r] = novelty_raw(pop_norm[id], ln_p);
 }
 
 // weighted population stats -> {mean, sd, zmin, zmax}; single workgroup, fixed reduction tree.
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256) void k_item_assemble(const int64_t* __restrict
     float v = 0.f;
     if (kind == COL_OHE) v = (meta_cat[(size_t)feat * n_items + id] == sub) ? 1.f : 0.f;
     else if (kind == COL_EMB) v = params[d[4] + meta_cat[(size_t)feat * n_items + id] * dim + sub];
-    else if (kind == COL_NUM) v = (float)meta_cat[(size_t)feat * n_items + id];
+    else if (kind == COL_NUM) v = meta_num(meta_cat[(size_t)feat * n_items + id], sub);
     else if (kind == COL_ACE) v = ace[(size_t)id * ld_ace + sub];
     else if (kind == COL_ITEMEMB) v = params[d[4] + id * dim + sub];
     else if (kind == COL_RECENCY) v = norm_apply(rec_raw[r], stats + g * 8);
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256) void k_item_assemble_lds(const int64_t* __rest
             const int kind = (int)d[0], feat = (int)d[1], sub = (int)d[2];
             float v = 0.f;
             if (kind == COL_OHE) v = (meta_cat[(size_t)feat * n_items + id] == sub) ? 1.f : 0.f;
-            else if (kind == COL_NUM) v = (float)meta_cat[(size_t)feat * n_items + id];
+            else if (kind == COL_NUM) v = meta_num(meta_cat[(size_t)feat * n_items + id], sub);
             else if (kind == COL_RECENCY) v = norm_apply(rec_raw[r], stats + g * 8);
             else if (kind == COL_NOVELTY) v = norm_apply(nov_raw[r], stats + g * 8 + 4);
             row[c] = v;
@@ -392,7 +408,7 @@ extern "C" int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, 
                                      const float* pop_norm, float* rec_raw, float* nov_raw, void* stream) {
     if (!ids || !ref_ts || !created || !pop_norm || !rec_raw || !nov_raw || R <= 0) return -CHAM_ERR_ARG;
     hipLaunchKernelGGL(k_item_dynamic_raw, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       ids, ref_ts, R, created, pop_norm, rec_raw, nov_raw);
+                       ids, ref_ts, R, created, pop_norm, rec_raw, nov_raw, g_cham_ln_elapsed_base, g_cham_ln_pop_base);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -404,7 +420,7 @@ extern "C" int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, 
     if (!last_ids || n_last <= 0 || !created || !pop_norm || !scratch || !stats) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_last + 255) / 256), dim3(256), 0, st, last_ids, n_last, max_ts, created,
-                       pop_norm, scratch, scratch + n_last);
+                       pop_norm, scratch, scratch + n_last, g_cham_ln_elapsed_base, g_cham_ln_pop_base);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)nullptr, n_last, stats, 3);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_last, (const float*)nullptr, n_last, stats + 4, 3);
     CHAM_CHECK_LAUNCH();
@@ -420,7 +436,7 @@ extern "C" int cham_norm_stats_from_buffer(const int64_t* buffer_ids, int n_pref
     float* w = scratch + 2 * (size_t)n_prefix;
     hipLaunchKernelGGL(k_nonzero_weights, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, w);
     hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, max_ts, created,
-                       pop_norm, scratch, scratch + n_prefix);
+                       pop_norm, scratch, scratch + n_prefix, g_cham_ln_elapsed_base, g_cham_ln_pop_base);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)w, n_prefix, stats, 3);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_prefix, (const float*)w, n_prefix, stats + 4, 3);
     CHAM_CHECK_LAUNCH();

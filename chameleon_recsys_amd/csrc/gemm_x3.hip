@@ -2,7 +2,7 @@
 // in fp32 ("bf16x3"; same contract, arguments and epilogues as cham_gemm_f32 in gemm.hip).
 //
 //   a = a_h + a_m + a_l   (a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m); 3 x 8 significand bits = fp32's 24)
-//   a b = a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m)  [+ a_m b_l + a_l b_m + a_l b_l: < 2^-25 |a b|, dropped]
+//   a b = a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m)  [+ a_m b_l + a_l b_m + a_l b_l: two terms of <= 2^-24 |a b| each (worst case 2^-23, tests/test_split3_cpu.py), dropped]
 //
 // bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result carries the same kind of
 // error as the native fp32 MFMA path (fp32 accumulation rounding; tests/test_gemm_x3_gpu.py measures both against float64 on the

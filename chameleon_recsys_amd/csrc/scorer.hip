@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const T* __restrict__
                                                            float* __restrict__ logits, float* __restrict__ probs,
                                                            float* __restrict__ nll, float nov_factor,
                                                            const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
-                                                           float* __restrict__ nov_aux /*[BT,3]*/) {
+                                                           float* __restrict__ nov_aux /*[BT,3]*/, float inv_log2_base) {
     const int lane = threadIdx.x & 63, bt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bt >= BT) return;
     const int NC = N + 1;
@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const T* __restrict__
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int c = lane; c < NC; c += 64) probs[(size_t)bt * NC + c] *= inv;
-    // optional novelty regulariser (nar_model.py:673-683): - factor * sum_n softmax(s_neg / tau)_n * (-log2 pop_norm[neg_n]);
+    // optional novelty regulariser (nar_model.py:673-683, 544): - factor * sum_n softmax(s_neg / tau)_n * (-log_base pop_norm[neg_n]),
+    // base = popularity_smooth_log_base (2 in every shipped script; -log2(p) * inv_log2_base, inv_log2_base exactly 1 for base 2);
     // the softmax over the negatives alone (:517) has its own max / normaliser; {max, sum, q.nov} are kept for the backward
     float novterm = 0.f;
     if (nov_factor > 0.f) {
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_score_softmax_fwd(const T* __restrict__
             if (c > 0) {
                 const float e = expf(logits[(size_t)bt * NC + c] * inv_tau - mxn);
                 sn += e;
-                acc += e * (-log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]));
+                acc += e * (-log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]) * inv_log2_base);
             }
         sn = wave_sum(sn); acc = wave_sum(acc);
         novterm = acc / sn;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const T* __restrict__
                                                            float* __restrict__ ds, T* __restrict__ dS3, float nov_factor,
                                                            const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
                                                            const float* __restrict__ logits, float inv_tau,
-                                                           const float* __restrict__ nov_aux) {
+                                                           const float* __restrict__ nov_aux, float inv_log2_base) {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int NC = N + 1;
     if (row >= (size_t)BT * NC) return;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const T* __restrict__
     if (nov_factor > 0.f && c > 0 && mask[bt]) {
         // d/ds_c of -factor * sum_n q_n nov_n with q = softmax(s_neg / tau): -factor/tau * q_c * (nov_c - q.nov)
         const float q = expf(logits[row] * inv_tau - nov_aux[(size_t)bt * 3]) / nov_aux[(size_t)bt * 3 + 1];
-        const float nov_c = -log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]);
+        const float nov_c = -log2f(pop_norm[neg_ids[(size_t)bt * N + (c - 1)]]) * inv_log2_base;
         g -= nov_factor * scale * q * (nov_c - nov_aux[(size_t)bt * 3 + 2]);
     }
     ds[row] = g;
@@ -653,7 +654,7 @@ static int score_softmax_fwd_impl(const T* S3, int K3, const float* w4, const fl
     if (!S3 || !w4 || !b4 || !mask || !logits || !probs || !nll || K3 != 32 || BT <= 0 || N <= 0) return -CHAM_ERR_ARG;
     if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !nov_aux)) return -CHAM_ERR_ARG;
     hipLaunchKernelGGL((k_score_softmax_fwd<32, T>), dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S3, w4, b4, BT, N,
-                       1.0f / tau, mask, logits, probs, nll, novelty_reg_factor, neg_ids, pop_norm, nov_aux);
+                       1.0f / tau, mask, logits, probs, nll, novelty_reg_factor, neg_ids, pop_norm, nov_aux, g_cham_inv_log2_pop_base);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -680,7 +681,7 @@ static int score_softmax_bwd_impl(const T* S3, int K3, const float* w4, const fl
     const size_t rows = (size_t)BT * (N + 1);
     hipLaunchKernelGGL((k_score_softmax_bwd<32, T>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
                        probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3, novelty_reg_factor, neg_ids, pop_norm, logits,
-                       1.0f / tau, nov_aux);
+                       1.0f / tau, nov_aux, g_cham_inv_log2_pop_base);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

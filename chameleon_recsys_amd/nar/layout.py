@@ -70,6 +70,7 @@ class ParamLayout:
 
         emb, ctx_cols, item_cols = [], [], []
         self.ctx_cat_names, self.ctx_num_names, self.meta_names = [], [], []
+        self.meta_is_float = set()
         # ---- user-context columns, nar_model.py:746-767 (dict insertion order)
         for name, cfg in scfg.items():
             if name in SESSION_REQ_SEQ_FEATURES:
@@ -109,7 +110,10 @@ class ParamLayout:
                     emb.append(e)
                     item_cols += [(COL_EMB, fi, s, dim, e) for s in range(dim)]
             elif cfg['type'] == 'numerical':
-                item_cols.append((COL_NUM, fi, 0, 1, None))
+                is_float = cfg.get('dtype') == 'float'          # stored as float32 bits in the int64 metadata table (NARRuntime)
+                if is_float:
+                    self.meta_is_float.add(name)
+                item_cols.append((COL_NUM, fi, 1 if is_float else 0, 1, None))
             else:
                 raise Exception('Invalid feature type: {}'.format(name))
         if ifc['article_content_embeddings']:

@@ -167,12 +167,19 @@ class NARRuntime:
         meta = params['articles_metadata']
         self.ace = torch.from_numpy(ace).to(dev)
         self.created = torch.from_numpy(np.ascontiguousarray(meta['created_at_ts'], dtype=np.int64)).to(dev)
-        for n in L.meta_names:      # metadata columns live in ONE int64 table: a float-valued numerical article feature would be truncated
-            if acfg[n]['type'] == 'numerical' and not np.issubdtype(np.asarray(meta[n]).dtype, np.integer):
-                raise NotImplementedError("numerical (float) article metadata feature %r: only integer-valued article features are built "
-                                          "(the shipped G1 / Adressa configs have categorical metadata only)" % n)
+        def meta_column(n):
+            # metadata columns live in ONE int64 table.  A float-valued numerical article feature (config dtype 'float',
+            # nar_model.py:755-757) is stored as its float32 bit pattern and read back bit-exactly by the assemble kernels
+            # (layout.meta_is_float -> descriptor sub-field 1); everything else as the integer it is.
+            a = np.asarray(meta[n])
+            if n in L.meta_is_float:
+                return np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+            if acfg[n]['type'] == 'numerical' and not np.issubdtype(a.dtype, np.integer) and not np.array_equal(a, np.round(a)):
+                raise ValueError("article feature %r holds non-integer values but its config says dtype %r: declare it "
+                                 "{'type': 'numerical', 'dtype': 'float'}" % (n, acfg[n].get('dtype')))
+            return a.astype(np.int64)
         if L.meta_names:
-            mc = np.stack([np.asarray(meta[n], dtype=np.int64) for n in L.meta_names])
+            mc = np.stack([meta_column(n) for n in L.meta_names])
         else:
             mc = np.zeros((1, self.n_items), np.int64)
         self.meta_cat = torch.from_numpy(np.ascontiguousarray(mc)).to(dev)
@@ -245,7 +252,7 @@ class NARRuntime:
         self.profile = None           # list -> per-GEMM-launch HIP-event timing (bench.py roofline leg)
         # data-parallel context (set by parallel.DataParallelNAR)
         self.dp_rank, self.dp_world, self.dp_allreduce, self.dp_sharded = 0, 1, None, None
-        self.dp_early_bucket, self.dp_gather_slots, self.dp_mode = None, None, 'allreduce'
+        self.dp_early_bucket, self.dp_gather_slots, self.dp_mode, self.dp_active = None, None, 'allreduce', False
 
     # ---- views into the flat buffers
     def view(self, flat, name):
@@ -586,8 +593,12 @@ class NARModuleModel:
                  internal_features_config={'recency': True, 'novelty': True, 'article_content_embeddings': True,
                                            'item_clicked_embeddings': True},
                  eval_cold_start=False, runtime=None, rnn_cell='ugrnn', gemm_dtype='f32'):
-        if elapsed_days_smooth_log_base != 1.3 or popularity_smooth_log_base != 2.0:
-            raise NotImplementedError("log bases other than the reference defaults (1.3, 2.0) are compiled into the kernels")
+        # log_base / log_1p bases of the recency and novelty features (nar_model.py:28-34, 1071-1075, 1148): launch scalars of the kernels
+        for b in (elapsed_days_smooth_log_base, popularity_smooth_log_base):
+            if not (b > 0.0) or b == 1.0:
+                raise ValueError("log bases must be > 0 and != 1")
+        self.elapsed_days_smooth_log_base = float(elapsed_days_smooth_log_base)
+        self.popularity_smooth_log_base = float(popularity_smooth_log_base)
         self.novelty_reg_factor = float(novelty_reg_factor)
         self.is_training = (mode == ModeKeys.TRAIN)
         if self.is_training and not (0.0 < keep_prob <= 1.0):
@@ -783,6 +794,7 @@ class NARModuleModel:
         pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
         self._plan, self._d = pl, d
         pl.used_p3 = False
+        check(lib.cham_set_log_bases(self.elapsed_days_smooth_log_base, self.popularity_smooth_log_base), "cham_set_log_bases")
         torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
         # BT = rows of the row-wise stages = the P valid positions (all B*T when nothing is padded); BTf = the [B, T] layout
@@ -801,7 +813,7 @@ class NARModuleModel:
             torch.cuda.current_stream().wait_event(ps[3])
         else:
             self._neg_sample(pl, d, step, pl._samp_cur, s)
-        if rt.dp_mode == 'sparse' and rt.dp_world > 1:
+        if rt.dp_mode == 'sparse' and getattr(rt, 'dp_active', rt.dp_world > 1):
             # item rows this step can touch on ANY rank (parallel.py, mode "sparse"): GLOBAL clicked ids + candidate pool + pad item,
             # as int32 row indices in a buffer of the plan (nothing is allocated or freed around the collective)
             n1 = d['aci'].numel()

@@ -88,8 +88,10 @@ def define_flags():
     a('--rnn_cell', default='ugrnn', choices=['ugrnn', 'gru'], help="recurrent cell: 'ugrnn' = the reference's tf.contrib.rnn.UGRNNCell "
       "(nar_model.py:1317), 'gru' = its commented-out GRUCell alternative (:1315)")
     a('--gemm_dtype', default='f32', choices=['f32', 'f32_native', 'bf16'],
-      help="f32: fp32 operands and fp32-grade error, wide GEMMs as six bf16-plane products on the bf16 matrix cores; f32_native: every "
-           "GEMM on the native fp32 MFMA; bf16: bf16-resident candidate-row matrices, fp32 accumulate")
+      help="f32: fp32 operands and fp32-grade error, wide GEMMs as six bf16-plane products on the bf16 matrix cores (caveats: an INFINITE "
+           "operand yields NaN where fp32 yields +-inf - behind a tanh layer the native path saturates to a finite +-1 instead - and "
+           "operands below 2^-100 lose their lowest plane; tests/test_gemm_p3_gpu.py pins both); f32_native: every GEMM on the native "
+           "fp32 MFMA; bf16: bf16-resident candidate-row matrices, fp32 accumulate")
     a('--clicked_items_state', default='host', choices=['host', 'device'], help="keep the recent-clicks state in host numpy (reference "
       "class) or in HBM (bit-identical, no host round trip per step)")
     return ap

@@ -60,7 +60,12 @@ class DataParallelNAR:
         rt.dp_rank, rt.dp_world = self.rank, self.world
         rt.dp_mode = self.mode
         self._early, self._early_work = None, None
-        if self.world > 1:
+        # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
+        # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
+        # (tests/test_dp_rccl_gpu.py; bench.py's dp_self_exchange_ms)
+        self.active = self.world > 1 or (os.environ.get("CHAM_DP_FORCE", "0") == "1" and dist.is_initialized())
+        rt.dp_active = self.active
+        if self.active:
             L = getattr(rt, 'layout', None)
             # Early bucket: the session-FC and scorer kernels [Wf1 .. Ws4] are contiguous in the flat buffer and their gradients
             # are final long before the tail of the backward pass (PreCAR backward beside the W2 weight gradient): their
@@ -92,8 +97,10 @@ class DataParallelNAR:
                 rt.dp_allreduce = self._sparse_allreduce
             else:
                 rt.dp_allreduce = self._allreduce
-            # identical initial weights on every rank
+            # identical initial weights on every rank (a write to rt.flat that bypasses load_logical_weights: bump the version the
+            # bf16 / plane shadows of the weights are keyed on)
             dist.broadcast(rt.flat, src=0, group=self.pg)
+            rt.weights_version = getattr(rt, 'weights_version', 0) + 1
 
     # ---- early bucket (see __init__)
     def _issue_early_bucket(self, flat_grads):
@@ -161,7 +168,7 @@ class DataParallelNAR:
     # ---- checkpoints: in the sharded / hybrid modes a rank's Adam slots are only valid on its own slice
     def _gather_slots(self, m, v):
         """Full (m, v) on every rank, for NARRuntime.state_dict(): the owned slices all-gathered (no-op in the replicated modes)."""
-        if self.world == 1 or self.mode in ("allreduce", "sparse"):
+        if not self.active or self.mode in ("allreduce", "sparse"):
             return m, v
         total = m.numel()
         E = total if self.mode == "sharded" else self.emb_sharded
@@ -228,7 +235,7 @@ class DataParallelNAR:
     def global_loss(self):
         """[total, xe, reg]: xe summed over ranks (each rank holds its rows' share / global sum(mask))."""
         loss = self.model.total_loss.clone()
-        if self.world > 1:
+        if self.active:
             xe = loss[1:2].clone()
             dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=self.pg)
             loss[1] = xe[0]

@@ -38,6 +38,13 @@ int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t* buffer, i
 /* user context features, nar_model.py:730-773 + :887-907.  cat [n_cat][R] int64, num [n_num][R] float */
 int cham_ctx_assemble(const int64_t* cat, const float* num, int R, const int64_t* desc, int F, const float* params,
                       const float* gamma, const float* beta, float* xraw, float* xs, void* stream);
+/* The two smoothing-log bases of the dynamic item features - NARModuleModel(elapsed_days_smooth_log_base = 1.3,
+ * popularity_smooth_log_base = 2.0), nar_model.py:122-123, used by log_base / log_1p (:28-34) in the recency feature (:1071-1075), the
+ * novelty feature (:1148) and the novelty regulariser (:544, 673-683).  Launch scalars of cham_item_dynamic_raw, cham_norm_stats_from_*
+ * and cham_score_softmax_fwd / _bwd; process-wide, set before the launches of a step (NARModuleModel.forward does).  Bases must be
+ * > 0 and != 1. */
+int cham_set_log_bases(float elapsed_days_smooth_log_base, float popularity_smooth_log_base);
+
 /* raw recency log_1.3(1+relu((f32(ts)-f32(created))/86.4e6)) and novelty -log2(pop_norm): nar_model.py:1055-1060,
  * 1074, 1147-1148 */
 int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, int R, const int64_t* created, const float* pop_norm,
@@ -117,7 +124,7 @@ int cham_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb,
 
 /* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip): identical contract, fp32 storage and fp32-grade error; every operand is split
  * into three bf16 planes (a = a_h + a_m + a_l, exact) while staged into LDS and six plane products are accumulated in fp32 on
- * v_mfma_f32_32x32x16_bf16 (the dropped terms are < 2^-25 |a b|).  6/16 of the native fp32 matrix time on gfx950.  N <= 64 is
+ * v_mfma_f32_32x32x16_bf16 (the dropped terms are <= 2^-23 |a b| in the worst case: tests/test_split3_cpu.py).  6/16 of the native fp32 matrix time on gfx950.  N <= 64 is
  * delegated to cham_gemm_f32.  An infinite operand yields NaN where cham_gemm_f32 yields inf. */
 int cham_gemm_f32x3(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
                     int K, const float* bias, int act, const float* dref, int ldr, int dact, const float* rowscale, int ldrs,

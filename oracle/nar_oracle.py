@@ -248,23 +248,25 @@ class NAROracle:
     # -- nar_model.py:1092-1131 + 1062-1089
     def _recency(self, ids, ref_ts, buffer_ids, stats_ref_ts=None):
         created = self.meta['created_at_ts'][ids].unsqueeze(-1)
-        x = self._log1p_base(self._elapsed_days(created, ref_ts), 1.3)
+        eb = float(self.p.get('elapsed_days_smooth_log_base', 1.3))          # nar_model.py:122, 1071-1075
+        x = self._log1p_base(self._elapsed_days(created, ref_ts), eb)
         last = self._last_buffer_items(buffer_ids)
         if last.numel() == 0:
             stats = x[(ids != 0)].reshape(-1)
         else:
             stats = self._log1p_base(self._elapsed_days(self.meta['created_at_ts'][last],
-                                                        ref_ts.max() if stats_ref_ts is None else stats_ref_ts), 1.3)
+                                                        ref_ts.max() if stats_ref_ts is None else stats_ref_ts), eb)
         return self._normalize_values(x, stats)
 
     # -- nar_model.py:1134-1193
     def _novelty(self, ids, buffer_ids, pop_norm):
-        nov = -(torch.log(pop_norm[ids].unsqueeze(-1)) / torch.log(torch.tensor(2.0)))
+        pb = torch.tensor(float(self.p.get('popularity_smooth_log_base', 2.0)))      # nar_model.py:123, 1148
+        nov = -(torch.log(pop_norm[ids].unsqueeze(-1)) / torch.log(pb))
         last = self._last_buffer_items(buffer_ids)
         if last.numel() == 0:
             stats = nov[(ids != 0)]
         else:
-            stats = -(torch.log(pop_norm[last].unsqueeze(-1)) / torch.log(torch.tensor(2.0)))
+            stats = -(torch.log(pop_norm[last].unsqueeze(-1)) / torch.log(pb))
         return self._normalize_values(nov, stats)
 
     # -- nar_model.py:921-994
@@ -467,7 +469,7 @@ class NAROracle:
             total = xe + reg
         if p.get('novelty_reg_factor', 0.0) > 0.0:                                                                # :673-683
             neg_prob = torch.softmax(s_neg / tau, dim=-1)
-            neg_nov = -(torch.log(pop_t[neg]) / torch.log(torch.tensor(2.0)))
+            neg_nov = -(torch.log(pop_t[neg]) / torch.log(torch.tensor(float(p.get('popularity_smooth_log_base', 2.0)))))       # :544, 1148
             nov = (p['novelty_reg_factor'] * (neg_prob * neg_nov * loss_mask.unsqueeze(-1)).sum(-1)).sum() / loss_mask.sum()
             total = total - nov
         out = dict(total_loss=total, xe_loss=xe, reg_loss=reg, logits=logits, probs=probs, neg_items=neg,

@@ -49,7 +49,9 @@ def make_pair(p, seed=3):
                            recent_clicks_for_normalization=p['recent_clicks_for_normalization'],
                            articles_metadata=p['articles_metadata'], CAR_embedding_size=p['CAR_embedding_size'],
                            rnn_units=p['rnn_units'], novelty_reg_factor=p.get('novelty_reg_factor', 0.0), runtime=rt,
-                           rnn_num_layers=p.get('rnn_num_layers', 1), rnn_cell=p.get('rnn_cell', 'ugrnn'), gemm_dtype=p.get('gemm_dtype', 'f32'))
+                           rnn_num_layers=p.get('rnn_num_layers', 1), rnn_cell=p.get('rnn_cell', 'ugrnn'), gemm_dtype=p.get('gemm_dtype', 'f32'),
+                           elapsed_days_smooth_log_base=p.get('elapsed_days_smooth_log_base', 1.3),
+                           popularity_smooth_log_base=p.get('popularity_smooth_log_base', 2.0))
     orc = NAROracle(p, weights=w)
     return model, orc
 

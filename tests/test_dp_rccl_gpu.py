@@ -1,0 +1,77 @@
+"""RCCL on the one GPU a test box has: a process group of ONE rank on the "nccl" backend (= RCCL on ROCm) drives DataParallelNAR with
+the world > 1 guard lifted (CHAM_DP_FORCE=1), so every collective of every exchange mode executes on RCCL, stream-ordered with the
+step's two lanes - all_reduce in two buckets (the early one asynchronously from the side lane), reduce_scatter_tensor,
+all_gather_into_tensor, the packed sparse exchange, the all_gather of the Adam slots for a checkpoint - i.e. the branches of
+nar/parallel.py that the two-process tests (tests/test_dp_gpu.py, gloo: RCCL refuses two ranks on one device) cannot reach.  With one
+rank every collective is the identity, so weights, Adam slots and losses must be BIT-identical to the plain single-process step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chameleon_recsys_amd.nar import synthetic
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+STEPS = 3
+
+
+def _params():
+    return H.tiny_params(C=128, H=100, neg=8, batch_size=48)
+
+
+def _train(p, batches, dp_mode):
+    from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
+    from chameleon_recsys_amd.nar.parallel import DataParallelNAR
+    model, _ = H.make_pair(p, seed=7)
+    dp = DataParallelNAR(model, mode=dp_mode) if dp_mode else None
+    st = DeviceClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'],
+                                 p['recent_clicks_for_normalization'], 1000)
+    for f, l in batches[:2]:
+        aci = np.concatenate([f['item_clicked'], l['label_last_item']], 1)
+        st.update_from_device_batch(torch.from_numpy(aci).cuda(), torch.from_numpy(f['event_timestamp']).cuda())
+    losses = []
+    for f, l in batches[2:2 + STEPS]:
+        model.feed_state(st, st)
+        d = dp.upload(f, l) if dp else model.upload_batch(f, l)
+        model.train_step(d)
+        losses.append((dp.global_loss() if dp else model.total_loss).cpu().numpy().copy())
+        st.update_from_device_batch(d['aci'], d['g_event_ts'])
+    torch.cuda.synchronize()
+    sd = model.rt.state_dict()
+    return np.stack(losses), model.rt.flat.cpu().numpy(), sd['m'].numpy(), sd['v'].numpy(), (dp.active if dp else False)
+
+
+def _worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CHAM_DP_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    p = _params()
+    batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
+    ref = _train(p, batches, None)
+    out = {}
+    for mode in ("allreduce", "sharded", "hybrid", "sparse"):
+        losses, flat, m, v, active = _train(p, batches, mode)
+        assert active, "CHAM_DP_FORCE did not install the exchange hooks"
+        out[mode] = (bool(np.array_equal(losses, ref[0])), bool(np.array_equal(flat, ref[1])), bool(np.array_equal(m, ref[2])),
+                     bool(np.array_equal(v, ref[3])), float(np.abs(losses - ref[0]).max()))
+    # the 33.6 MB-class two-bucket exchange itself, timed on this rank's stream (bench.py reports the same as dp_self_exchange_ms)
+    g = torch.zeros(8 << 20, device="cuda")
+    for _ in range(3):
+        dist.all_reduce(g[:1 << 20]); dist.all_reduce(g[1 << 20:])
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "result.npy"), np.array([out], dtype=object), allow_pickle=True)
+    dist.destroy_process_group()
+
+
+def test_every_exchange_mode_on_rccl_world_of_one_is_bit_identical(gpu, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    out = np.load(str(tmp_path / "result.npy"), allow_pickle=True)[0]
+    for mode, (l_ok, w_ok, m_ok, v_ok, dl) in out.items():
+        assert l_ok and w_ok and m_ok and v_ok, "mode %s on RCCL: losses %s (max diff %g) weights %s m %s v %s" % (mode, l_ok, dl, w_ok, m_ok, v_ok)

@@ -1,13 +1,47 @@
 """Item-row gather / assemble (nar_model.py:921-994 + scale/center :887-907): the LDS-tiled kernel (csrc/features.hip
 k_item_assemble_lds: contiguous source segments staged per workgroup, 16-byte row stores) must produce exactly the rows of the
-one-thread-per-element kernel it replaces - G1 and Adressa feature schemas, ragged tile tails."""
+one-thread-per-element kernel it replaces - and both the rows of a numpy gather built from the layout's column descriptors - G1 and
+Adressa feature schemas, ragged tile tails."""
 import numpy as np
 import pytest
 import torch
 
 from chameleon_recsys_amd.nar import synthetic
+from chameleon_recsys_amd.nar.layout import COL_ACE, COL_EMB, COL_ITEMEMB, COL_NOVELTY, COL_NUM, COL_OHE, COL_RECENCY
 
 pytestmark = pytest.mark.gpu
+
+
+def _numpy_item_rows(rt, ids, rec, nov, stats, g1, g2):
+    """Item feature rows [R, Fi] from the resident tables, column by column as the layout describes them (float32 arithmetic)."""
+    L = rt.layout
+    desc = L.item_descriptors()
+    flat, meta, ace = rt.flat.cpu().numpy(), rt.meta_cat.cpu().numpy(), rt.ace.cpu().numpy()
+    R = ids.shape[0]
+    grp = np.where(np.arange(R) < g1, 0, np.where(np.arange(R) < g2, 1, 2))
+    f32 = np.float32
+
+    def norm(x, st):          # normalize_values + min_max_normalization, nar_model.py:996-1039
+        z = (x - st[:, 0]) / st[:, 1]
+        scaled = (z - st[:, 2] + f32(1e-24)) / np.maximum(st[:, 3] - st[:, 2], f32(2e-24))
+        return scaled * f32(2.0) - f32(1.0)
+    out = np.zeros((R, L.Fi), np.float32)
+    for c, (kind, feat, sub, dim, off) in enumerate(desc):
+        if kind == COL_OHE:
+            out[:, c] = (meta[feat, ids] == sub).astype(np.float32)
+        elif kind == COL_EMB:
+            out[:, c] = flat[off + meta[feat, ids] * dim + sub]
+        elif kind == COL_NUM:
+            out[:, c] = meta[feat, ids].astype(np.float32)
+        elif kind == COL_ACE:
+            out[:, c] = ace[ids, sub]
+        elif kind == COL_ITEMEMB:
+            out[:, c] = flat[off + ids * dim + sub]
+        elif kind == COL_RECENCY:
+            out[:, c] = norm(rec.astype(f32), stats[grp, 0:4].astype(f32))
+        elif kind == COL_NOVELTY:
+            out[:, c] = norm(nov.astype(f32), stats[grp, 4:8].astype(f32))
+    return out
 
 
 @pytest.mark.parametrize("dataset,n_items,D,R", [("gcom", 5000, 250, 1003), ("adressa", 3000, 64, 517), ("gcom", 2000, 128, 7)])
@@ -45,6 +79,16 @@ def test_item_assemble_lds_equals_elementwise(gpu, dataset, n_items, D, R):
     assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
     assert torch.equal(outs[0][0], outs[1][0]), "raw feature rows differ"
     assert torch.equal(outs[0][1], outs[1][1]), "scaled feature rows differ"
+    # ... and both against a NUMPY gather built from the layout's column descriptors (nar_model.py:921-994 column order): table rows and
+    # one-hot bits bit-exact, the two normalised columns and the gamma / beta image to fp32 rounding (the device contracts a*b+c to an FMA)
+    ref_raw = _numpy_item_rows(rt, ids.cpu().numpy(), rec.cpu().numpy(), nov.cpu().numpy(), stats.cpu().numpy(), g1, g2)
+    desc = L.item_descriptors()
+    dyn = np.isin(desc[:, 0], (COL_RECENCY, COL_NOVELTY))
+    got_raw, got_s = outs[1][0].numpy(), outs[1][1].numpy()
+    assert np.array_equal(got_raw[:, ~dyn], ref_raw[:, ~dyn]), "gathered columns differ from the numpy gather"
+    assert np.allclose(got_raw[:, dyn], ref_raw[:, dyn], rtol=2e-6, atol=2e-6)
+    gam, bet = rt.p('gamma_item').cpu().numpy(), rt.p('beta_item').cpu().numpy()
+    assert np.allclose(got_s, ref_raw * gam[None, :] + bet[None, :], rtol=2e-6, atol=2e-6)
     # the ACE block really is the article's content embedding row
     segs = rt.item_segs.cpu().numpy()
     ace_seg = [sg for sg in segs if sg[0] == 0][0]

@@ -249,3 +249,40 @@ def test_p3_big_w2_wgrad_splitk(gpu):
         torch.cuda.synchronize()
         e_p3 = float((out.double() - ref).abs().max()) / scale
         assert e_p3 < 1e-4 and e_p3 < 1.5 * e_nat + 1e-7, (splits, e_p3, e_nat)
+
+
+def test_infinite_operand_nan_in_plane_arithmetic_inf_in_native(gpu):
+    """The documented semantic difference of the plane-product arithmetic (csrc/gemm_x3.hip header, --gemm_dtype help): splitting an
+    infinite operand computes inf - inf, so the affected outputs are NaN where the native fp32 MFMA yields +-inf (or NaN only where it
+    meets a zero).  Pinned for all three GEMM paths, and one level up: behind a tanh epilogue (the CAR layer) the native path SATURATES
+    to a finite +-1 while both plane paths return NaN - a diverging run shows up as NaN in the default arithmetic, possibly as a finite
+    loss in f32_native."""
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    M = N = K = 256
+    g = torch.Generator(device=gpu).manual_seed(3)
+    A = torch.rand(M, K, device=gpu, generator=g) + 0.5          # strictly positive: inf * b keeps a sign
+    B = torch.rand(K, N, device=gpu, generator=g) + 0.5
+    A[7, 3] = float('inf')
+    bias = torch.zeros(N, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for name, fn in (("native", lib.cham_gemm_f32), ("x3", lib.cham_gemm_f32x3)):
+        for act in (0, 2):
+            C = torch.zeros(M, N, device=gpu)
+            check(fn(ptr(A), K, 0, ptr(B), N, 0, ptr(C), N, M, N, K, ptr(bias) if act else None, act, None, 0, 0, None, 0, 1, 0, None, 0, 1, st), name)
+            outs[(name, act)] = C
+    Ap, BTp = split3(A), split3(B.t().contiguous())
+    for act in (0, 2):
+        C = torch.zeros(M, N, device=gpu)
+        check(lib.cham_gemm_p3(ptr(Ap), M * K, K, ptr(BTp), N * K, K, 0, ptr(C), N, M, N, K, ptr(bias) if act else None, act, None, 0, 0, 0, None, 0, 1, st), "p3")
+        outs[("p3", act)] = C
+    torch.cuda.synchronize()
+    other = torch.ones(M, dtype=torch.bool, device=gpu); other[7] = False
+    for k, C in outs.items():
+        assert torch.isfinite(C[other]).all(), k                 # only the row that holds the inf is affected
+    assert torch.isinf(outs[("native", 0)][7]).all() and (outs[("native", 0)][7] > 0).all()
+    assert (outs[("native", 2)][7] == 1.0).all()                 # tanh(+inf) = 1: finite
+    for name in ("x3", "p3"):
+        assert torch.isnan(outs[(name, 0)][7]).all() and torch.isnan(outs[(name, 2)][7]).all(), name

@@ -3,6 +3,7 @@
 reproduce the fp32 product to ~2^-24 of |a||b| - the size of one fp32 rounding, i.e. what the native fp32 MFMA path also carries per
 accumulation step."""
 import numpy as np
+import pytest
 
 
 def bf16_rne(x):
@@ -53,9 +54,15 @@ def test_six_plane_products_match_the_fp32_product_to_one_fp32_rounding():
     assert float(rel3.max()) > 2.0 ** -17
 
 
-def test_plane_product_dot_product_error_is_fp32_class():
-    """A K = 1024 dot product: six-plane accumulation in fp32 (as the MFMA does per 16-k block) vs plain fp32 accumulation, both against
-    float64."""
+X3_ORDER = ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))       # gemm_x3.hip: smallest terms first
+P3_ORDER = ((2, 0), (1, 0), (0, 0), (0, 2), (1, 1), (0, 1))       # gemm_p3.hip: the order that lets one fragment set serve the pipeline
+
+
+@pytest.mark.parametrize("order", [X3_ORDER, P3_ORDER], ids=["x3", "p3"])
+def test_plane_product_dot_product_error_is_fp32_class(order):
+    """A K = 1024 dot product: six-plane accumulation in fp32 (as the MFMA does per 16-k block, in either kernel's pass order - the
+    accumulator already holds the sum over the previous k blocks, so the order inside a block does not matter) vs plain fp32
+    accumulation, both against float64."""
     rng = np.random.default_rng(2)
     K, n = 1024, 2000
     a = rng.standard_normal((n, K)).astype(np.float32)
@@ -64,7 +71,7 @@ def test_plane_product_dot_product_error_is_fp32_class():
     A, B = split3(a), split3(b)
     acc = np.zeros(n, np.float32)
     for k0 in range(0, K, 16):
-        for pa, pb in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):       # the kernel's pass order, smallest terms first
+        for pa, pb in order:
             blk = (A[pa][:, k0:k0 + 16].astype(np.float64) * B[pb][:, k0:k0 + 16].astype(np.float64)).sum(1)
             acc = (acc.astype(np.float64) + blk).astype(np.float32)          # one fp32 rounding per MFMA accumulation
     plain = np.zeros(n, np.float32)

@@ -425,3 +425,49 @@ def test_dropout_is_identity_in_eval_and_independent_of_row_shards(gpu):
         logits.append(model.outputs_numpy()['logits']); g_sum += model.rt.grads
     assert np.abs(np.concatenate(logits) - full['logits']).max() < 1e-5
     assert float((g_sum - g_full).abs().max()) < 2e-5 * float(g_full.abs().max()) + 1e-7
+
+
+def test_step_parity_non_default_log_bases(gpu):
+    """NARModuleModel(elapsed_days_smooth_log_base, popularity_smooth_log_base) (nar_model.py:122-123; log_base :28-34): the bases of
+    the recency feature (:1071-1075), the novelty feature (:1148) and the novelty regulariser (:544) are launch scalars - a step with
+    bases far from the defaults (and the regulariser on) against the oracle, then the defaults again on the same runtime."""
+    p = H.tiny_params(novelty_reg_factor=0.3, elapsed_days_smooth_log_base=2.5, popularity_smooth_log_base=10.0)
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    assert model.elapsed_days_smooth_log_base == 2.5 and model.popularity_smooth_log_base == 10.0
+    _compare_step(model, orc, *batches[3], st, check_grads=False)
+    # ... and the bases really are used: the default-base oracle disagrees on the same inputs
+    p0 = dict(p); p0.pop('elapsed_days_smooth_log_base'); p0.pop('popularity_smooth_log_base')
+    from oracle.nar_oracle import NAROracle
+    orc0 = NAROracle(p0, weights=orc.weights_numpy())
+    buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+    f, l = batches[3]
+    ref0 = orc0.forward(f, l, buf, pop, 'train')
+    out = model.outputs_numpy()
+    assert abs(float(ref0['total_loss'].detach()) - float(out['loss'][0])) > 1e-2
+    with pytest.raises(ValueError):
+        H.make_pair(H.tiny_params(popularity_smooth_log_base=1.0))
+
+
+def test_step_parity_numerical_article_metadata(gpu):
+    """'numerical' article features (nar_model.py:755-757 reached from get_item_features :926-939): a float-valued one (stored as
+    float32 bits in the metadata table) and an integer-valued one, next to the categorical column - forward and gradients."""
+    p = H.tiny_params()
+    rng = np.random.default_rng(5)
+    n = p['content_article_embeddings_matrix'].shape[0]
+    acfg = p['articles_features_config']
+    acfg['text_length_z'] = {'type': 'numerical', 'dtype': 'float'}
+    acfg['n_images'] = {'type': 'numerical', 'dtype': 'int'}
+    p['articles_metadata']['text_length_z'] = rng.standard_normal(n).astype(np.float32)
+    p['articles_metadata']['n_images'] = rng.integers(0, 5, size=n).astype(np.int64)
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p)
+    L = model.rt.layout
+    assert L.meta_is_float == {'text_length_z'} and L.f_item == 37 + 2 + 64 + 44 + 2
+    _compare_step(model, orc, *batches[3], st)
+    bad = dict(p); bad['articles_features_config'] = dict(acfg); bad['articles_features_config']['text_length_z'] = {'type': 'numerical', 'dtype': 'int'}
+    from chameleon_recsys_amd.nar.nar_model import NARRuntime
+    with pytest.raises(ValueError):
+        NARRuntime(bad)
