@@ -89,6 +89,8 @@ def gemm_symbol(r):
     if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
         return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
+        return "k_dm_mulpred_fused(DmfParams)"
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
         return "void gemm_p3_kernel<%s, %d, 0>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
@@ -438,7 +440,9 @@ def main():
         sh[0] += 1; sh[1] += t_ms
         # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
         # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
-        if r.get('p3'):       # operands as three bf16 planes (6 B per element), fp32 output, the dgrad reads the activation's h plane
+        if r.get('dmf'):      # dS1 in, Z2c in, three planes out, pred / dpred / b2 partials per position
+            e['bytes'] += 4.0 * r['M'] * r['K'] + 6.0 * r['K'] * r['N'] + 4.0 * r['M'] * r['N'] + 6.0 * r['M'] * r['N']
+        elif r.get('p3'):       # operands as three bf16 planes (6 B per element), fp32 output, the dgrad reads the activation's h plane
             e['bytes'] += 6.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
                 (4.0 * r['N'] if r['bias'] else 0)
         elif r.get('b16'):
@@ -464,7 +468,7 @@ def main():
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3')) else FP32_MATRIX_PEAK_TFLOPS)
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3') or e['r'].get('dmf')) else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
                 "mfma_peak_tflops": round(peak, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4),

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "cham_split3": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P]),
     "cham_combine_fwd_p3": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
     "cham_mulpred_bwd_p3": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P]),
+    "cham_dm_mulpred_p3": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
     "cham_gemm_b16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                               P, c_size_t, c_int, P]),
     "cham_gemm_b16_set_variant": (None, [c_int]),

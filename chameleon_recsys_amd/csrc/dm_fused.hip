@@ -1,0 +1,267 @@
+// Scorer layer-1 dgrad fused with the `cand (.) pred` backward (round 3; gfx950, wave64).
+//
+//   dM[r, k]   = sum_j dS1[r, j] Ws1[k, j]                        (autodiff of nar_model.py:447-473, matching_dense_layer_1; K = 128)
+//   dZ2[r, k]  = dM[r, k] * pred[p(r), k] * (1 - Z2c[r, k]^2)     (autodiff of cand (.) pred and the CAR tanh, :478-495, :384-388)
+//   dpred[p,k] = (sum_{r in p} dM[r, k] Z2c[r, k]) * (1 - pred[p, k]^2)
+//   b2part[p,k]= sum_{r in p} dZ2[r, k]                            (the position's share of the CAR bias gradient)
+//
+// Unfused (cham_gemm_f32x3 + cham_mulpred_bwd_p3) the [B*T*(1+N), C] matrix dM is written as fp32 (1 GB at the G1 shape) by a K = 128
+// GEMM that is all epilogue, and read straight back: 1.19 + 0.73 ms of a 12.3 ms step, on the critical path between the scorer backward
+// and the CAR dgrad (profiles/r03_notes.md).  Here dM exists only in the MFMA accumulators; HBM sees dS1 (0.13 GB), Z2c (1 GB) in
+// and the three bf16 planes of dZ2 (1.5 GB) out.
+//
+// One workgroup = PW = floor(256 / (1+N)) whole positions (their PW * (1+N) <= 256 candidate rows; (1+N) >= 32) x ALL C columns:
+//   * 8 waves, wave w owns rows [32 w, 32 w + 32): its dS1 fragments (32 rows x K = 128, three bf16 planes: 96 VGPRs) are loaded and split
+//     once and stay in registers;
+//   * the columns are walked in tiles of 64 = two 32x32 MFMA tiles per wave whose B fragments are PERMUTED - fragment row n of tile j is
+//     Ws1 row 2 n + j - so lane n ends up with two CONSECUTIVE columns (8-byte Z2c loads, 4-byte plane stores, whole 256- / 128-byte row
+//     segments per half-wave) while keeping 16 rows of those columns in one lane: the per-position column sums are in-lane adds + one
+//     half-wave exchange, then a fixed-order sum over the waves through LDS.  No float atomics.
+//   * Ws1's planes (written once per step by cham_split3) stream through LDS by LDS-DMA in half-stages of 64 columns x 64 k x 3 planes
+//     = 24 KB, two buffers; six plane products as in gemm_x3.hip / gemm_p3.hip.
+// Per half-stage and wave: 48 MFMAs, 24 ds_read_b128, 3 DMA requests, one barrier; every second half-stage the epilogue of a column tile.
+#include "gemm_shared.h"
+#include <type_traits>
+
+#define DMF_NT 2                              // 32-column MFMA tiles per wave and column tile (4: 128 columns per tile spills the register file)
+#define DMF_COLS (32 * DMF_NT)                // columns per column tile
+#define DMF_PLANE (DMF_COLS * 128)            // one plane of a half-stage: DMF_COLS slots x 64 k x 2 B
+#define DMF_HALF (3 * DMF_PLANE)              // one half-stage: three planes
+#define DMF_RED_OFF (2 * DMF_HALF)            // [8 waves][2 slots][2 quantities][DMF_COLS columns] fp32
+#define DMF_RED_BYTES (8 * 4 * DMF_COLS * 4)
+
+static_assert(DMF_NT == 2, "the epilogue packs exactly two tiles' columns per lane");
+
+struct DmfParams {
+    const float* dS1; int lds1;                 // [Rc, 128]
+    const __bf16* W; long long w_ps;            // planes of Ws1 [C, 128] as stored, plane stride in elements
+    const float* Z2c; const float* pred;        // [Rc, C], [BT, C]
+    __bf16* out; long long out_ps;              // planes of dZ2 [Rc, C]
+    float* dpred; float* b2part;                // [BT, C]
+    int C, BT, NC, PW;
+};
+
+__device__ __forceinline__ void dmf_dma_one(unsigned lds, unsigned voff, const u32x4& r) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r) : "memory");
+}
+
+__global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dmf_smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int NC = p.NC, C = p.C;
+    const int pos0 = blockIdx.x * p.PW;                                   // first position of this workgroup
+    const int npos = min(p.PW, p.BT - pos0);
+    const int rows_valid = npos * NC;                                     // <= 256
+    const size_t row0 = (size_t)pos0 * NC;                                // first candidate row
+    const int wr0 = 32 * wave;                                            // this wave's first row inside the workgroup
+
+    // ---- A: this wave's 32 rows of dS1, K = 128, split into planes; lane (row l31, k-half hh) holds 8 consecutive k per 16-k step
+    bf16x8 AH[8], AM[8], AL[8];
+    {
+        const int r = wr0 + l31;
+        const bool ok = r < rows_valid;
+        const float* src = p.dS1 + (row0 + (ok ? r : 0)) * (size_t)p.lds1 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+            if (ok) { x0 = *reinterpret_cast<const float4*>(src + 16 * s); x1 = *reinterpret_cast<const float4*>(src + 16 * s + 4); }
+            const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
+        }
+    }
+
+    // ---- B: LDS-DMA of Ws1's planes.  Half-stage image per plane: [slot 0..127][64 k] (128 B per slot), slot = j * 32 + n holds Ws1 row
+    // n0 + 4 n + j; the eight 16-byte pieces of a slot are XOR-ed with (slot >> 1) & 7 (conflict-free ds_read_b128 fragments).  One
+    // request fills 8 slots: lane l -> slot 8 c + l / 8, LDS piece l & 7, i.e. source piece (l & 7) ^ ((slot >> 1) & 7).
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)dmf_smem;
+    u32x4 rw[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned long long a = (unsigned long long)(p.W + q * p.w_ps);
+        rw[q].x = (unsigned)a; rw[q].y = (unsigned)(a >> 32) & 0xFFFFu; rw[q].z = (unsigned)((size_t)C * 128 * 2); rw[q].w = 0x00020000u;
+    }
+    // one request per plane and half-stage fills this wave's 8 slots
+    unsigned voff;
+    {
+        const int slot = 8 * wave + (lane >> 3);
+        const int piece = (lane & 7) ^ ((slot >> 1) & 7);
+        const int col = DMF_NT * (slot & 31) + (slot >> 5);               // column inside the column tile
+        voff = (unsigned)(col * 128 + piece * 8) * 2u;
+    }
+    auto dma_half = [&](int h) {                                          // half-stage h: column tile h / 2, k half h & 1 -> buffer h & 1
+        const unsigned base = lds_base + (unsigned)(h & 1) * DMF_HALF + (unsigned)wave * 1024u;
+        const unsigned add = (unsigned)(((h >> 1) * DMF_COLS) * 128 + (h & 1) * 64) * 2u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dmf_dma_one(base + (unsigned)q * DMF_PLANE, voff + add, rw[q]);
+    };
+    // fragment read offsets: tile j, lane (n = l31, hh), 16-k step t of the half: slot = 32 j + n, piece (2 t + hh) ^ ((slot >> 1) & 7)
+    // ((slot >> 1) & 7 does not depend on j: tile j is the same lane offset + j * 4096)
+    unsigned fo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fo[t] = (unsigned)(l31 * 128 + (((2 * t + hh) ^ ((l31 >> 1) & 7)) * 16));
+
+    // ---- rows of this lane: e -> local row wr0 + (e & 3) + 8 (e >> 2) + 4 hh; positions: the wave's 32 rows span at most two (NC >= 32)
+    const int pa = wr0 / NC;                                              // local position of the wave's first row
+    const int bnd = (pa + 1) * NC - wr0;                                  // rows (relative to wr0) >= bnd belong to position pa + 1
+    const int ntiles = C / DMF_COLS, nhalf = 2 * ntiles;
+
+    dma_half(0);
+    dma_half(1);
+    floatx16 acc[DMF_NT];
+#pragma unroll
+    for (int j = 0; j < DMF_NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      // half-stage 0 landed (this wave's requests)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+
+    // the MFMAs of one half-stage; PAR = k half (compile-time: the A fragments are register arrays and must be indexed statically)
+    auto mfma_half = [&](auto PARC) {
+        constexpr int PAR = decltype(PARC)::value, s0 = PAR * 4;
+        const unsigned char* S = dmf_smem + PAR * DMF_HALF;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x8 bh[DMF_NT], bm[DMF_NT], bl[DMF_NT];
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(S + fo[t] + j * 4096);
+                bm[j] = *reinterpret_cast<const bf16x8*>(S + DMF_PLANE + fo[t] + j * 4096);
+                bl[j] = *reinterpret_cast<const bf16x8*>(S + 2 * DMF_PLANE + fo[t] + j * 4096);
+            }
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[s0 + t], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bm[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bm[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
+        }
+    };
+    for (int h = 0; h < nhalf; ++h) {
+        if (h & 1) mfma_half(std::integral_constant<int, 1>{});
+        else mfma_half(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's requests for half-stage h + 1 (issued a half-stage ago) have landed; nothing else of its is in flight except
+        // the previous tile's stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (h & 1) {
+            // ---- epilogue of column tile h / 2: lane n holds columns n0 + 2 n, n0 + 2 n + 1 of its 16 rows
+            const int col = (h >> 1) * DMF_COLS + DMF_NT * l31;
+            float2 pra = make_float2(0.f, 0.f), prb = pra;
+            if (pa < npos) pra = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa) * C + col);
+            if (pa + 1 < npos) prb = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa + 1) * C + col);
+            float2 sa = make_float2(0.f, 0.f), sb = sa, ca = sa, cb = sa;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * hh;           // row relative to the wave's first row
+                const int r = wr0 + rr;
+                if (r < rows_valid) {
+                    const size_t off = (row0 + r) * (size_t)C + col;
+                    const float2 z = *reinterpret_cast<const float2*>(p.Z2c + off);
+                    const bool second = rr >= bnd;
+                    const float2 pr = second ? prb : pra;
+                    const float2 g = make_float2(acc[0][e], acc[1][e]);
+                    float2 o;
+                    o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
+                    {
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        bf16x2_t ph, pm, pl;
+                        __bf16 a, b, c;
+                        split3(o.x, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c;
+                        split3(o.y, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c;
+                        *reinterpret_cast<bf16x2_t*>(p.out + off) = ph;
+                        *reinterpret_cast<bf16x2_t*>(p.out + off + p.out_ps) = pm;
+                        *reinterpret_cast<bf16x2_t*>(p.out + off + 2 * p.out_ps) = pl;
+                    }
+                    const float2 gz = make_float2(g.x * z.x, g.y * z.y);
+                    if (second) { sb.x += gz.x; sb.y += gz.y; cb.x += o.x; cb.y += o.y; }
+                    else { sa.x += gz.x; sa.y += gz.y; ca.x += o.x; ca.y += o.y; }
+                }
+                acc[0][e] = 0.f; acc[1][e] = 0.f;
+            }
+            // the other half-wave holds the other 16 rows of the same columns: lower half + upper half, in that order
+            float* red = reinterpret_cast<float*>(dmf_smem + DMF_RED_OFF) + (size_t)wave * (4 * DMF_COLS);       // [slot 2][quantity 2][DMF_COLS]
+            float2 q[4] = {sa, ca, sb, cb};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float2 o;
+                o.x = __shfl_xor(q[i].x, 32, 64); o.y = __shfl_xor(q[i].y, 32, 64);
+                if (hh == 0) *reinterpret_cast<float2*>(red + i * DMF_COLS + DMF_NT * l31) = make_float2(q[i].x + o.x, q[i].y + o.y);
+            }
+        }
+        // every wave: done reading buffer h & 1, its requests for h + 1 landed (and, on odd h, its partial sums are in LDS)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (h & 1) {
+            // ---- per-position column sums of this column tile: thread (position, column) adds the waves in ascending order
+            const float* redw = reinterpret_cast<const float*>(dmf_smem + DMF_RED_OFF);
+            for (int idx = threadIdx.x; idx < npos * DMF_COLS; idx += 512) {
+                const int pl = idx / DMF_COLS, c = idx % DMF_COLS;
+                float s = 0.f, cs = 0.f;
+                const int w_lo = (pl * NC) >> 5, w_hi = min(7, ((pl + 1) * NC - 1) >> 5);
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const int slot = (pl == (32 * w) / NC) ? 0 : 1;
+                    s += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + c];
+                    cs += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + DMF_COLS + c];
+                }
+                const int colg = (h >> 1) * DMF_COLS + c;
+                const float pr = p.pred[(size_t)(pos0 + pl) * C + colg];
+                p.dpred[(size_t)(pos0 + pl) * C + colg] = s * (1.f - pr * pr);
+                if (p.b2part) p.b2part[(size_t)(pos0 + pl) * C + colg] = cs;
+            }
+            // (the next epilogue writes `red` again only after the next two barriers)
+        }
+        // (requested only now: the loads of the block above are visible to the compiler, whose wait for them would also wait for
+        // requests issued before them)
+        if (h + 2 < nhalf) dma_half(h + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// dS1 [BT * (1 + N), 128] (row stride lds1), planes of Ws1 [C, 128] (cham_split3 of the weight as stored), Z2c [BT * (1 + N), C], pred
+// [BT, C] -> planes of dZ2 (plane stride out_plane_stride elements), dpred_pre [BT, C], col_part [BT, C] (may be NULL).
+// Takes C % 64 == 0, 32 <= 1 + N <= 256 and K = 128 (the reference's matching_dense_layer_1 width); -EINVAL otherwise (the caller
+// keeps cham_gemm_f32x3 + cham_mulpred_bwd_p3).
+extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
+                                  const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, float* dpred_pre,
+                                  float* col_part, void* stream) {
+    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0) return -CHAM_ERR_ARG;
+    const int NC = N + 1;
+    if (K != 128 || (C % DMF_COLS) || C <= 0 || NC < 32 || NC > 256 || (lds1 & 3) || lds1 < K || (out_plane_stride & 3) || (w_plane_stride & 7))
+        return -CHAM_ERR_ARG;
+    if (((uintptr_t)dS1 | (uintptr_t)Wp | (uintptr_t)Z2c | (uintptr_t)pred | (uintptr_t)dZ2p) & 15) return -CHAM_ERR_ARG;
+    if (BT == 0) return CHAM_OK;
+    DmfParams p;
+    p.dS1 = dS1; p.lds1 = lds1; p.W = reinterpret_cast<const __bf16*>(Wp); p.w_ps = w_plane_stride; p.Z2c = Z2c; p.pred = pred;
+    p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.dpred = dpred_pre; p.b2part = col_part;
+    p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
+    constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dm_mulpred_fused), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return -CHAM_ERR_LAUNCH;
+        done = true;
+    }
+    hipLaunchKernelGGL(k_dm_mulpred_fused, dim3((BT + p.PW - 1) / p.PW), dim3(512), smem, (hipStream_t)stream, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

@@ -547,10 +547,7 @@ extern "C" int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, co
         g.A = nullptr; g.B = nullptr; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = 0; g.ldb = 0; g.ldc = ldc; g.bias = nullptr; g.act = ACT_NONE;
         g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1; g.accumulate = accumulate;
         g.kchunk = kchunk; g.splits = p.splits; g.partial = workspace; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
-        const size_t n = (size_t)M * N;
-        int blocks = (int)((n + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, g);
+        launch_splitk_reduce(g, st);
         CHAM_CHECK_LAUNCH();
         return CHAM_OK;
     }

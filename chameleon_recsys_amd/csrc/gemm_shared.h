@@ -251,18 +251,89 @@ struct TileLoaderBF {
 };
 
 
-// fixed-order reduction of split-K partials (+ the generic epilogue)
+// fixed-order reduction of split-K partials (+ the generic epilogue).  Four consecutive columns per thread (16-byte loads of every
+// partial slab, four slabs in flight), the slabs added in ascending split order exactly as the scalar form did (bit-identical sums).
+// Round 2's one-element-per-thread form with a 64-bit divide per element cost 1.1 ms per step over its ten launches.
+__device__ __forceinline__ float4 splitk_finish(const GemmParams& p, float4 v, int row, int col) {
+    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    v.x = act_fwd(v.x, p.act); v.y = act_fwd(v.y, p.act); v.z = act_fwd(v.z, p.act); v.w = act_fwd(v.w, p.act);
+    if (p.dref) {
+        const float* d = p.dref + (size_t)row * p.ldr + col;
+        v.x *= act_bwd_from_out(d[0], p.dact); v.y *= act_bwd_from_out(d[1], p.dact);
+        v.z *= act_bwd_from_out(d[2], p.dact); v.w *= act_bwd_from_out(d[3], p.dact);
+    }
+    return v;
+}
 static __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmParams p) {
-    const size_t n = (size_t)p.M * p.N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * n + i];
-        const int row = (int)(i / p.N), col = (int)(i % p.N);
-        if (p.bias) v += p.bias[col];
-        v = act_fwd(v, p.act);
-        if (p.dref) v *= act_bwd_from_out(p.dref[(size_t)row * p.ldr + col], p.dact);
+    const size_t n = (size_t)p.M * p.N, n4 = n / 4;           // (N % 4 == 0: gemm_plan)
+    const unsigned N4 = (unsigned)p.N / 4u;
+    const bool vec_c = ((p.ldc & 3) == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 4 <= p.splits; s += 4) {
+            const float4 x0 = src[(size_t)(s + 0) * n4], x1 = src[(size_t)(s + 1) * n4], x2 = src[(size_t)(s + 2) * n4],
+                         x3 = src[(size_t)(s + 3) * n4];
+            v.x += x0.x; v.y += x0.y; v.z += x0.z; v.w += x0.w;
+            v.x += x1.x; v.y += x1.y; v.z += x1.z; v.w += x1.w;
+            v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
+            v.x += x3.x; v.y += x3.y; v.z += x3.z; v.w += x3.w;
+        }
+        for (; s < p.splits; ++s) { const float4 x = src[(size_t)s * n4]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+        const int row = (int)(i / N4), col = (int)(i % N4) * 4;
+        v = splitk_finish(p, v, row, col);
         float* c = p.C + (size_t)row * p.ldc + col;
-        *c = p.accumulate ? (*c + v) : v;
+        if (vec_c) {
+            float4* c4 = reinterpret_cast<float4*>(c);
+            if (p.accumulate) { const float4 o = *c4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *c4 = v;
+        } else {
+            if (p.accumulate) { v.x += c[0]; v.y += c[1]; v.z += c[2]; v.w += c[3]; }
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        }
+    }
+}
+// Small outputs with MANY splits (the scorer's narrow weight gradients: 128 x 64 outputs, hundreds of K-splits - the form above walked
+// them with 32 threads, 0.47 ms per launch on the lane the W2 weight gradient waits on): 16 threads share one group of four columns,
+// thread g sums the splits g, g + 16, ... and the sixteen partial sums are added in ascending g through LDS - a fixed order.
+static __global__ __launch_bounds__(256) void gemm_splitk_reduce_wide(GemmParams p) {
+    __shared__ float4 red[256];
+    const size_t n = (size_t)p.M * p.N, n4 = n / 4;
+    const unsigned N4 = (unsigned)p.N / 4u;
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + o;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* src = reinterpret_cast<const float4*>(p.partial) + i;
+        int s = g;
+        for (; s + 48 < p.splits; s += 64) {
+            const float4 x0 = src[(size_t)s * n4], x1 = src[(size_t)(s + 16) * n4], x2 = src[(size_t)(s + 32) * n4], x3 = src[(size_t)(s + 48) * n4];
+            v.x += x0.x; v.y += x0.y; v.z += x0.z; v.w += x0.w;
+            v.x += x1.x; v.y += x1.y; v.z += x1.z; v.w += x1.w;
+            v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
+            v.x += x3.x; v.y += x3.y; v.z += x3.z; v.w += x3.w;
+        }
+        for (; s < p.splits; s += 16) { const float4 x = src[(size_t)s * n4]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (g != 0 || i >= n4) return;
+    for (int q = 1; q < 16; ++q) { const float4 x = red[q * 16 + o]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    const int row = (int)(i / N4), col = (int)(i % N4) * 4;
+    v = splitk_finish(p, v, row, col);
+    float* c = p.C + (size_t)row * p.ldc + col;
+    if (p.accumulate) { v.x += c[0]; v.y += c[1]; v.z += c[2]; v.w += c[3]; }
+    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+}
+static inline void launch_splitk_reduce(const GemmParams& p, hipStream_t st) {
+    const size_t n4 = (size_t)p.M * p.N / 4;
+    if (n4 <= 32768 && p.splits >= 32) {
+        hipLaunchKernelGGL(gemm_splitk_reduce_wide, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, p);
+    } else {
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
     }
 }
 

@@ -431,10 +431,7 @@ static int x3_launch_cfg(GemmParams& p, hipStream_t st) {
         p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
         const int rc = x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
         if (rc != CHAM_OK) return rc;
-        const size_t n = (size_t)p.M * p.N;
-        int blocks = (int)((n + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        launch_splitk_reduce(p, st);
         CHAM_CHECK_LAUNCH();
         return CHAM_OK;
     }

@@ -246,6 +246,9 @@ class NARRuntime:
             C_ = L.C
             self.w2p = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)       # planes of W2 as stored (CAR dgrad)
             self.w2tp = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)      # planes of W2^T (CAR forward)
+            # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip); CHAM_DM_FUSED=0: the two separate kernels
+            self.dm_fused = os.environ.get("CHAM_DM_FUSED", "1") == "1" and L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
+            self.ws1p = torch.zeros(3, C_, 128, dtype=torch.bfloat16, device=dev)     # planes of Ws1 as stored
         self._plans = {}
         self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
         self.plan_bytes_budget = 128 << 30        # of the 288 GB: activations of the cached shapes
@@ -284,6 +287,8 @@ class NARRuntime:
         if self.p3:
             C = self.layout.C
             check(self.lib.cham_split3(ptr(self.p('W2')), C, C, C, ptr(self.w2p), C * C, C, ptr(self.w2tp), C * C, C, _stream()), "cham_split3")
+            if self.dm_fused:
+                check(self.lib.cham_split3(ptr(self.p('Ws1')), C, 128, 128, ptr(self.ws1p), C * 128, 128, None, 0, 0, _stream()), "cham_split3")
         if self.b16:
             for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
                 r, c = self.layout.entries[name].shape
@@ -1042,9 +1047,11 @@ class NARModuleModel:
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
         fused = False      # (round 1's fused scorer-dgrad + mulpred epilogue measured slower than the two passes and was removed in round 2)
+        # scorer layer-1 dgrad + cand (.) pred backward in one kernel (csrc/dm_fused.hip): dM never reaches HBM
+        dm_fused = use_p3 and rt.dm_fused and 32 <= NC <= 256
         if b16:
             rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
-        else:
+        elif not dm_fused:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
         e_side0 = mark() if (on and rt.x3 and rt.ws1_after_dm) else e_dS1
         def scorer_small_wgrads():       # layers 2-4: short split-K GEMMs + column sums, nothing but Adam (and the early DP bucket) waits for them
@@ -1088,7 +1095,18 @@ class NARModuleModel:
             check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(
                 ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N, ptr(pl.dpred[g0:g1]),
                 _stream()), "cham_mulpred_bwd")
-        if use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
+        if dm_fused:
+            prof = rt.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.cham_dm_mulpred_p3(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
+                                         ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_p3")
+            if prof is not None:
+                e1.record()
+                prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=False,
+                                 dmf=True, tile=0, epi=0, ev=(e0, e1)))
+        elif use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_p3(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part), s),
                   "cham_mulpred_bwd_p3")
         elif not fused:

@@ -166,6 +166,16 @@ int cham_combine_fwd_p3(const float* U, const float* V, int C, int BT, int N, in
 int cham_mulpred_bwd_p3(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,
                         long long plane_stride, float* col_part, void* stream);
 
+/* Scorer layer-1 dgrad fused with the `cand (.) pred` backward (csrc/dm_fused.hip): what cham_gemm_f32x3(dS1, Ws1^T) followed by
+ * cham_mulpred_bwd_p3 compute - the autodiff of matching_dense_layer_1 (nar_model.py:447-473), of cand (.) pred (:478-495) and of the
+ * CAR tanh (:384-388) - without materialising the [B*T*(1+N), C] matrix between them: dS1 [BT*(1+N), K = 128] (row stride lds1), Wp =
+ * plane 0 of cham_split3(Ws1 [C, K]) (planes w_plane_stride elements apart), Z2c [BT*(1+N), C], pred [BT, C] -> the three planes of the
+ * gradient at the CAR tanh (dZ2p, planes out_plane_stride elements apart), dpred_pre [BT, C] and, when col_part != NULL, col_part[bt] =
+ * the sum of position bt's rows.  Takes K == 128, C % 64 == 0 and 32 <= 1 + N <= 256; -EINVAL otherwise (the caller keeps the two
+ * separate calls). */
+int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c, const float* pred,
+                       int C, int BT, int N, void* dZ2p, long long out_plane_stride, float* dpred_pre, float* col_part, void* stream);
+
 /* bf16-RESIDENT GEMMs of the bf16 configuration (csrc/gemm_b16.hip): the matrices with one row per candidate live in HBM as bf16
  * (weights: a bf16 shadow of the fp32 master copy); fp32 accumulation / bias / activation.
  *   transA = 0, transB = 1 (NT): A [M, lda], B [N, ldb] bf16, k contiguous; C bf16 (out_f32 = 0) or fp32 [M, ldc];
