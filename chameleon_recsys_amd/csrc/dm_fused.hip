@@ -63,20 +63,35 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     const int wr0 = 32 * wave;                                            // this wave's first row inside the workgroup
 
     // ---- A: this wave's 32 rows of dS1, K = 128, split into planes; lane (row l31, k-half hh) holds 8 consecutive k per 16-k step
+    // (every global access of this kernel goes through a buffer descriptor sized to the workgroup's valid rows: rows beyond them read
+    // zeros / drop their stores without a branch - a branch around a load makes hipcc wait for each load in turn, 16 dependent HBM round
+    // trips per column tile in the first version of this epilogue: 1.25 ms for the kernel, profiles/r03_notes.md)
     bf16x8 AH[8], AM[8], AL[8];
     {
-        const int r = wr0 + l31;
-        const bool ok = r < rows_valid;
-        const float* src = p.dS1 + (row0 + (ok ? r : 0)) * (size_t)p.lds1 + 8 * hh;
+        const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dS1 + row0 * (size_t)p.lds1), 0,
+                                                                            (unsigned)((size_t)rows_valid * p.lds1 * 4), 0x00020000);
+        const unsigned ao = ((unsigned)(wr0 + l31) * (unsigned)p.lds1 + 8u * hh) * 4u;
+        u32x4 x[16];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-            if (ok) { x0 = *reinterpret_cast<const float4*>(src + 16 * s); x1 = *reinterpret_cast<const float4*>(src + 16 * s + 4); }
-            const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            x[2 * s] = __builtin_amdgcn_raw_buffer_load_b128(aw, ao + 64u * s, 0, 0);
+            x[2 * s + 1] = __builtin_amdgcn_raw_buffer_load_b128(aw, ao + 64u * s + 16u, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float v[8] = {__uint_as_float(x[2 * s].x), __uint_as_float(x[2 * s].y), __uint_as_float(x[2 * s].z), __uint_as_float(x[2 * s].w),
+                                __uint_as_float(x[2 * s + 1].x), __uint_as_float(x[2 * s + 1].y), __uint_as_float(x[2 * s + 1].z),
+                                __uint_as_float(x[2 * s + 1].w)};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
         }
     }
+    const __amdgpu_buffer_rsrc_t zw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z2c + row0 * (size_t)C), 0,
+                                                                        (unsigned)((size_t)rows_valid * C * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t ow[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + q * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
 
     // ---- B: LDS-DMA of Ws1's planes.  Half-stage image per plane: [slot 0..127][64 k] (128 B per slot), slot = j * 32 + n holds Ws1 row
     // n0 + 4 n + j; the eight 16-byte pieces of a slot are XOR-ed with (slot >> 1) & 7 (conflict-free ds_read_b128 fragments).  One
@@ -168,32 +183,37 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             if (pa < npos) pra = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa) * C + col);
             if (pa + 1 < npos) prb = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa + 1) * C + col);
             float2 sa = make_float2(0.f, 0.f), sb = sa, ca = sa, cb = sa;
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t zz[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {      // all sixteen row loads in flight at once (rows beyond the valid ones: zeros)
+                const unsigned r = (unsigned)(wr0 + (e & 3) + 8 * (e >> 2) + 4 * hh);
+                zz[e] = __builtin_amdgcn_raw_buffer_load_b64(zw, (r * (unsigned)C + (unsigned)col) * 4u, 0, 0);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * hh;           // row relative to the wave's first row
-                const int r = wr0 + rr;
-                if (r < rows_valid) {
-                    const size_t off = (row0 + r) * (size_t)C + col;
-                    const float2 z = *reinterpret_cast<const float2*>(p.Z2c + off);
-                    const bool second = rr >= bnd;
-                    const float2 pr = second ? prb : pra;
-                    const float2 g = make_float2(acc[0][e], acc[1][e]);
-                    float2 o;
-                    o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
-                    {
-                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                        bf16x2_t ph, pm, pl;
-                        __bf16 a, b, c;
-                        split3(o.x, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c;
-                        split3(o.y, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c;
-                        *reinterpret_cast<bf16x2_t*>(p.out + off) = ph;
-                        *reinterpret_cast<bf16x2_t*>(p.out + off + p.out_ps) = pm;
-                        *reinterpret_cast<bf16x2_t*>(p.out + off + 2 * p.out_ps) = pl;
-                    }
-                    const float2 gz = make_float2(g.x * z.x, g.y * z.y);
-                    if (second) { sb.x += gz.x; sb.y += gz.y; cb.x += o.x; cb.y += o.y; }
-                    else { sa.x += gz.x; sa.y += gz.y; ca.x += o.x; ca.y += o.y; }
+                const unsigned r = (unsigned)(wr0 + rr);
+                const float2 z = make_float2(__uint_as_float(zz[e].x), __uint_as_float(zz[e].y));
+                const bool second = rr >= bnd;
+                const float2 pr = second ? prb : pra;
+                const float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
+                float2 o;
+                o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
+                {
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    bf16x2_t ph, pm, pl;
+                    __bf16 a, b, c;
+                    split3(o.x, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c;
+                    split3(o.y, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c;
+                    const unsigned oo = (r * (unsigned)C + (unsigned)col) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ph), ow[0], oo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), ow[1], oo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pl), ow[2], oo, 0, 0);
                 }
+                const float2 gz = make_float2(g.x * z.x, g.y * z.y);
+                sb.x += second ? gz.x : 0.f; sb.y += second ? gz.y : 0.f; cb.x += second ? o.x : 0.f; cb.y += second ? o.y : 0.f;
+                sa.x += second ? 0.f : gz.x; sa.y += second ? 0.f : gz.y; ca.x += second ? 0.f : o.x; ca.y += second ? 0.f : o.y;
                 acc[0][e] = 0.f; acc[1][e] = 0.f;
             }
             // the other half-wave holds the other 16 rows of the same columns: lower half + upper half, in that order

@@ -213,6 +213,10 @@ class NARRuntime:
         # - measured neutral (16.95-17.13 ms both ways; 64 splits 17.6 ms): experiment switch, default off
         self.tail_on_side = os.environ.get("CHAM_TAIL_ON_SIDE", "0") == "1"
         self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
+        # K-splits of the plane-resident W2 weight gradient: 0 = automatic (16: one workgroup per CU for the whole 2 ms, nothing else
+        # gets a CU meanwhile); 32 (default): two rounds of shorter workgroups, the main lane's PreCAR backward slips in between
+        # (11.73-11.75 vs 11.80-11.84 ms/step, two alternating runs each in one gpurun call)
+        self.p3_w2_splits = int(os.environ.get("CHAM_P3_W2_SPLITS", "32"))
         # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
         # per-CU matrix kernels that only time-slice the chip when they overlap
         self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
@@ -1209,7 +1213,7 @@ class NARModuleModel:
                         # rows (fp32) added by the on-the-fly kernel; b2 from the per-position partial sums of k_mulpred_bwd_p3
                         if on and rt.w2_after_dgrad:
                             rt.side_stream.wait_event(e_cdgrad)
-                        rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=0)
+                        rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=rt.p3_w2_splits)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)

@@ -128,7 +128,8 @@ def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, p3):
         # CAR forward + dgrad (NT) and the W2 weight gradient (TN, split-K) on the plane-resident kernel; scorer layer 1 (row scale),
         # its wgrad and dgrad on the 256x128 on-the-fly instance; nothing wide on the native kernels
         assert c3[0] == 2 and c3[1] == 1 and c[1] == 0 and c[2] == 0, (c3, x, c)
-        assert x[1] >= (3 if length_dist == "full" else 1), x
+        # (scorer layer 1 forward + its weight gradient; its dgrad lives in the fused kernel csrc/dm_fused.hip)
+        assert x[1] >= (2 if length_dist == "full" else 0) and x[0] + x[1] >= 2 and model.rt.dm_fused, x
     elif gemm_dtype == "f32":
         # CAR forward / dgrad / wgrad, scorer layer 1 (row scale) + its wgrad and dgrad on the 256x128 bf16x3 instance; nothing wide on
         # the native kernels
@@ -180,7 +181,7 @@ def test_step_parity_adressa_shape(gpu):
     p3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
     x, c3 = x3_counts(lib), p3_counts(lib)
-    assert c3[0] == 2 and c3[1] == 1 and x[1] >= 3, (c3, x)
+    assert c3[0] == 2 and c3[1] == 1 and x[1] >= 2, (c3, x)
 
 
 def test_step_parity_g1_shape_bf16(gpu):
