@@ -311,49 +311,86 @@ __global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ 
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < R) perm[rank[r]] = r;
 }
-// NTH = 64: segments of <= 32 rows (almost all: one wave, lanes over the columns, rows in order, 4 loads in flight);
-// NTH = 1024: longer segments (popular articles sit in hundreds to thousands of a batch's rows): 16 waves = (16 / column blocks)
-// row stripes x column blocks of 64, stripe s takes rows s, s + S, ... in order, the stripe sums are added in stripe order.
-// Both are launched over all R sorted positions; a workgroup that is not the head of a segment of its length class exits.
-template <int NTH>
-__global__ __launch_bounds__(NTH) void k_emb_grad_grouped(const float* __restrict__ dxs, int R, int F, int c0, int dim,
-                                                          const float* __restrict__ gamma, const int64_t* __restrict__ ids,
-                                                          const int* __restrict__ perm, float* __restrict__ table_grad) {
-    constexpr int NW = NTH / 64;
-    __shared__ float part[NW][64];
-    const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t id = ids[perm[i]];
-    if (i > 0 && ids[perm[i - 1]] == id) return;          // not the head of its segment
-    int len = 0;
-    for (;;) {                                            // segment length (every wave computes the same value)
-        const int j = i + len + lane;
-        const bool same = j < R && ids[perm[j]] == id;
-        const unsigned long long m = __ballot(same);
-        const int run = (m == ~0ull) ? 64 : __ffsll((long long)~m) - 1;
-        len += run;
-        if (run < 64 || NTH == 64) break;                 // (the one-wave launch only needs to know whether len <= 32)
-    }
-    if ((NTH == 64) != (len <= 32)) return;               // the other launch's length class
-    const int* rows = perm + i;
-    const int ncb = (dim + 63) / 64;                      // column blocks of 64 (dim <= 512)
-    if (NTH == 64) {
-        for (int cb = 0; cb < ncb; ++cb) {
-            const int sub = cb * 64 + lane;
-            const bool cok = sub < dim;
-            float a = 0.f;
-            int m = 0;
-            for (; m + 4 <= len; m += 4) {
-                float x[4];
+// Segment table of the sorted row list (depends on the ids only: built in the forward pass next to `perm`): seg[0] = number of
+// segments, seg[1] = number of LONG segments (> 32 rows), seg[2 .. 2 + n_seg] = first sorted position of every segment (+ R as the
+// end marker), seg[R + 4 ..] = the indices of the long segments.  One workgroup, two block scans, ascending order everywhere.
+// (Round 2 launched one workgroup per SORTED POSITION, twice - 64 and 1024 threads - and let the non-heads exit: 400 k waves created to
+// run ~10 k segment sums, 1.08 ms for 71 MB at the config-5 size; profiles/r03_notes.md.)
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* wsum /*[16]*/, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = cok ? dxs[(size_t)rows[m + u] * F + c0 + sub] : 0.f;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) { if (q < w) off += wsum[q]; tot += wsum[q]; }
+    *total = tot;
+    return off + incl - v;
+}
+__global__ __launch_bounds__(1024) void k_seg_table(const int64_t* __restrict__ ids, const int* __restrict__ perm, int R, int* __restrict__ seg) {
+    __shared__ int wsum[16];
+    int* seg_start = seg + 2;
+    int* long_list = seg + R + 4;
+    const int tid = threadIdx.x;
+    const int CH = (R + 1023) / 1024, i0 = min(R, tid * CH), i1 = min(R, i0 + CH);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += (i == 0 || ids[perm[i]] != ids[perm[i - 1]]) ? 1 : 0;
+    int n_seg;
+    int k = block_excl_scan_1024(cnt, wsum, &n_seg);
+    for (int i = i0; i < i1; ++i)
+        if (i == 0 || ids[perm[i]] != ids[perm[i - 1]]) seg_start[k++] = i;
+    if (tid == 0) { seg_start[n_seg] = R; seg[0] = n_seg; }
+    __threadfence_block();
+    __syncthreads();
+    const int CH2 = (n_seg + 1023) / 1024, k0 = min(n_seg, tid * CH2), k1 = min(n_seg, k0 + CH2);
+    int cl = 0;
+    for (int q = k0; q < k1; ++q) cl += (seg_start[q + 1] - seg_start[q] > 32) ? 1 : 0;
+    int n_long;
+    int o = block_excl_scan_1024(cl, wsum, &n_long);
+    for (int q = k0; q < k1; ++q)
+        if (seg_start[q + 1] - seg_start[q] > 32) long_list[o++] = q;
+    if (tid == 0) seg[1] = n_long;
+}
+// short segments (<= 32 rows: almost all): one WAVE per segment, lanes over the columns, rows in order, 4 loads in flight
+__global__ __launch_bounds__(256) void k_emb_grad_short(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                        const float* __restrict__ gamma, const int64_t* __restrict__ ids,
+                                                        const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= seg[0]) return;
+    const int start = seg[2 + k], len = seg[2 + k + 1] - start;
+    if (len > 32) return;
+    const int* rows = perm + start;
+    const int64_t id = ids[rows[0]];
+    for (int sub = lane; sub < dim; sub += 64) {
+        float a = 0.f;
+        int m = 0;
+        for (; m + 4 <= len; m += 4) {
+            float x[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a += x[u];
-            }
-            for (; m < len; ++m) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
-            if (cok) table_grad[(size_t)id * dim + sub] = a * gamma[c0 + sub];
+            for (int u = 0; u < 4; ++u) x[u] = dxs[(size_t)rows[m + u] * F + c0 + sub];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a += x[u];
         }
-        return;
+        for (; m < len; ++m) a += dxs[(size_t)rows[m] * F + c0 + sub];
+        table_grad[(size_t)id * dim + sub] = a * gamma[c0 + sub];
     }
+}
+// long segments (popular articles sit in hundreds to thousands of a batch's rows): one workgroup of 16 waves = (16 / column blocks) row
+// stripes x column blocks of 64; stripe s takes rows s, s + S, ... in order, the stripe sums are added in stripe order.
+__global__ __launch_bounds__(1024) void k_emb_grad_long(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                        const float* __restrict__ gamma, const int64_t* __restrict__ ids,
+                                                        const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
+    constexpr int NW = 16;
+    __shared__ float part[NW][64];
+    if ((int)blockIdx.x >= seg[1]) return;
+    const int k = seg[R + 4 + blockIdx.x];
+    const int start = seg[2 + k], len = seg[2 + k + 1] - start;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int* rows = perm + start;
+    const int64_t id = ids[rows[0]];
+    const int ncb = (dim + 63) / 64;                      // column blocks of 64 (dim <= 512)
     const int ncb2 = ncb <= 1 ? 1 : (ncb <= 2 ? 2 : (ncb <= 4 ? 4 : 8)), S = NW / ncb2;      // wave w = stripe * ncb2 + column block
     const int cb = w % ncb2, stripe = w / ncb2;
     const int sub = cb * 64 + lane;
@@ -516,8 +553,9 @@ extern "C" int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int di
 }
 
 extern "C" size_t cham_group_rows_workspace_bytes(int R) { return R > 0 ? (size_t)R * sizeof(int) : 0; }
-extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!ids || !perm || !workspace || R <= 0 || R >= (1 << 20) || workspace_bytes < cham_group_rows_workspace_bytes(R))
+extern "C" size_t cham_group_rows_segments_len(int R) { return R > 0 ? (size_t)R + 4 + (size_t)R / 33 + 4 : 0; }      // int32 elements of `seg`
+extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ids || !perm || !seg || !workspace || R <= 0 || R >= (1 << 20) || workspace_bytes < cham_group_rows_workspace_bytes(R))
         return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int* rank = reinterpret_cast<int*>(workspace);
@@ -527,16 +565,17 @@ extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* w
     const int ns = (R + span - 1) / span;
     hipLaunchKernelGGL(k_rank_keys, dim3((R + 255) / 256, ns), dim3(256), 0, st, ids, R, span, rank);
     hipLaunchKernelGGL(k_perm_from_rank, dim3((R + 255) / 256), dim3(256), 0, st, rank, R, perm);
+    hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(1024), 0, st, ids, perm, R, seg);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
 
 extern "C" int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
-                                     const int32_t* perm, float* table_grad, void* stream) {
-    if (!dxs || !gamma || !ids || !perm || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 512 || c0 + dim > F)
+                                     const int32_t* perm, const int32_t* seg, float* table_grad, void* stream) {
+    if (!dxs || !gamma || !ids || !perm || !seg || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 512 || c0 + dim > F)
         return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_emb_grad_grouped<64>, dim3(R), dim3(64), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, table_grad);
-    hipLaunchKernelGGL(k_emb_grad_grouped<1024>, dim3(R), dim3(1024), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, table_grad);
+    hipLaunchKernelGGL(k_emb_grad_short, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, seg, table_grad);
+    hipLaunchKernelGGL(k_emb_grad_long, dim3(R / 33 + 1), dim3(1024), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, seg, table_grad);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -134,13 +134,33 @@ class Estimator:
             self._store['runtime'].load_state_dict(sd)
 
     def save_checkpoint(self):
+        """Checkpoint of the runtime in model_dir.  Under data parallelism state_dict() is a COLLECTIVE in the sharded / hybrid modes (it
+        all-gathers the Adam slots their owner ranks hold): every rank calls it at the same step (see _checkpoint_due), rank 0 alone
+        writes the file."""
         p = self._ckpt_path()
         rt = self._store.get('runtime')
         if p and rt is not None:
-            tmp = p + ".tmp"
-            torch.save(rt.state_dict(), tmp)
-            os.replace(tmp, p)
+            sd = rt.state_dict()
+            if getattr(rt, 'dp_rank', 0) == 0:
+                tmp = p + ".tmp"
+                torch.save(sd, tmp)
+                os.replace(tmp, p)
             self._last_ckpt_time = time.time()
+
+    def _checkpoint_due(self):
+        """save_checkpoints_secs elapsed?  A per-rank wall-clock decision would let ranks enter save_checkpoint() - a collective under the
+        sharded / hybrid exchange modes - at different steps (hang, or a gather paired with the next step's reduce-scatter): with an active
+        data-parallel group rank 0 decides and broadcasts."""
+        secs = self.config.save_checkpoints_secs
+        due = bool(secs) and time.time() - self._last_ckpt_time > secs
+        rt = self._store.get('runtime')
+        if rt is not None and getattr(rt, 'dp_active', False):
+            import torch.distributed as dist
+            if dist.is_initialized():
+                flag = torch.tensor([1 if due else 0], dtype=torch.int32, device=rt.device if dist.get_backend() == "nccl" else "cpu")
+                dist.broadcast(flag, src=0)
+                due = bool(int(flag.item()))
+        return due
 
     def get_variable_value(self, name):
         return self._store['runtime'].logical_weights()[name]
@@ -202,7 +222,7 @@ class Estimator:
                 self.steps_per_sec = n / dt
                 print("INFO:global_step/sec: %.4g (step %d)" % (n / dt, self.global_step), flush=True)
                 last_log = n
-            if self.config.save_checkpoints_secs and time.time() - self._last_ckpt_time > self.config.save_checkpoints_secs:
+            if self.config.save_checkpoints_secs and self._checkpoint_due():
                 self.save_checkpoint()
         torch.cuda.synchronize()
         if n:

@@ -35,8 +35,21 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _raw_device = getattr(torch._C, '_cuda_getDevice', None)
 
 
+_raw_checked = False
+
+
 def _stream():
+    global _raw_stream, _raw_checked
     if _raw_stream is not None and _raw_device is not None:
+        if not _raw_checked:       # private torch API: validate it once against the public one (a changed signature / meaning -> fall back)
+            _raw_checked = True
+            try:
+                if int(_raw_stream(_raw_device())) != int(torch.cuda.current_stream().cuda_stream):
+                    _raw_stream = None
+            except Exception:
+                _raw_stream = None
+            if _raw_stream is None:
+                return torch.cuda.current_stream().cuda_stream
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
@@ -489,6 +502,7 @@ class StepPlan:
         self.stat_scratch = f32(3 * max(1, int(rt.params['recent_clicks_for_normalization'])))
         self.w_rows = f32(RV)
         self.perm = torch.zeros(RV, dtype=torch.int32, device=dev)          # item rows grouped by id (cham_group_rows)
+        self.seg = torch.zeros(int(rt.lib.cham_group_rows_segments_len(RV)), dtype=torch.int32, device=dev)      # its segment table
         self.group_ws = torch.zeros(RV, dtype=torch.int32, device=dev)
         self.Xc_raw, self.Xc_s, self.dXc = f32(BT, Fc), f32(BT, Fc), f32(BT, Fc)
         self.Xi_raw, self.Xi_s, self.dXi = f32(RV, Fi), f32(RV, Fi), f32(RV, Fi)
@@ -847,7 +861,10 @@ class NARModuleModel:
         pl.ref_ts[:BT].copy_(d['ets_rows'])
         pl.ref_ts[BT:RV].fill_(d['max_ts'])
         if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
-            check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.group_ws), pl.group_ws.numel() * 4, s), "cham_group_rows")
+            if RV >= (1 << 20):
+                raise ValueError("%d item rows in one step (2 * positions + candidate pool + 1): the row grouping of the embedding gradient takes "
+                                 "fewer than 2^20 - process the batch with train_step_microbatched(features, labels, micro_sessions)" % RV)
+            check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s), "cham_group_rows")
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
         if st['n_last'] > 0 and st.get('device'):
@@ -1274,7 +1291,7 @@ class NARModuleModel:
             for kind, feat, c0, dim, card, off in rt.item_emb_groups:
                 if kind == COL_ITEMEMB:
                     check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')), ptr(pl.ids_all), ptr(pl.perm),
-                                                    rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_grouped")
+                                                    ptr(pl.seg), rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_grouped")
                 else:
                     check(lib.cham_emb_grad_scan(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')),
                                                  rt.meta_cat.data_ptr() + 8 * feat * rt.n_items, ptr(pl.ids_all), card,

@@ -87,13 +87,17 @@ int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* d
  *  - cham_emb_grad_scan: small tables (context / metadata embeddings), one workgroup per table row scanning the R source keys;
  *    key(r) = keysrc[r] (ids == NULL) or keysrc[ids[r]] (article metadata of item rows);
  *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows ranks the rows by (id, row) (depends on the
- *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key; ids >= 0, R < 2^20, dim <= 512. */
+ *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key, and builds the segment table `seg`
+ *    (cham_group_rows_segments_len(R) int32: number of segments, number of segments longer than 32 rows, first sorted position of every
+ *    segment, the indices of the long ones); cham_emb_grad_grouped then runs one wave per short segment and one 16-wave workgroup per
+ *    long one, rows in ascending order; ids >= 0, R < 2^20, dim <= 512. */
 int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
                        const int64_t* ids, int cardinality, float* table_grad, void* stream);
 size_t cham_group_rows_workspace_bytes(int R);
-int cham_group_rows(const int64_t* ids, int R, int32_t* perm, void* workspace, size_t workspace_bytes, void* stream);
+size_t cham_group_rows_segments_len(int R);
+int cham_group_rows(const int64_t* ids, int R, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes, void* stream);
 int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
-                          const int32_t* perm, float* table_grad, void* stream);
+                          const int32_t* perm, const int32_t* seg, float* table_grad, void* stream);
 
 /* --- dropout (dropout_keep_prob < 1): tf.layers.dropout at nar_model.py:338, 352, 368, 418 and DropoutWrapper(output_keep_prob) at
  * :1331.  y = x / keep_prob * mask (TF 1.12 tf.nn.dropout); the mask is a pure function of the element's coordinates:

@@ -30,16 +30,25 @@ def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     d_ids, d_dxs, d_gamma = torch.from_numpy(ids).to(gpu), torch.from_numpy(dxs).to(gpu), torch.from_numpy(gamma).to(gpu)
     perm = torch.full((R,), -1, dtype=torch.int32, device=gpu)
     ws = torch.zeros(lib.cham_group_rows_workspace_bytes(R) // 4, dtype=torch.int32, device=gpu)
-    check(lib.cham_group_rows(ptr(d_ids), R, ptr(perm), ptr(ws), ws.numel() * 4, _s()), "cham_group_rows")
+    seg = torch.full((int(lib.cham_group_rows_segments_len(R)),), -7, dtype=torch.int32, device=gpu)
+    check(lib.cham_group_rows(ptr(d_ids), R, ptr(perm), ptr(seg), ptr(ws), ws.numel() * 4, _s()), "cham_group_rows")
     torch.cuda.synchronize()
     pm = perm.cpu().numpy()
     assert np.array_equal(np.sort(pm), np.arange(R)), "perm is not a permutation"
     key = ids[pm] * (1 << 20) + pm
     assert (np.diff(key) > 0).all(), "rows are not sorted by (id, row)"
+    # segment table: heads of the runs of equal ids in sorted order, the long ones listed
+    sg = seg.cpu().numpy()
+    sid = ids[pm]
+    heads = np.flatnonzero(np.r_[True, sid[1:] != sid[:-1]])
+    assert sg[0] == len(heads) and np.array_equal(sg[2:2 + len(heads)], heads) and sg[2 + len(heads)] == R
+    lens = np.diff(np.r_[heads, R])
+    longs = np.flatnonzero(lens > 32)
+    assert sg[1] == len(longs) and np.array_equal(sg[R + 4:R + 4 + len(longs)], longs)
     outs = []
     for _ in range(2):
         table = torch.zeros(n_items * dim if n_items <= 50000 else int(uniq.max() + 1) * dim, device=gpu)
-        check(lib.cham_emb_grad_grouped(ptr(d_dxs), R, F, c0, dim, ptr(d_gamma), ptr(d_ids), ptr(perm), ptr(table), _s()), "grouped")
+        check(lib.cham_emb_grad_grouped(ptr(d_dxs), R, F, c0, dim, ptr(d_gamma), ptr(d_ids), ptr(perm), ptr(seg), ptr(table), _s()), "grouped")
         torch.cuda.synchronize()
         outs.append(table.cpu())
     assert torch.equal(outs[0], outs[1]), "not bit-reproducible"
