@@ -318,6 +318,12 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: until it is printed, file descriptor 1 points at stderr, so that nothing a library
+    # writes at C level (librccl prints a version banner through stdio when a communicator is created) can end up next to it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from chameleon_recsys_amd.nar import synthetic
@@ -610,7 +616,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)
+        if world > 1:
+            dist.barrier()
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)          # C stdio buffers (RCCL banner) leave through the redirected descriptor
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 

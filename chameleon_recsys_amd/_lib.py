@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cham_score_softmax_bwd_b16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, c_float, P, P, P, P, P]),
     "cham_colsum_b16": (c_int, [P, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
     "cham_cast_b16": (c_int, [P, c_int, c_int, P, P, P]),
+    "cham_upcast_b16": (c_int, [P, c_size_t, P, P]),
     "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_ugrnn_point_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),

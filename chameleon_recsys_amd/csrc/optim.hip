@@ -221,6 +221,21 @@ extern "C" int cham_cast_b16(const float* W, int R, int Cc, void* dst, void* dst
     return CHAM_OK;
 }
 
+// bf16 -> fp32 copy of a contiguous array (n % 4 == 0): the bf16 configuration's dropout path hands the bf16-resident gradient of the
+// PreCAR output to the dense (fp32-storage) PreCAR backward.  Exact.
+__global__ __launch_bounds__(256) void k_upcast_b16(const __bf16* __restrict__ src, size_t n4, float* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(dst + 4 * i, ld4(src + 4 * i));
+}
+extern "C" int cham_upcast_b16(const void* src, size_t n, float* dst, void* stream) {
+    if (!src || !dst || (n & 3)) return -CHAM_ERR_ARG;
+    if (n == 0) return CHAM_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_upcast_b16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(src), n / 4, dst);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
 // ---- gradient accumulation over session micro-batches (large-catalog / large-batch configurations): the step's row
 // shards share the pool, the denominators and the weights, so their gradient buffers simply add up.
 __global__ __launch_bounds__(256) void k_accumulate(float* __restrict__ acc, const float* __restrict__ x, size_t n4, size_t n, int first) {

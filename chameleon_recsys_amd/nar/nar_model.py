@@ -140,6 +140,7 @@ class NARRuntime:
 
     def __init__(self, params, device='cuda:0', seed=42, weights=None):
         self.lib = _lib.load()
+        self._views = {}
         if not torch.cuda.is_available():
             raise _lib.ChameleonLibError("no ROCm device visible: the NAR step has no CPU path")
         self.device = torch.device(device)
@@ -276,8 +277,15 @@ class NARRuntime:
 
     # ---- views into the flat buffers
     def view(self, flat, name):
-        e = self.layout.entries[name]
-        return flat[e.offset:e.offset + int(np.prod(e.shape))].view(*e.shape)
+        """Tensor view of one logical tensor inside a flat buffer (cached per buffer: a step asks ~70 times)."""
+        cache = self._views.get(id(flat))
+        if cache is None or cache[0] is not flat:
+            cache = self._views[id(flat)] = (flat, {})
+        v = cache[1].get(name)
+        if v is None:
+            e = self.layout.entries[name]
+            v = cache[1][name] = flat[e.offset:e.offset + int(np.prod(e.shape))].view(*e.shape)
+        return v
 
     def p(self, name):
         return self.view(self.flat, name)
@@ -574,6 +582,8 @@ class StepPlan:
             self.rnn_drop = [f32(self.BT, L.Hp) for _ in range(L.L)]
             need = rt.lib.cham_combine_bwd_workspace_bytes(Fw, self.B * self.T, self.N, self.pmax)
             self.drop_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            if rt.b16:      # bf16 configuration: the dense PreCAR layer computes / consumes fp32 images of the bf16-resident candidate rows
+                self.Z1f, self.dZ1f = f32(self.Rall, L.C), f32(self.Rall, L.C)
 
     def cand_Z1(self, P=None):
         """Candidate rows of the PreCAR output of the last step as fp32 [P * NC, C] (tests): the fp32 matrix, or the sum of its planes."""
@@ -626,8 +636,6 @@ class NARModuleModel:
         self.is_training = (mode == ModeKeys.TRAIN)
         if self.is_training and not (0.0 < keep_prob <= 1.0):
             raise ValueError("dropout_keep_prob must be in (0, 1]")
-        if self.is_training and keep_prob != 1.0 and gemm_dtype == 'bf16':
-            raise NotImplementedError("dropout_keep_prob < 1.0 is built for the fp32 configuration only")
         self.mode = mode
         self.inputs, self.labels = inputs, labels
         self.lr, self.keep_prob = lr, keep_prob
@@ -961,7 +969,11 @@ class NARModuleModel:
         if rt.b16:
             # bf16 configuration: candidate-row matrices are bf16 in HBM, weights through their bf16 shadows (csrc/gemm_b16.hip)
             sh = rt.shadow
-            check(lib.cham_combine_fwd_b16(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1c), s), "cham_combine_fwd_b16")
+            if drop:      # dense PreCAR rows (masks differ per occurrence): bf16-rounded operands, fp32 out, stored as the bf16-resident Z1c
+                rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1f[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
+                check(lib.cham_cast_b16(pl.Z1f[BT:].data_ptr(), Rc, C, ptr(pl.Z1c), None, s), "cham_cast_b16")
+            else:
+                check(lib.cham_combine_fwd_b16(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1c), s), "cham_combine_fwd_b16")
             rt.gemm_b16(pl.Z1c, C, 0, sh['W2T'], C, 1, pl.Z2c, C, 0, Rc, C, C, bias=p('b2'), act=ACT_TANH)
             rt.join()
             check(lib.cham_mul_rows_b16(ptr(pl.Z2c), ptr(pl.pred), C, BT, NC, ptr(pl.Mc), s), "cham_mul_rows_b16")
@@ -1260,9 +1272,14 @@ class NARModuleModel:
             if drop:        # dense PreCAR backward: one weight gradient over all CAR rows, d(input rows) masked, then summed per
                 #             position / per item row by the same deterministic scatter as the factorised path (width Fc + Fi)
                 Fw = drop['Fw']
-                rt.gemm(pl.Xd, pl.dZ1, drop['gW1'], Fw, C, Rall, Fw, C, C, transA=1, splits=0)
-                rt.colsum(pl.dZ1, C, Rall, C, g('b1'))
-                rt.gemm(pl.dZ1, drop['W1'], pl.dXd, Rall, Fw, C, C, C, Fw, transB=1)
+                dZ1 = pl.dZ1
+                if b16:      # fp32 image of [clicked rows (fp32) ; candidate rows (bf16-resident)] for the dense PreCAR backward
+                    dZ1 = pl.dZ1f
+                    dZ1[:BT].copy_(pl.dZ1[:BT])
+                    check(lib.cham_upcast_b16(ptr(pl.dZ1c), Rc * C, dZ1[BT:].data_ptr(), st), "cham_upcast_b16")
+                rt.gemm(pl.Xd, dZ1, drop['gW1'], Fw, C, Rall, Fw, C, C, transA=1, splits=0)
+                rt.colsum(dZ1, C, Rall, C, g('b1'))
+                rt.gemm(dZ1, drop['W1'], pl.dXd, Rall, Fw, C, C, C, Fw, transB=1)
                 dropout(pl.dXd, pl.dXd, BT, Fw, Fw, 16, 16, 1, pos, Fc, Fc - L.f_ctx)
                 dropout(pl.dXd[BT:], pl.dXd[BT:], Rc, Fw, Fw, 17, 18, NC, pos, Fc, Fc - L.f_ctx)
                 check(lib.cham_combine_bwd(ptr(pl.dXd), Fw, BT, N, pmax, ptr(neg_slot), ptr(pl.dUx), ptr(pl.dVx), ptr(pl.drop_ws),

@@ -232,6 +232,8 @@ int cham_score_softmax_bwd_b16(const void* S3, int K3, const float* w4, const fl
 int cham_colsum_b16(const void* X, int ld, int R, int F, const float* w, float* out, int accumulate, float* workspace,
                     size_t workspace_bytes, void* stream);
 int cham_cast_b16(const float* W, int R, int Cc, void* dst, void* dstT, void* stream);
+/* dst[i] = (float)src[i] for a contiguous bf16 array of n elements (n % 4 == 0): the bf16 configuration with dropout_keep_prob < 1 */
+int cham_upcast_b16(const void* src, size_t n, float* dst, void* stream);
 
 /* --- K3 recurrent cell time steps: nar_model.py:1308-1361.
  * cell_kind 0 = UGRNN (tf.contrib.rnn.UGRNNCell, the reference's cell, :1317): xproj [B,T,2Hp] = x W_x + b (gate | candidate),

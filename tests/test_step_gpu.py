@@ -470,3 +470,50 @@ def test_step_parity_numerical_article_metadata(gpu):
     from chameleon_recsys_amd.nar.nar_model import NARRuntime
     with pytest.raises(ValueError):
         NARRuntime(bad)
+
+
+def test_step_parity_bf16_with_dropout(gpu):
+    """dropout_keep_prob < 1 in the bf16 configuration (nar_model.py:338, 352, 368, 418, 1331 x BASELINE configs[2] arithmetic): the dense
+    PreCAR layer on bf16-rounded operands, its candidate rows stored bf16.  Forward against the oracle that emulates the rounding with the
+    same counter-based masks (logits 4e-3, loss 1e-3); gradients as accurate against the FP32 oracle (same masks) as the emulation is
+    (the criterion of test_step_parity_bf16_compute_mode)."""
+    from oracle.nar_oracle import NAROracle
+    p = H.tiny_params(gemm_dtype='bf16', dropout_keep_prob=0.85, C=128, H=96, neg=9, batch_size=40)
+    batches = synthetic.make_batches(5, 40, 8, 1000, p['session_features_config'], length_dist='g1')
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=5)
+    assert model.rt.gemm_dtype == 'bf16' and model.keep_prob == 0.85
+    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    orc32 = NAROracle(p32, weights=orc.weights_numpy())
+    for f, l in batches[3:5]:
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        model.feed_state(pop, buf)
+        model.forward(model.upload_batch(f, l))
+        out = model.outputs_numpy()
+        grads = {}
+        for name, o in (("bf16", orc), ("f32", orc32)):
+            for v in o.w.values():
+                v.grad = None
+            o.global_step = model.rt.global_step
+            ref = o.forward(f, l, buf, pop, 'train')
+            if name == "bf16":
+                mask = ref['mask'].numpy()
+                assert np.array_equal(out['neg_items'], ref['neg_items'].numpy())
+                assert np.abs(out['logits'] - ref['logits'].detach().numpy())[mask].max() < 4e-3
+                assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 1e-3
+                dropped = float((ref['x_neg'].detach().numpy()[np.asarray(l['label_next_item']) != 0] == 0).mean())
+                assert dropped > 0.15 * 0.8, dropped
+            else:
+                assert abs(out['loss'][0] - float(ref['total_loss'].detach())) < 3e-2
+            ref['xe_loss'].backward()
+            grads[name] = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros_like(v.detach().numpy())) for k, v in o.w.items()}
+        model.backward()
+        torch.cuda.synchronize()
+        g = model.rt.logical_grads()
+        for k in g:
+            scale = max(1e-6, float(np.abs(grads["f32"][k]).max()))
+            e_hip = float(np.abs(g[k] - grads["f32"][k]).max())
+            e_emu = float(np.abs(grads["bf16"][k] - grads["f32"][k]).max())
+            assert e_hip < 3.0 * e_emu + 2e-2 * scale + 2e-5, (k, e_hip, e_emu, scale)
+        H.update_state(st, f, l)
+        model.rt.global_step += 1
