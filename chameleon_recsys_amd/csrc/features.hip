@@ -311,11 +311,21 @@ __global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ 
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < R) perm[rank[r]] = r;
 }
-// Segment table of the sorted row list (depends on the ids only: built in the forward pass next to `perm`): seg[0] = number of
-// segments, seg[1] = number of LONG segments (> 32 rows), seg[2 .. 2 + n_seg] = first sorted position of every segment (+ R as the
-// end marker), seg[R + 4 ..] = the indices of the long segments.  One workgroup, two block scans, ascending order everywhere.
-// (Round 2 launched one workgroup per SORTED POSITION, twice - 64 and 1024 threads - and let the non-heads exit: 400 k waves created to
-// run ~10 k segment sums, 1.08 ms for 71 MB at the config-5 size; profiles/r03_notes.md.)
+// Segment table of the sorted row list (depends on the ids only: built in the forward pass next to `perm`), int32 words:
+//   seg[0] = number of segments, seg[1] = number of LONG segments (> 32 rows), seg[2] = number of work items of the long segments
+//   (chunks of EMB_CHUNK rows); seg[4 ..] = first sorted position of every segment (+ R as the end marker); then the indices of the
+//   long segments; then the first work item of every long segment (+ end marker); then the partial sums of the work items (as floats).
+// One workgroup, block scans, ascending order everywhere.
+// (Round 2 launched one workgroup per SORTED POSITION, twice, and let the non-heads exit, and a popular article's rows - Zipf ids: the
+// top item holds ~12 % of a micro-batch's 23 k rows at the config-5 size - were summed by ONE workgroup in two stripes of dependent
+// index -> row loads: 1.08 ms for 71 MB.  Now: one wave per short segment; long segments cut into chunks of 128 rows, one workgroup
+// per chunk, the chunk sums added in chunk order.  profiles/r03_notes.md)
+#define EMB_CHUNK 128
+__host__ __device__ inline int seg_nl(int R) { return R / 33 + 2; }                       // capacity of the long-segment list
+__host__ __device__ inline int seg_nw(int R) { return R / 33 + R / EMB_CHUNK + 4; }       // capacity of the work list
+__host__ __device__ inline size_t seg_off_long(int R) { return (size_t)R + 6; }
+__host__ __device__ inline size_t seg_off_work(int R) { return seg_off_long(R) + seg_nl(R); }
+__host__ __device__ inline size_t seg_off_partial(int R) { return (seg_off_work(R) + seg_nl(R) + 1 + 3) & ~(size_t)3; }
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* wsum /*[16]*/, int* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int incl = v;
@@ -331,8 +341,9 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* wsum /*[16]*/, i
 }
 __global__ __launch_bounds__(1024) void k_seg_table(const int64_t* __restrict__ ids, const int* __restrict__ perm, int R, int* __restrict__ seg) {
     __shared__ int wsum[16];
-    int* seg_start = seg + 2;
-    int* long_list = seg + R + 4;
+    int* seg_start = seg + 4;
+    int* long_list = seg + seg_off_long(R);
+    int* work_first = seg + seg_off_work(R);
     const int tid = threadIdx.x;
     const int CH = (R + 1023) / 1024, i0 = min(R, tid * CH), i1 = min(R, i0 + CH);
     int cnt = 0;
@@ -345,13 +356,19 @@ __global__ __launch_bounds__(1024) void k_seg_table(const int64_t* __restrict__ 
     __threadfence_block();
     __syncthreads();
     const int CH2 = (n_seg + 1023) / 1024, k0 = min(n_seg, tid * CH2), k1 = min(n_seg, k0 + CH2);
-    int cl = 0;
-    for (int q = k0; q < k1; ++q) cl += (seg_start[q + 1] - seg_start[q] > 32) ? 1 : 0;
-    int n_long;
+    int cl = 0, cw = 0;
+    for (int q = k0; q < k1; ++q) {
+        const int len = seg_start[q + 1] - seg_start[q];
+        if (len > 32) { ++cl; cw += (len + EMB_CHUNK - 1) / EMB_CHUNK; }
+    }
+    int n_long, n_work;
     int o = block_excl_scan_1024(cl, wsum, &n_long);
-    for (int q = k0; q < k1; ++q)
-        if (seg_start[q + 1] - seg_start[q] > 32) long_list[o++] = q;
-    if (tid == 0) seg[1] = n_long;
+    int ow = block_excl_scan_1024(cw, wsum, &n_work);
+    for (int q = k0; q < k1; ++q) {
+        const int len = seg_start[q + 1] - seg_start[q];
+        if (len > 32) { long_list[o] = q; work_first[o] = ow; ++o; ow += (len + EMB_CHUNK - 1) / EMB_CHUNK; }
+    }
+    if (tid == 0) { seg[1] = n_long; seg[2] = n_work; work_first[n_long] = n_work; }
 }
 // short segments (<= 32 rows: almost all): one WAVE per segment, lanes over the columns, rows in order, 4 loads in flight
 __global__ __launch_bounds__(256) void k_emb_grad_short(const float* __restrict__ dxs, int R, int F, int c0, int dim,
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256) void k_emb_grad_short(const float* __restrict_
                                                         const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= seg[0]) return;
-    const int start = seg[2 + k], len = seg[2 + k + 1] - start;
+    const int start = seg[4 + k], len = seg[4 + k + 1] - start;
     if (len > 32) return;
     const int* rows = perm + start;
     const int64_t id = ids[rows[0]];
@@ -377,41 +394,49 @@ __global__ __launch_bounds__(256) void k_emb_grad_short(const float* __restrict_
         table_grad[(size_t)id * dim + sub] = a * gamma[c0 + sub];
     }
 }
-// long segments (popular articles sit in hundreds to thousands of a batch's rows): one workgroup of 16 waves = (16 / column blocks) row
-// stripes x column blocks of 64; stripe s takes rows s, s + S, ... in order, the stripe sums are added in stripe order.
-__global__ __launch_bounds__(1024) void k_emb_grad_long(const float* __restrict__ dxs, int R, int F, int c0, int dim,
-                                                        const float* __restrict__ gamma, const int64_t* __restrict__ ids,
-                                                        const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
-    constexpr int NW = 16;
-    __shared__ float part[NW][64];
-    if ((int)blockIdx.x >= seg[1]) return;
-    const int k = seg[R + 4 + blockIdx.x];
-    const int start = seg[2 + k], len = seg[2 + k + 1] - start;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int* rows = perm + start;
-    const int64_t id = ids[rows[0]];
-    const int ncb = (dim + 63) / 64;                      // column blocks of 64 (dim <= 512)
-    const int ncb2 = ncb <= 1 ? 1 : (ncb <= 2 ? 2 : (ncb <= 4 ? 4 : 8)), S = NW / ncb2;      // wave w = stripe * ncb2 + column block
-    const int cb = w % ncb2, stripe = w / ncb2;
-    const int sub = cb * 64 + lane;
-    const bool cok = cb < ncb && sub < dim;
-    float a = 0.f;
-    int m = stripe;
-    for (; m + 7 * S < len; m += 8 * S) {                 // 8 independent row loads in flight per wave
-        float x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = cok ? dxs[(size_t)rows[m + u * S] * F + c0 + sub] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a += x[u];
-    }
-    for (; m < len; m += S) a += cok ? dxs[(size_t)rows[m] * F + c0 + sub] : 0.f;
-    part[w][lane] = a;
+// long segments, pass 1: work item = EMB_CHUNK consecutive sorted rows of one long segment; thread = column, rows in order, 8 in flight
+__global__ __launch_bounds__(256) void k_emb_grad_long_part(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                            const int* __restrict__ perm, int* __restrict__ seg) {
+    __shared__ int rws[EMB_CHUNK];
+    const int wid = blockIdx.x;
+    if (wid >= seg[2]) return;
+    const int* work_first = seg + seg_off_work(R);
+    int lo = 0, hi = seg[1];                       // the long segment q with work_first[q] <= wid < work_first[q + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (work_first[mid] <= wid) lo = mid; else hi = mid; }
+    const int k = seg[seg_off_long(R) + lo];
+    const int start = seg[4 + k], len = seg[4 + k + 1] - start;
+    const int r0 = (wid - work_first[lo]) * EMB_CHUNK, n = min(EMB_CHUNK, len - r0);
+    for (int i = threadIdx.x; i < n; i += 256) rws[i] = perm[start + r0 + i];
     __syncthreads();
-    if (w < ncb) {                                        // wave w finishes column block w: stripe sums in stripe order
-        const int sub2 = w * 64 + lane;
+    float* partial = reinterpret_cast<float*>(seg + seg_off_partial(R)) + (size_t)wid * dim;
+    for (int sub = threadIdx.x; sub < dim; sub += 256) {
+        float a = 0.f;
+        int m = 0;
+        for (; m + 8 <= n; m += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = dxs[(size_t)rws[m + u] * F + c0 + sub];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += x[u];
+        }
+        for (; m < n; ++m) a += dxs[(size_t)rws[m] * F + c0 + sub];
+        partial[sub] = a;
+    }
+}
+// pass 2: the chunk sums of a long segment, in chunk order
+__global__ __launch_bounds__(256) void k_emb_grad_long_final(int R, int dim, int c0, const float* __restrict__ gamma, const int64_t* __restrict__ ids,
+                                                             const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
+    const int q = blockIdx.x;
+    if (q >= seg[1]) return;
+    const int* work_first = seg + seg_off_work(R);
+    const int k = seg[seg_off_long(R) + q];
+    const int64_t id = ids[perm[seg[4 + k]]];
+    const int w0 = work_first[q], w1 = work_first[q + 1];
+    const float* partial = reinterpret_cast<const float*>(seg + seg_off_partial(R));
+    for (int sub = threadIdx.x; sub < dim; sub += 256) {
         float t = 0.f;
-        for (int s2 = 0; s2 < S; ++s2) t += part[s2 * ncb2 + w][lane];
-        if (sub2 < dim) table_grad[(size_t)id * dim + sub2] = t * gamma[c0 + sub2];
+        for (int w = w0; w < w1; ++w) t += partial[(size_t)w * dim + sub];
+        table_grad[(size_t)id * dim + sub] = t * gamma[c0 + sub];
     }
 }
 
@@ -553,7 +578,9 @@ extern "C" int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int di
 }
 
 extern "C" size_t cham_group_rows_workspace_bytes(int R) { return R > 0 ? (size_t)R * sizeof(int) : 0; }
-extern "C" size_t cham_group_rows_segments_len(int R) { return R > 0 ? (size_t)R + 4 + (size_t)R / 33 + 4 : 0; }      // int32 elements of `seg`
+extern "C" size_t cham_group_rows_segments_len(int R) {      // int32 words of `seg` (the tail holds the chunk sums of the long segments, <= 512 columns)
+    return R > 0 ? seg_off_partial(R) + (size_t)seg_nw(R) * 512 : 0;
+}
 extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ids || !perm || !seg || !workspace || R <= 0 || R >= (1 << 20) || workspace_bytes < cham_group_rows_workspace_bytes(R))
         return -CHAM_ERR_ARG;
@@ -575,7 +602,8 @@ extern "C" int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int
     if (!dxs || !gamma || !ids || !perm || !seg || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 512 || c0 + dim > F)
         return -CHAM_ERR_ARG;
     hipLaunchKernelGGL(k_emb_grad_short, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, seg, table_grad);
-    hipLaunchKernelGGL(k_emb_grad_long, dim3(R / 33 + 1), dim3(1024), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, seg, table_grad);
+    hipLaunchKernelGGL(k_emb_grad_long_part, dim3(seg_nw(R)), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, perm, const_cast<int32_t*>(seg));
+    hipLaunchKernelGGL(k_emb_grad_long_final, dim3(seg_nl(R)), dim3(256), 0, (hipStream_t)stream, R, dim, c0, gamma, ids, perm, seg, table_grad);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

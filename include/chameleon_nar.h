@@ -88,9 +88,10 @@ int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* d
  *    key(r) = keysrc[r] (ids == NULL) or keysrc[ids[r]] (article metadata of item rows);
  *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows ranks the rows by (id, row) (depends on the
  *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key, and builds the segment table `seg`
- *    (cham_group_rows_segments_len(R) int32: number of segments, number of segments longer than 32 rows, first sorted position of every
- *    segment, the indices of the long ones); cham_emb_grad_grouped then runs one wave per short segment and one 16-wave workgroup per
- *    long one, rows in ascending order; ids >= 0, R < 2^20, dim <= 512. */
+ *    (cham_group_rows_segments_len(R) int32 words: number of segments, of segments longer than 32 rows and of their 128-row chunks,
+ *    first sorted position of every segment, the indices of the long ones, their first chunk, scratch for the chunk sums - the buffer
+ *    is written by cham_emb_grad_grouped too); cham_emb_grad_grouped then runs one wave per short segment, one workgroup per 128-row
+ *    chunk of a long one and adds the chunk sums in chunk order; rows in ascending order throughout; ids >= 0, R < 2^20, dim <= 512. */
 int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
                        const int64_t* ids, int cardinality, float* table_grad, void* stream);
 size_t cham_group_rows_workspace_bytes(int R);

@@ -41,10 +41,13 @@ def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     sg = seg.cpu().numpy()
     sid = ids[pm]
     heads = np.flatnonzero(np.r_[True, sid[1:] != sid[:-1]])
-    assert sg[0] == len(heads) and np.array_equal(sg[2:2 + len(heads)], heads) and sg[2 + len(heads)] == R
+    assert sg[0] == len(heads) and np.array_equal(sg[4:4 + len(heads)], heads) and sg[4 + len(heads)] == R
     lens = np.diff(np.r_[heads, R])
     longs = np.flatnonzero(lens > 32)
-    assert sg[1] == len(longs) and np.array_equal(sg[R + 4:R + 4 + len(longs)], longs)
+    assert sg[1] == len(longs) and np.array_equal(sg[R + 6:R + 6 + len(longs)], longs)
+    chunks = (lens[longs] + 127) // 128                              # work items: 128-row chunks of the long segments
+    wf = R + 6 + R // 33 + 2
+    assert sg[2] == chunks.sum() and np.array_equal(sg[wf:wf + len(longs) + 1], np.r_[0, np.cumsum(chunks)])
     outs = []
     for _ in range(2):
         table = torch.zeros(n_items * dim if n_items <= 50000 else int(uniq.max() + 1) * dim, device=gpu)
