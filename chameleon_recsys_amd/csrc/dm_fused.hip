@@ -29,8 +29,6 @@
 #define DMF_HALF (3 * DMF_PLANE)              // one half-stage: three planes
 #define DMF_RED_OFF (2 * DMF_HALF)            // [8 waves][2 slots][2 quantities][DMF_COLS columns] fp32
 #define DMF_RED_BYTES (8 * 4 * DMF_COLS * 4)
-#define DMF_AL_OFF (DMF_RED_OFF + DMF_RED_BYTES)      // the lowest plane of the waves' dS1 fragments: [8 waves][8 steps][64 lanes] x 16 B = 64 KB
-#define DMF_AL_BYTES (8 * 8 * 64 * 16)
 
 static_assert(DMF_NT == 2, "the epilogue packs exactly two tiles' columns per lane");
 
@@ -68,10 +66,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     // (every global access of this kernel goes through a buffer descriptor sized to the workgroup's valid rows: rows beyond them read
     // zeros / drop their stores without a branch - a branch around a load makes hipcc wait for each load in turn, 16 dependent HBM round
     // trips per column tile in the first version of this epilogue: 1.25 ms for the kernel, profiles/r03_notes.md)
-    // (the lowest plane - used by one of the six products - lives in LDS, wave-private and lane-linear: its 32 registers hold the
-    // prefetched Z2 rows of the column tile instead)
-    bf16x8 AH[8], AM[8];
-    unsigned char* ALs = dmf_smem + DMF_AL_OFF + (size_t)wave * 8192 + (size_t)lane * 16;
+    bf16x8 AH[8], AM[8], AL[8];
     {
         const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dS1 + row0 * (size_t)p.lds1), 0,
                                                                             (unsigned)((size_t)rows_valid * p.lds1 * 4), 0x00020000);
@@ -87,10 +82,8 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             const float v[8] = {__uint_as_float(x[2 * s].x), __uint_as_float(x[2 * s].y), __uint_as_float(x[2 * s].z), __uint_as_float(x[2 * s].w),
                                 __uint_as_float(x[2 * s + 1].x), __uint_as_float(x[2 * s + 1].y), __uint_as_float(x[2 * s + 1].z),
                                 __uint_as_float(x[2 * s + 1].w)};
-            bf16x8 al;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; al[e] = c; }
-            *reinterpret_cast<bf16x8*>(ALs + s * 1024) = al;
+            for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
         }
     }
     const __amdgpu_buffer_rsrc_t zw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z2c + row0 * (size_t)C), 0,
@@ -156,7 +149,6 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             bf16x8 bh[DMF_NT], bm[DMF_NT], bl[DMF_NT];
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ALs + (s0 + t) * 1024);
 #pragma unroll
             for (int j = 0; j < DMF_NT; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(S + fo[t] + j * 4096);
@@ -164,7 +156,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                 bl[j] = *reinterpret_cast<const bf16x8*>(S + 2 * DMF_PLANE + fo[t] + j * 4096);
             }
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[s0 + t], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
@@ -177,19 +169,9 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
         }
     };
-    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-    u32x2_t zz[16];
     for (int h = 0; h < nhalf; ++h) {
-        if (h & 1) {
-            // the Z2 rows of this column tile: sixteen loads in flight behind the 48 MFMAs below (rows beyond the valid ones: zeros)
-            const unsigned colz = (unsigned)((h >> 1) * DMF_COLS + DMF_NT * l31);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned r = (unsigned)(wr0 + (e & 3) + 8 * (e >> 2) + 4 * hh);
-                zz[e] = __builtin_amdgcn_raw_buffer_load_b64(zw, (r * (unsigned)C + colz) * 4u, 0, 0);
-            }
-            mfma_half(std::integral_constant<int, 1>{});
-        } else mfma_half(std::integral_constant<int, 0>{});
+        if (h & 1) mfma_half(std::integral_constant<int, 1>{});
+        else mfma_half(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         // this wave's requests for half-stage h + 1 (issued a half-stage ago) have landed; nothing else of its is in flight except
         // the previous tile's stores
@@ -201,6 +183,13 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             if (pa < npos) pra = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa) * C + col);
             if (pa + 1 < npos) prb = *reinterpret_cast<const float2*>(p.pred + (size_t)(pos0 + pa + 1) * C + col);
             float2 sa = make_float2(0.f, 0.f), sb = sa, ca = sa, cb = sa;
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t zz[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {      // all sixteen row loads in flight at once (rows beyond the valid ones: zeros)
+                const unsigned r = (unsigned)(wr0 + (e & 3) + 8 * (e >> 2) + 4 * hh);
+                zz[e] = __builtin_amdgcn_raw_buffer_load_b64(zw, (r * (unsigned)C + (unsigned)col) * 4u, 0, 0);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * hh;           // row relative to the wave's first row
@@ -245,23 +234,19 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
         if (h & 1) {
             // ---- per-position column sums of this column tile: thread (position, column) adds the waves in ascending order
             const float* redw = reinterpret_cast<const float*>(dmf_smem + DMF_RED_OFF);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = threadIdx.x + 512 * u;
-                if (idx < npos * DMF_COLS) {
-                    const int pl = idx / DMF_COLS, c = idx % DMF_COLS;
-                    float s = 0.f, cs = 0.f;
-                    const int w_lo = (pl * NC) >> 5, w_hi = min(7, ((pl + 1) * NC - 1) >> 5);
-                    for (int w = w_lo; w <= w_hi; ++w) {
-                        const int slot = (pl == (32 * w) / NC) ? 0 : 1;
-                        s += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + c];
-                        cs += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + DMF_COLS + c];
-                    }
-                    const int colg = (h >> 1) * DMF_COLS + c;
-                    const float pr = p.pred[(size_t)(pos0 + pl) * C + colg];
-                    p.dpred[(size_t)(pos0 + pl) * C + colg] = s * (1.f - pr * pr);
-                    if (p.b2part) p.b2part[(size_t)(pos0 + pl) * C + colg] = cs;
+            for (int idx = threadIdx.x; idx < npos * DMF_COLS; idx += 512) {
+                const int pl = idx / DMF_COLS, c = idx % DMF_COLS;
+                float s = 0.f, cs = 0.f;
+                const int w_lo = (pl * NC) >> 5, w_hi = min(7, ((pl + 1) * NC - 1) >> 5);
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const int slot = (pl == (32 * w) / NC) ? 0 : 1;
+                    s += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + c];
+                    cs += redw[(size_t)w * (4 * DMF_COLS) + slot * (2 * DMF_COLS) + DMF_COLS + c];
                 }
+                const int colg = (h >> 1) * DMF_COLS + c;
+                const float pr = p.pred[(size_t)(pos0 + pl) * C + colg];
+                p.dpred[(size_t)(pos0 + pl) * C + colg] = s * (1.f - pr * pr);
+                if (p.b2part) p.b2part[(size_t)(pos0 + pl) * C + colg] = cs;
             }
             // (the next epilogue writes `red` again only after the next two barriers)
         }
@@ -289,7 +274,7 @@ extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void*
     p.dS1 = dS1; p.lds1 = lds1; p.W = reinterpret_cast<const __bf16*>(Wp); p.w_ps = w_plane_stride; p.Z2c = Z2c; p.pred = pred;
     p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.dpred = dpred_pre; p.b2part = col_part;
     p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
-    constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES + DMF_AL_BYTES;
+    constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dm_mulpred_fused), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
