@@ -534,7 +534,7 @@ def main():
     # i.e. every GEMM on v_mfma_f32_32x32x2_f32 - so the line carries both arms measured in one run
     native_arm = None
     if args.dtype == "f32" and getattr(rt, 'x3', False) and not args.no_native_arm:
-        rt.x3 = False
+        had_p3, rt.x3, rt.p3 = rt.p3, False, False       # p3 off as well: the plane-resident CAR GEMMs are plane products too
         n_arm = max(5, min(args.steps, 10))
         for i in range(3):
             one_step(args.warmup + args.steps + 200 + i)
@@ -544,7 +544,7 @@ def main():
             one_step(args.warmup + args.steps + 203 + i)
         barrier()
         adt = time.perf_counter() - t0
-        rt.x3 = True
+        rt.x3, rt.p3 = True, had_p3
         if world > 1:
             tt = torch.tensor([adt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -530,7 +530,7 @@ extern "C" int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, co
         if (want > maxk) want = maxk;
         const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));
         if (want > maxw) want = maxw;
-        if (want >= 8) want = want / 8 * 8;
+        if (splits_hint <= 0 && want >= 8) want = want / 8 * 8;      // an explicit count is taken as given (e.g. 14 x 16 tiles = 224 workgroups: one round that leaves 32 CUs to the kernels of the other lane)
         if (want > 1) splits = (int)want;
     }
     int kchunk = (K + splits - 1) / splits;

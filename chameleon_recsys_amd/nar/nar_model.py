@@ -100,6 +100,10 @@ class variable_store:
         _VARIABLE_STORE = self._prev
 
 
+_TORCH_DTYPE = {np.dtype(n).str: t for n, t in (('int64', torch.int64), ('int32', torch.int32), ('float32', torch.float32),
+                                                   ('uint8', torch.uint8))}
+
+
 class _PinnedRing:
     """Page-locked staging buffers for the per-step host -> device copies: a batch's arrays are packed into one
     pinned arena and copied with truly asynchronous DMA (a copy from pageable memory goes through the driver's bounce buffer and
@@ -747,21 +751,6 @@ class NARModuleModel:
             else np.zeros((1, B * T), np.int64)
         num = np.stack([np.asarray(features[n], np.float32).reshape(-1) for n in L.ctx_num_names]) if L.ctx_num_names \
             else np.zeros((1, B * T), np.float32)
-        # H2D copies on their own stream: queued behind the running step's kernels on the compute stream, a copy from pageable
-        # host memory blocks the host until that step has finished (one implicit synchronisation per step)
-        main, up, ring = torch.cuda.current_stream(), self.rt.upload_stream, self.rt.pinned
-        if ring is not None:                  # page-locked staging arena for this batch's arrays (sized generously: ~3x the inputs)
-            ring.begin(256 * 40 + 3 * 8 * (aci.size + 3 * B * T + (len(L.ctx_cat_names) + len(L.ctx_num_names) + 2) * B * T))
-
-        def t(a):
-            a = np.ascontiguousarray(a)
-            x = ring.stage(a) if ring is not None else torch.from_numpy(a)
-            if up is None:
-                return x.to(dev, non_blocking=True)
-            with torch.cuda.stream(up):
-                x = x.to(dev, non_blocking=True)
-            x.record_stream(main)             # allocated on the upload stream, consumed on the compute stream
-            return x
         g_ets = ets if global_features is None else np.ascontiguousarray(gf['event_timestamp'], dtype=np.int64)
         label_next = np.ascontiguousarray(labels['label_next_item'], dtype=np.int64)
         # Valid-position compaction.  The reference computes every padded (session, time) position and multiplies it
@@ -772,20 +761,62 @@ class NARModuleModel:
         mrows = mask.reshape(-1)
         pos = np.flatnonzero(mrows).astype(np.int32)
         P = int(pos.shape[0])
-        d = dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts,
-                 g_event_ts=t(g_ets), aci=t(aci), item_clicked=t(item_clicked), label_next=t(label_next),
-                 event_ts=t(ets), seq_len=t(seq_len))
-        if self.rt.compact and 0 < P < B * T:
-            d.update(P=P, pos=t(pos), ic_rows=t(item_clicked.reshape(-1)[pos]), ln_rows=t(label_next.reshape(-1)[pos]),
-                     ets_rows=t(ets.reshape(-1)[pos]), mask=t(np.ones(P, np.uint8)), cat=t(cat[:, pos]), num=t(num[:, pos]))
+        host = dict(g_event_ts=g_ets, aci=aci, item_clicked=item_clicked, label_next=label_next, event_ts=ets, seq_len=seq_len)
+        compacted = self.rt.compact and 0 < P < B * T
+        if compacted:
+            host.update(pos=pos, ic_rows=item_clicked.reshape(-1)[pos], ln_rows=label_next.reshape(-1)[pos], ets_rows=ets.reshape(-1)[pos],
+                        mask=np.ones(P, np.uint8), cat=cat[:, pos], num=num[:, pos])
         else:
-            d.update(P=B * T, pos=None, ic_rows=d['item_clicked'].view(-1), ln_rows=d['label_next'].view(-1),
-                     ets_rows=d['event_ts'].view(-1), mask=t(mrows.astype(np.uint8)), cat=t(cat), num=t(num))
-        d['uploaded'] = torch.cuda.Event()
-        d['uploaded'].record(up if up is not None else main)      # consumers (forward, presample) wait for exactly the copies above
+            host.update(mask=mrows.astype(np.uint8), cat=cat, num=num)
+        d = dict(B=B, T=T, Bg=aci.shape[0], row_begin=row_begin, sum_mask=sum_mask, max_ts=max_ts, P=P if compacted else B * T, pos=None)
+        d.update(self._h2d(host))
+        if not compacted:
+            d.update(ic_rows=d['item_clicked'].view(-1), ln_rows=d['label_next'].view(-1), ets_rows=d['event_ts'].view(-1))
+        return d
+
+    def _h2d(self, host):
+        """The batch's arrays -> device tensors + the 'uploaded' event its consumers (forward, presample) wait for.  The copies
+        run on their own stream: queued behind the running step's kernels on the compute stream, a copy from pageable host
+        memory would block the host until that step has finished (one implicit synchronisation per step).  With the pinned
+        ring (default) the arrays are packed into ONE page-locked arena and cross in ONE copy into one device block the
+        returned tensors are views of (13 copies, allocations and stream records fewer per step on the host)."""
+        dev = self.rt.device
+        main, up, ring = torch.cuda.current_stream(), self.rt.upload_stream, self.rt.pinned
+        arrs = {k: np.ascontiguousarray(a) for k, a in host.items()}
+        out = {}
+        if ring is not None:
+            offs, total = {}, 0
+            for k, a in arrs.items():
+                offs[k] = total
+                total += (a.nbytes + 255) & ~255
+            ring.begin(total)
+            arena = ring.bufs[ring.k]
+            bytes_view = arena.numpy()
+            for k, a in arrs.items():
+                if a.nbytes:
+                    bytes_view[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)
+            with torch.cuda.stream(up if up is not None else main):
+                block = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+                block[:total].copy_(arena[:total], non_blocking=True)
+            if up is not None:
+                block.record_stream(main)         # allocated on the upload stream, consumed on the compute stream
+            for k, a in arrs.items():
+                out[k] = block[offs[k]:offs[k] + a.nbytes].view(_TORCH_DTYPE[a.dtype.str]).view(a.shape)
+        else:
+            for k, a in arrs.items():
+                x = torch.from_numpy(a)
+                if up is None:
+                    out[k] = x.to(dev, non_blocking=True)
+                    continue
+                with torch.cuda.stream(up):
+                    x = x.to(dev, non_blocking=True)
+                x.record_stream(main)
+                out[k] = x
+        out['uploaded'] = torch.cuda.Event()
+        out['uploaded'].record(up if up is not None else main)
         if ring is not None:
             ring.end(up if up is not None else main)
-        return d
+        return out
 
     def _neg_sample(self, pl, d, step, k, stream):
         """K0 negative sampling (nar_model.py:265-276) of batch d with key `step` into the plan's sampler-output set k."""
