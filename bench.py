@@ -89,6 +89,8 @@ def gemm_symbol(r):
     if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
         return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    if r.get('b1'):       # bf16-resident operands on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel)
+        return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
         return "k_dm_mulpred_fused(DmfParams)"
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
@@ -168,7 +170,8 @@ def dp_self_exchange(rt):
     return out
 
 
-EPI_NAMES = {0: "plain", 1: "bias+leaky", 2: "bias+tanh", 3: "x leaky'", 4: "x tanh'", 5: "bias", 6: "split-K partials (+ reduce kernel)"}
+EPI_NAMES = {0: "plain", 1: "bias+leaky", 2: "bias+tanh", 3: "x leaky'", 4: "x tanh'", 5: "bias", 6: "split-K partials (+ reduce kernel)",
+             10: "plain -> bf16", 12: "bias+tanh -> bf16", 13: "x leaky' -> bf16"}
 
 
 def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, state="device", gemm_dtype="f32"):
@@ -451,7 +454,7 @@ def main():
         elif r.get('p3'):       # operands as three bf16 planes (6 B per element), fp32 output, the dgrad reads the activation's h plane
             e['bytes'] += 6.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
                 (4.0 * r['N'] if r['bias'] else 0)
-        elif r.get('b16'):
+        elif r.get('b16') or r.get('b1'):
             e['bytes'] += 2.0 * (r['M'] * r['K'] + r['K'] * r['N'] + (r['M'] * r['N'] if r['dref'] else 0)) + \
                 (4.0 if (r['out_f32'] or r['epi'] == 6) else 2.0) * r['M'] * r['N'] + (4.0 * r['N'] if r['bias'] else 0)
         else:
@@ -465,7 +468,7 @@ def main():
         mode = "NN" if not r['transA'] and not r['transB'] else ("TN (wgrad)" if r['transA'] else
                                                                  ("NT (dgrad)" if r['dref'] or not r['bias'] else "NT (forward, transposed weight shadow)"))
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
-            sym, ("bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else
+            sym, ("bf16-resident, LDS-DMA staging" if r.get('b1') else "bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else
             ("fp32-grade (operands resident in HBM as three bf16 planes written by their producers, six bf16 MFMA products per fp32 product, "
              "fp32 accumulate, LDS-DMA staging)" if r.get('p3') else
              "fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "cham_gemm_f32x3_launch_counts": (None, [P, c_int]),
     "cham_gemm_p3": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                              P, c_size_t, c_int, P]),
+    "cham_gemm_b16_dma": (c_int, [P, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_p3_launch_counts": (None, [P, c_int]),
     "cham_gemm_p3_set_variant": (None, [c_int]),
     "cham_split3": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P]),

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct P3Params {
     const __bf16* A; const __bf16* B;          // plane 0 of each operand
@@ -429,6 +430,227 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     }
 }
 
+// ================================================================================================================================
+// The bf16 configuration's CAR GEMMs on the same core: ONE bf16 plane per operand (the matrices the bf16 configuration keeps in HBM),
+// the three A slabs / three B slabs of a stage holding three CONSECUTIVE 16-k chunks, so a stage advances K by 48 and its three
+// passes are the "diagonal" products chunk q of A x chunk q of B: per stage and wave 24 MFMAs, 18 ds_read_b128, 6 DMA requests, one
+// barrier - nothing else in the K loop (gemm_b16.hip stages through registers: 0.26-0.32 of the bf16 matrix peak).
+//   step i:  top   DMA of stage i + 2
+//            P0    A0 x B0 | fragment reads of chunk 1 (this stage)
+//            P1    A1 x B1 | fragment reads of chunk 2
+//            mid   s_waitcnt vmcnt(6) (stage i + 1 landed) + s_barrier
+//            P2    A2 x B2 | fragment reads of chunk 0 of stage i + 1
+//   K tail (K % 48 != 0): NT operands are k-contiguous, a chunk past K would read the row's neighbours - the requests of such a
+//   chunk go out with a zero-sized descriptor (every lane out of range: zeros land in LDS); TN: the k-rows past the split's end are
+//   beyond the descriptor's range anyway.
+//   NT runs the MFMAs with swapped operands (accumulator = C^T: a lane owns four consecutive output columns of its row), so the
+//   bf16 epilogues load / store 8 bytes per access (as gemm_b16.hip); TN keeps the shared split-K partial epilogue.
+// EPI: NT 12 = + bias -> tanh -> bf16, 13 = x leaky'(saved bf16 activation) -> bf16, 10 = plain -> bf16;  TN 6 = split-K partial, 0 = fp32.
+__device__ __forceinline__ float b1_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float b1_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned b1_pack(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;           // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool TN, int EPI>
+__global__ __launch_bounds__(512) void gemm_b1_kernel(P3Params p) {
+    constexpr int BM = 256, BN = 256, KS = 48, TM = 4, TNN = 2;
+    constexpr bool SWAP = !TN;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
+
+    const int nwg = p.nbm * p.nbn;
+    int tile_m, tile_n, split;
+    if (p.xcd_split) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+        split = (lin & 7) + 8 * (slot / nwg);
+        const int t = slot % nwg;
+        tile_m = t / p.nbn; tile_n = t % p.nbn;
+    } else {
+        const int id = blockIdx.x;
+        const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
+        const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
+        tile_m = swz / p.nbn; tile_n = swz % p.nbn;
+        split = blockIdx.y;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int klen = max(kend - kbeg, 0);
+    const int nk = (klen + KS - 1) / KS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+    // ---- one descriptor per 16-k chunk of a stage
+    u32x4 ra[3], rb[3];
+    unsigned va, vb, stepa, stepb;
+    if constexpr (!TN) {
+        const size_t abytes = (size_t)max(p.M - m0, 0) * p.lda * 2, bbytes = (size_t)max(p.N - n0, 0) * p.ldb * 2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            ra[q] = p3_rsrc(p.A + (size_t)m0 * p.lda + kbeg + 16 * q, (unsigned)min(abytes > 32u * q ? abytes - 32u * q : (size_t)0, (size_t)0xFFFFFFF0u));
+            rb[q] = p3_rsrc(p.B + (size_t)n0 * p.ldb + kbeg + 16 * q, (unsigned)min(bbytes > 32u * q ? bbytes - 32u * q : (size_t)0, (size_t)0xFFFFFFF0u));
+        }
+        const int row = 32 * wave + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+        va = ((unsigned)row * (unsigned)p.lda + 8u * half) * 2u;
+        vb = ((unsigned)row * (unsigned)p.ldb + 8u * half) * 2u;
+        stepa = stepb = KS * 2;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const size_t rows = (size_t)max(klen - 16 * q, 0);
+            const size_t abytes = rows * p.lda * 2, bbytes = rows * p.ldb * 2;
+            ra[q] = p3_rsrc(p.A + (size_t)(kbeg + 16 * q) * p.lda + m0, (unsigned)min(abytes > (size_t)m0 * 2 ? abytes - (size_t)m0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+            rb[q] = p3_rsrc(p.B + (size_t)(kbeg + 16 * q) * p.ldb + n0, (unsigned)min(bbytes > (size_t)n0 * 2 ? bbytes - (size_t)n0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+        }
+        const int k = 2 * wave + (lane >> 5), jp = lane & 31, j = ((((jp >> 2) ^ (k & 3)) << 2) | (jp & 3));
+        va = ((unsigned)k * (unsigned)p.lda + 8u * j) * 2u;
+        vb = ((unsigned)k * (unsigned)p.ldb + 8u * j) * 2u;
+        stepa = (unsigned)KS * (unsigned)p.lda * 2u; stepb = (unsigned)KS * (unsigned)p.ldb * 2u;
+    }
+
+    unsigned fa[TM], fb[TNN];
+    if constexpr (!TN) {
+        const int l31 = lane & 31;
+        const unsigned fo = (unsigned)l31 * 32u + (unsigned)((lane >> 5) ^ ((l31 >> 3) & 1)) * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)(wm0 + 32 * i) * 32u + fo;
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)(wn0 + 32 * j) * 32u + fo;
+    } else {
+        const int i16 = lane & 15, kq = 8 * (lane >> 5) + (i16 >> 2);
+        const unsigned within = 32u * ((lane >> 4) & 1) + 8u * (i16 & 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)kq * 512u + (unsigned)((((wm0 >> 5) + i) ^ (kq & 3))) * 64u + within;
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)kq * 512u + (unsigned)((((wn0 >> 5) + j) ^ (kq & 3))) * 64u + within;
+    }
+
+    floatx16 acc[TM][TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)p3_smem;
+    const unsigned wave_off = (unsigned)wave * 1024u;
+    bf16x8 A0[TM], A1[TM], A2[TM], B0[TNN], B1[TNN], B2[TNN];
+
+    // requests of stage s: NT chunks that start at or past the end of the reduction range get a zero-sized descriptor
+    auto dma = [&](int s, unsigned slot) {
+        u32x4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        if constexpr (!TN) {
+            const int k0 = s * KS;
+            const bool v0 = k0 < klen, v1 = k0 + 16 < klen, v2 = k0 + 32 < klen;
+            a0.z = v0 ? a0.z : 0u; b0.z = v0 ? b0.z : 0u;
+            a1.z = v1 ? a1.z : 0u; b1.z = v1 ? b1.z : 0u;
+            a2.z = v2 ? a2.z : 0u; b2.z = v2 ? b2.z : 0u;
+        }
+        p3_dma_stage(lds_base + slot * P3_STAGE + wave_off, va, vb, a0, a1, a2, b0, b1, b2);
+        va += stepa; vb += stepb;
+    };
+    // the pass's fragment reads are issued BEFORE its MFMAs (pinned: left to itself the scheduler sinks them to the end of the pass and
+    // the next pass starts by waiting for them)
+    auto mma = [&](const bf16x8 (&X)[TM], const bf16x8 (&Y)[TNN]) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) {
+                if constexpr (SWAP) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[j], X[ii], acc[ii][j], 0, 0, 0);
+                else acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ii], Y[j], acc[ii][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nk > 0) {
+        dma(0, 0u);
+        dma(1, 1u);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        p3_barrier();
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii) A0[ii] = p3_frag<TN>(p3_smem + 0 * P3_SLAB + fa[ii]);
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) B0[j] = p3_frag<TN>(p3_smem + 3 * P3_SLAB + fb[j]);
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int nxt = cur == P3_RING - 1 ? 0 : cur + 1, nx2 = nxt == P3_RING - 1 ? 0 : nxt + 1;
+            const unsigned char* Sc = p3_smem + cur * P3_STAGE;
+            const unsigned char* Sn = p3_smem + nxt * P3_STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            dma(i + 2, (unsigned)nx2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A1[ii] = p3_frag<TN>(Sc + 1 * P3_SLAB + fa[ii]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) B1[j] = p3_frag<TN>(Sc + 4 * P3_SLAB + fb[j]);
+            mma(A0, B0);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A2[ii] = p3_frag<TN>(Sc + 2 * P3_SLAB + fa[ii]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) B2[j] = p3_frag<TN>(Sc + 5 * P3_SLAB + fb[j]);
+            mma(A1, B1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            p3_barrier();
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A0[ii] = p3_frag<TN>(Sn + 0 * P3_SLAB + fa[ii]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) B0[j] = p3_frag<TN>(Sn + 3 * P3_SLAB + fb[j]);
+            mma(A2, B2);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
+    }
+
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kl = lane_e >> 5, fl = lane_e & 31;
+    if constexpr (SWAP) {
+        // acc[i][j][e]: row m = wm0 + 32 i + fl, column n = wn0 + 32 j + 8 (e >> 2) + 4 kl + (e & 3)
+        const int limM = p.M - m0, limN = p.N - n0;
+        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+        const __amdgpu_buffer_rsrc_t cw = make_window(Cb + (size_t)m0 * p.ldc + n0);
+        const __amdgpu_buffer_rsrc_t dw = make_window(EPI == 13 ? (const void*)(p.dref + (size_t)m0 * p.ldr + n0) : (const void*)Cb);
+        const __amdgpu_buffer_rsrc_t bw = make_window(EPI == 12 ? (const void*)(p.bias + n0) : (const void*)Cb);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = wm0 + i * 32 + fl;
+            const bool mok = m < limM;
+#pragma unroll
+            for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = wn0 + j * 32 + 8 * q + 4 * kl;
+                    const bool ok = mok && n < limN;              // N % 4 == 0: a group of 4 columns is in or out as a whole
+                    float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    if constexpr (EPI == 12) {
+                        const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(bw, ok ? (unsigned)n * 4u : OOB_OFF, 0, 0);
+                        v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
+                        v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
+                    }
+                    if constexpr (EPI == 13) {
+                        const u32x2 y = __builtin_amdgcn_raw_buffer_load_b64(dw, ok ? ((unsigned)m * (unsigned)p.ldr + (unsigned)n) * 2u : OOB_OFF, 0, 0);
+                        v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
+                        v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
+                    }
+                    u32x2 w;
+                    w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, cw, ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB_OFF, 0, 0);
+                }
+        }
+    } else {
+        GemmParams g;
+        g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
+        g.bias = nullptr; g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1;
+        g.accumulate = p.accumulate; g.kchunk = p.kchunk; g.splits = p.splits; g.partial = p.partial; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
+        gemm_epilogue<EPI, TM, TNN>(g, acc, m0, n0, wm0, wn0, split, kl, fl);
+    }
+}
+
 // ---- split3 of an fp32 matrix into planes (weights, once per step; test helper for whole operands)
 // dst[q][r][c] (plane stride ps) = plane q of X[r][c]; dstT[q][c][r] likewise for the transposed matrix (either may be NULL)
 __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int R, int Cc, int ld, __bf16* __restrict__ dst, long long ps,
@@ -455,7 +677,7 @@ extern "C" int cham_split3(const float* X, int R, int Cc, int ld, void* dst, lon
     return CHAM_OK;
 }
 
-// launch counters: [0] NT launches, [1] TN launches, [6] epilogue and [7] K-splits of the last launch
+// launch counters: [0] NT launches, [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [6] epilogue and [7] K-splits of the last launch
 static long long g_p3_launches[8];
 extern "C" void cham_gemm_p3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_p3_launches[i]; if (reset) g_p3_launches[i] = 0; }
@@ -553,4 +775,90 @@ extern "C" int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, co
     }
     p.accumulate = accumulate;
     return p3_launch<true, 0>(p, st);
+}
+
+// ---- bf16 configuration: one bf16 plane per operand on the LDS-DMA core (gemm_b1_kernel above)
+//   tn = 0 (NT): A [M, lda], B [N, ldb] bf16, k contiguous, K % 16 == 0; C bf16 [M, ldc] = bf16(tanh(A B^T + bias)) (bias fp32 + act =
+//     CHAM_ACT_TANH), bf16(A B^T x leaky'(dref)) (dref = saved bf16 activation [M, ldr], dact = CHAM_ACT_LEAKY) or bf16(A B^T).
+//   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N] bf16; M % 256 == 0, N % 256 == 0; C fp32 [M, ldc] (+= with accumulate),
+//     split-K through `workspace` (splits_hint as cham_gemm_p3; fixed-order reduction).
+// Returns -CHAM_ERR_ARG for shapes it does not take (the caller keeps cham_gemm_b16 for those).  Launch counters: [2] NT, [3] TN.
+template <bool TN, int EPI>
+static int b1_launch(P3Params& p, hipStream_t st) {
+    g_p3_launches[6] = EPI; g_p3_launches[7] = p.splits;
+    constexpr int smem = P3_RING * P3_STAGE;
+    auto k = gemm_b1_kernel<TN, EPI>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return -CHAM_ERR_LAUNCH;
+        done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb, int tn, void* C, int ldc, int M, int N, int K,
+                                 const float* bias, int act, const void* dref, int ldr, int dact, int accumulate, float* workspace,
+                                 size_t workspace_bytes, int splits_hint, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return -CHAM_ERR_ARG;
+    if ((lda & 7) || (ldb & 7) || (N & 3) || (ldc & 3) || (dref && (ldr & 3))) return -CHAM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dref | (uintptr_t)bias) & 15) return -CHAM_ERR_ARG;
+    if ((size_t)ldc * 4 * 256 >= WINDOW_BYTES || (size_t)ldr * 2 * 256 >= WINDOW_BYTES) return -CHAM_ERR_ARG;
+    P3Params p;
+    p.A = reinterpret_cast<const __bf16*>(A); p.B = reinterpret_cast<const __bf16*>(B); p.a_ps = 0; p.b_ps = 0;
+    p.lda = lda; p.ldb = ldb; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.dref = reinterpret_cast<const __bf16*>(dref); p.ldr = ldr; p.partial = workspace; p.xcd_split = 0; p.accumulate = 0;
+    p.nbm = (M + 255) / 256; p.nbn = (N + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (!tn) {
+        if ((K & 15) || accumulate) return -CHAM_ERR_ARG;
+        if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
+        p.kchunk = K; p.splits = 1;
+        ++g_p3_launches[2];
+        if (dref) {
+            if (bias || act != ACT_NONE || dact != ACT_LEAKY) return -CHAM_ERR_ARG;
+            return b1_launch<false, 13>(p, st);
+        }
+        if (bias) {
+            if (act != ACT_TANH) return -CHAM_ERR_ARG;
+            return b1_launch<false, 12>(p, st);
+        }
+        if (act != ACT_NONE) return -CHAM_ERR_ARG;
+        return b1_launch<false, 10>(p, st);
+    }
+    if ((M & 255) || (N & 255) || bias || act != ACT_NONE || dref) return -CHAM_ERR_ARG;
+    if ((size_t)48 * lda * 2 >= (1ull << 31) || (size_t)48 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
+    const long tiles = (long)p.nbm * p.nbn;
+    int splits = 1;
+    if (splits_hint != 1 && workspace) {
+        long want = splits_hint > 1 ? splits_hint : (tiles >= 192 ? 1 : (256 + tiles - 1) / tiles);
+        const long maxk = (K + 1535) / 1536;
+        if (want > maxk) want = maxk;
+        const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));
+        if (want > maxw) want = maxw;
+        if (splits_hint <= 0 && want >= 8) want = want / 8 * 8;
+        if (want > 1) splits = (int)want;
+    }
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = ((kchunk + 47) / 48) * 48;
+    p.kchunk = kchunk;
+    p.splits = (K + kchunk - 1) / kchunk;
+    if ((size_t)kchunk * (lda > ldb ? lda : ldb) * 2 >= 0xFFFFFFF0ull) return -CHAM_ERR_ARG;
+    ++g_p3_launches[3];
+    if (p.splits > 1) {
+        p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
+        const int rc = b1_launch<true, 6>(p, st);
+        if (rc != CHAM_OK) return rc;
+        GemmParams g;
+        g.A = nullptr; g.B = nullptr; g.C = reinterpret_cast<float*>(C); g.M = M; g.N = N; g.K = K; g.lda = 0; g.ldb = 0; g.ldc = ldc; g.bias = nullptr;
+        g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1; g.accumulate = accumulate;
+        g.kchunk = kchunk; g.splits = p.splits; g.partial = workspace; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
+        launch_splitk_reduce(g, st);
+        CHAM_CHECK_LAUNCH();
+        return CHAM_OK;
+    }
+    p.accumulate = accumulate;
+    return b1_launch<true, 0>(p, st);
 }

@@ -264,6 +264,9 @@ class NARRuntime:
                 r, c = L.entries[name].shape
                 self.shadow[name] = torch.zeros(r, c, dtype=torch.bfloat16, device=dev)
                 self.shadow[name + 'T'] = torch.zeros(c, r, dtype=torch.bfloat16, device=dev)
+        # bf16 configuration: the three candidate-row CAR GEMMs on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel); CHAM_B16_DMA=0: the
+        # register-staged kernels of csrc/gemm_b16.hip for those too (A/B arm; also what shapes the core does not take fall back to)
+        self.b16_dma = self.gemm_dtype == 'bf16' and os.environ.get("CHAM_B16_DMA", "1") == "1" and L.C % 256 == 0
         if self.p3:
             C_ = L.C
             self.w2p = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)       # planes of W2 as stored (CAR dgrad)
@@ -405,8 +408,9 @@ class NARRuntime:
         return list(out)
 
     def gemm_b16(self, A, lda, transA, B, ldb, transB, C, ldc, out_f32, M, N, K, bias=None, act=ACT_NONE, dref=None, ldr=0,
-                 dact=ACT_NONE, accumulate=0, splits=1):
-        """bf16-resident GEMM (csrc/gemm_b16.hip): NT (transA=0, transB=1) or TN (transA=1, transB=0)."""
+                 dact=ACT_NONE, accumulate=0, splits=1, dma=False):
+        """bf16-resident GEMM (csrc/gemm_b16.hip): NT (transA=0, transB=1) or TN (transA=1, transB=0).  dma: the LDS-DMA core
+        (cham_gemm_b16_dma; NT with bf16 output / TN with fp32 output, M and N multiples of 256 for TN)."""
         ws = None
         if splits != 1:
             ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
@@ -415,6 +419,17 @@ class NARRuntime:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0 = self._tile_counts_b16()
             e0.record()
+        if dma:
+            check(self.lib.cham_gemm_b16_dma(ptr(A), lda, ptr(B), ldb, transA, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref), ldr, dact,
+                                             accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_b16_dma")
+            if prof is not None:
+                e1.record()
+                import ctypes
+                c = (ctypes.c_longlong * 8)()
+                self.lib.cham_gemm_p3_launch_counts(c, 0)
+                prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c[7]), act=act, dref=dref is not None, dact=dact,
+                                 bias=bias is not None, rowscale=False, bf16=True, b1=True, out_f32=int(transA), tile=0, epi=int(c[6]), ev=(e0, e1)))
+            return
         check(self.lib.cham_gemm_b16(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, out_f32, M, N, K, ptr(bias), act, ptr(dref),
                                      ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()),
               "cham_gemm_b16")
@@ -1005,7 +1020,7 @@ class NARModuleModel:
                 check(lib.cham_cast_b16(pl.Z1f[BT:].data_ptr(), Rc, C, ptr(pl.Z1c), None, s), "cham_cast_b16")
             else:
                 check(lib.cham_combine_fwd_b16(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1c), s), "cham_combine_fwd_b16")
-            rt.gemm_b16(pl.Z1c, C, 0, sh['W2T'], C, 1, pl.Z2c, C, 0, Rc, C, C, bias=p('b2'), act=ACT_TANH)
+            rt.gemm_b16(pl.Z1c, C, 0, sh['W2T'], C, 1, pl.Z2c, C, 0, Rc, C, C, bias=p('b2'), act=ACT_TANH, dma=rt.b16_dma)
             rt.join()
             check(lib.cham_mul_rows_b16(ptr(pl.Z2c), ptr(pl.pred), C, BT, NC, ptr(pl.Mc), s), "cham_mul_rows_b16")
             rt.gemm_b16(pl.Mc, C, 0, sh['Ws1T'], C, 1, pl.S1, 128, 0, Rc, 128, C, bias=p('bs1'), act=ACT_LEAKY)
@@ -1193,7 +1208,7 @@ class NARModuleModel:
         if rt.dgrad_nn:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
         if b16:
-            rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY)
+            rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY, dma=rt.b16_dma)
         if use_p3:      # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
@@ -1264,7 +1279,7 @@ class NARModuleModel:
                         fc_wgrads()
                     if b16:
                         # ... and the CAR layer-2 weight gradient: the candidate rows (bf16, TN) + the clicked-input rows (fp32), runs beside it
-                        rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0)
+                        rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0, dma=rt.b16_dma)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)

@@ -154,6 +154,18 @@ void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
 int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, const void* B, long long b_plane_stride, int ldb, int tn, float* C,
                  int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr, int dact, int accumulate,
                  float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+
+/* The bf16 configuration's CAR layer-2 GEMMs (nar_model.py:374-405 and their autodiff twins under --gemm_dtype bf16) on the same
+ * LDS-DMA core: ONE bf16 plane per operand, a stage = three consecutive 16-k chunks (csrc/gemm_p3.hip, gemm_b1_kernel).
+ *   tn = 0 (NT): A [M, lda], B [N, ldb] bf16, k contiguous, K % 16 == 0; C bf16 [M, ldc] = bf16(tanh(A B^T + bias)) (bias fp32, act =
+ *     CHAM_ACT_TANH), bf16((A B^T) x leaky'(dref)) (dref = saved bf16 activation [M, ldr], dact = CHAM_ACT_LEAKY) or bf16(A B^T).
+ *   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N] bf16; M % 256 == 0, N % 256 == 0, any K; C fp32 [M, ldc] (accumulate
+ *     adds to it); split-K through `workspace` as cham_gemm_p3.
+ * Returns -EINVAL for a shape it does not take (the caller keeps cham_gemm_b16).  cham_gemm_p3_launch_counts: out8[2] / out8[3] = its
+ * NT / TN launches. */
+int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb, int tn, void* C, int ldc, int M, int N, int K, const float* bias,
+                      int act, const void* dref, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes,
+                      int splits_hint, void* stream);
 void cham_gemm_p3_launch_counts(long long* out8, int reset);
 /* A/B aid (tests/bench_gemm_p3.py): 1 = staggered pipeline (default), 0 = the first version (all requests of a stage at the top of a step) */
 void cham_gemm_p3_set_variant(int variant);

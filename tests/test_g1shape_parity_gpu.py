@@ -184,8 +184,10 @@ def test_step_parity_adressa_shape(gpu):
     assert c3[0] == 2 and c3[1] == 1 and x[1] >= 2, (c3, x)
 
 
-def test_step_parity_g1_shape_bf16(gpu):
-    """BASELINE configs[2] arithmetic at the G1 shape: forward against the oracle that emulates the bf16 operand rounding
+@pytest.mark.parametrize("dma", [True, False])
+def test_step_parity_g1_shape_bf16(gpu, dma):
+    """(dma: the candidate-row CAR GEMMs on the LDS-DMA core - the default - or on the register-staged kernels.)
+    BASELINE configs[2] arithmetic at the G1 shape: forward against the oracle that emulates the bf16 operand rounding
     (logits 4e-3: bf16 products are exact in fp32, only the accumulation order differs, but a value that lands on the other side of
     a bf16 rounding boundary moves by 2^-8 relative), loss 1e-3, and within 3e-2 of the fp32 oracle; gradients as accurate against
     the FP32 oracle as the emulation is (see tests/test_step_gpu.py::test_step_parity_bf16_compute_mode)."""
@@ -195,7 +197,8 @@ def test_step_parity_g1_shape_bf16(gpu):
     batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist='full', sessions_per_hour=4 * B)
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p, seed=7)
-    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16'
+    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16' and model.rt.b16_dma
+    model.rt.b16_dma = dma
     p32 = dict(p); p32['gemm_dtype'] = 'f32'
     orc32 = NAROracle(p32, weights=orc.weights_numpy())
     f, l = batches[3]
@@ -204,6 +207,7 @@ def test_step_parity_g1_shape_bf16(gpu):
     lib = model.rt.lib
     b16_counts = (ctypes.c_longlong * 8)()
     lib.cham_gemm_b16_launch_counts(b16_counts, 1)
+    p3_counts(lib, reset=True)
     model.forward(model.upload_batch(f, l))
     out = model.outputs_numpy()
     grads = {}
@@ -225,9 +229,15 @@ def test_step_parity_g1_shape_bf16(gpu):
     model.backward()
     torch.cuda.synchronize()
     lib.cham_gemm_b16_launch_counts(b16_counts, 0)
-    # CAR forward / dgrad, scorer layer-1 forward / dgrad on the 256x128 8-wave bf16-resident instance, the two big weight gradients (TN) on its
-    # 4-wave variant
-    assert b16_counts[1] >= 4 and b16_counts[1] + b16_counts[2] >= 6, "expected the 256x128 bf16-resident instances to run: %r" % (list(b16_counts),)
+    # the three candidate-row CAR GEMMs on the LDS-DMA core (forward + dgrad NT, W2 weight gradient TN); scorer layer-1 forward / dgrad on the
+    # 256x128 8-wave register-staged instance, its weight gradient (TN) on the 4-wave variant
+    c3 = p3_counts(lib)
+    if dma:
+        assert c3[2] == 2 and c3[3] == 1, "expected the bf16 CAR GEMMs on the LDS-DMA core: %r" % (c3,)
+        assert b16_counts[1] >= 2 and b16_counts[1] + b16_counts[2] >= 3, "expected the 256x128 bf16-resident instances to run: %r" % (list(b16_counts),)
+    else:
+        assert c3[2] == 0 and c3[3] == 0, c3
+        assert b16_counts[1] >= 4 and b16_counts[1] + b16_counts[2] >= 6, "expected the 256x128 bf16-resident instances to run: %r" % (list(b16_counts),)
     g = model.rt.logical_grads()
     gmax = max(float(np.abs(v).max()) for v in grads["f32"].values())
     for k in g:
