@@ -59,7 +59,8 @@ class DataParallelNAR:
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
         rt.dp_mode = self.mode
-        self._early, self._early_work = None, None
+        self._early, self._early_work, self._early_bytes = None, None, 0
+        self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
         # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
         # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
         # (tests/test_dp_rccl_gpu.py; bench.py's dp_self_exchange_ms)
@@ -106,6 +107,7 @@ class DataParallelNAR:
     def _issue_early_bucket(self, flat_grads):
         """Called by the backward pass on the lane that produced the bucket, right after its last gradient was written."""
         a, b = self._early
+        self._early_bytes = 4 * (b - a)
         self._early_work = dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _wait_early_bucket(self):
@@ -129,8 +131,10 @@ class DataParallelNAR:
 
     def _allreduce(self, flat_grads):
         early = self._wait_early_bucket()
+        self.last_exchange_bytes = self._early_bytes if early else 0
         for a, b in self._ranges_without_early(0, flat_grads.numel(), early):
             dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            self.last_exchange_bytes += 4 * (b - a)
 
     def _sparse_allreduce(self, flat_grads):
         """ONE collective for everything but the early bucket: [flat buffer without the item table | touched item-table rows] packed
@@ -159,6 +163,8 @@ class DataParallelNAR:
         rows = comm[n_dense:].view(L, dim)
         check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
         dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
+        self.last_exchange_bytes = 4 * need + (self._early_bytes if early else 0)
+        self.last_touched_rows = L
         o = 0
         for a, b in ranges:
             flat_grads[a:b].copy_(comm[o:o + b - a]); o += b - a
