@@ -169,7 +169,10 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     u32x4 ra[3], rb[3];
     unsigned va, vb, stepa, stepb;
     if constexpr (!TN) {
-        const size_t abytes = (size_t)max(p.M - m0, 0) * p.lda * 2, bbytes = (size_t)max(p.N - n0, 0) * p.ldb * 2;
+        // (the window starts kbeg elements into the first row: it must end that much earlier, or the requests past the reduction range
+        // of the LAST K-split - issued, never consumed - would leave the operand's allocation)
+        const size_t aall = (size_t)max(p.M - m0, 0) * p.lda * 2, ball = (size_t)max(p.N - n0, 0) * p.ldb * 2, koff = (size_t)kbeg * 2;
+        const size_t abytes = aall > koff ? aall - koff : 0, bbytes = ball > koff ? ball - koff : 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             ra[q] = p3_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda + kbeg, (unsigned)min(abytes, (size_t)0xFFFFFFF0u));
@@ -677,7 +680,29 @@ extern "C" int cham_split3(const float* X, int R, int Cc, int ld, void* dst, lon
     return CHAM_OK;
 }
 
-// launch counters: [0] NT launches, [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [6] epilogue and [7] K-splits of the last launch
+// ---- NT with split-K: the LAST, partly filled round of 256 x 256 tiles of a tall NT GEMM (3 876 tiles on 256 CUs = 15 rounds + 36
+// tiles: a sixteenth of the kernel's time for 14 % of a round) is issued as its own launch with the reduction range cut into
+// 256 / tiles pieces, so that every CU gets a piece; this kernel adds the pieces in split order and applies the epilogue.
+__global__ __launch_bounds__(256) void k_p3_nt_finish(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
+                                                      const float* __restrict__ bias, int act, const __bf16* __restrict__ dref, int ldr) {
+    const size_t n4 = (size_t)M * N / 4;
+    const unsigned N4 = (unsigned)N / 4u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4* src = reinterpret_cast<const float4*>(partial) + i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < splits; ++q) { const float4 x = src[(size_t)q * n4]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+        const int row = (int)(i / N4), col = (int)(i % N4) * 4;
+        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (act == ACT_TANH) { v.x = cham_tanhf(v.x); v.y = cham_tanhf(v.y); v.z = cham_tanhf(v.z); v.w = cham_tanhf(v.w); }
+        if (dref) {
+            const float4 y = ld4(dref + (size_t)row * ldr + col);
+            v.x *= y.x > 0.f ? 1.f : 0.2f; v.y *= y.y > 0.f ? 1.f : 0.2f; v.z *= y.z > 0.f ? 1.f : 0.2f; v.w *= y.w > 0.f ? 1.f : 0.2f;
+        }
+        *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+    }
+}
+
+// launch counters: [0] NT launches ([4]: of those, with split-K), [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [6] epilogue and [7] K-splits of the last launch
 static long long g_p3_launches[8];
 extern "C" void cham_gemm_p3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_p3_launches[i]; if (reset) g_p3_launches[i] = 0; }
@@ -708,7 +733,8 @@ static int p3_launch(P3Params& p, hipStream_t st) {
 
 // C[M,N] = epi(sum of six plane products) - see the header.  A, B: plane 0 (bf16), planes `*_plane_stride` elements apart.
 //   tn = 0 (NT): A [M, lda], B [N, ldb], k contiguous; K % 16 == 0.  bias + act (CHAM_ACT_NONE / CHAM_ACT_TANH), or dref_h + dact =
-//     CHAM_ACT_LEAKY: x leaky'(saved activation) with dref_h the h plane [M, ldr] of that activation.
+//     CHAM_ACT_LEAKY: x leaky'(saved activation) with dref_h the h plane [M, ldr] of that activation.  splits_hint > 1 + workspace:
+//     the reduction range in that many pieces (partials + k_p3_nt_finish; for a launch that would not fill the CUs otherwise).
 //   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N]; M % 256 == 0, N % 256 == 0, any K; split-K through `workspace`
 //     (splits_hint: 1 none, 0 automatic, n at most n; fixed-order reduction), accumulate adds to C.
 // Returns -CHAM_ERR_ARG for shapes it does not take (the caller keeps cham_gemm_f32x3 for those).
@@ -730,10 +756,31 @@ extern "C" int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, co
         if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
         p.kchunk = K; p.splits = 1;
         ++g_p3_launches[0];
-        if (dref_h) {
-            if (bias || act != ACT_NONE || dact != ACT_LEAKY) return -CHAM_ERR_ARG;
-            return p3_launch<false, 3>(p, st);
+        if (dref_h && (bias || act != ACT_NONE || dact != ACT_LEAKY)) return -CHAM_ERR_ARG;
+        if (act != ACT_NONE && !(bias && act == ACT_TANH)) return -CHAM_ERR_ARG;
+        if (splits_hint > 1 && workspace && K >= 32) {       // explicit split-K (the partly filled last round of a tall GEMM: see k_p3_nt_finish)
+            long want = splits_hint;
+            if (want > K / 16) want = K / 16;
+            const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));
+            if (want > maxw) want = maxw;
+            if (want > 1) {
+                const int ksteps = (int)((K / 16 + want - 1) / want);
+                p.kchunk = ksteps * 16;
+                p.splits = (K + p.kchunk - 1) / p.kchunk;
+            }
         }
+        if (p.splits > 1) {
+            ++g_p3_launches[4];
+            const int rc = p3_launch<false, 6>(p, st);
+            if (rc != CHAM_OK) return rc;
+            const size_t n4 = (size_t)M * N / 4;
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_p3_nt_finish, dim3(blocks), dim3(256), 0, st, workspace, p.splits, M, N, C, ldc, bias, act, p.dref, ldr);
+            CHAM_CHECK_LAUNCH();
+            return CHAM_OK;
+        }
+        if (dref_h) return p3_launch<false, 3>(p, st);
         if (bias) {
             if (act == ACT_TANH) return p3_launch<false, 2>(p, st);
             if (act == ACT_NONE) return p3_launch<false, 5>(p, st);

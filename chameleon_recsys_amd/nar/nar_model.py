@@ -235,6 +235,9 @@ class NARRuntime:
         # gets a CU meanwhile); 32 (default): two rounds of shorter workgroups, the main lane's PreCAR backward slips in between
         # (11.73-11.75 vs 11.80-11.84 ms/step, two alternating runs each in one gpurun call)
         self.p3_w2_splits = int(os.environ.get("CHAM_P3_W2_SPLITS", "32"))
+        # the partly filled last round of a tall NT plane GEMM as its own split-K launch (see gemm_p3): shortens the kernel by ~2 % stand-alone,
+        # neutral in the step (11.85 / 11.82 vs 11.83 / 11.75 ms, alternating runs: other lanes' kernels already use those CUs) - off
+        self.p3_tail_split = os.environ.get("CHAM_P3_TAIL_SPLIT", "0") == "1"
         # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
         # per-CU matrix kernels that only time-slice the chip when they overlap
         self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
@@ -442,8 +445,22 @@ class NARRuntime:
                              ev=(e0, e1)))
 
     def gemm_p3(self, A, a_ps, lda, B, b_ps, ldb, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
-                accumulate=0, splits=1):
-        """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K)."""
+                accumulate=0, splits=1, whole=False):
+        """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K).
+        A tall NT GEMM whose 256 x 256 tiles end in a round that fills at most half of the 256 CUs (G1 shape: 3 876 tiles = 15 rounds
+        + 36 tiles) goes out as two launches: the full rounds, and the rows of the last round with the reduction range cut into
+        256 // tiles pieces (split-K partials + k_p3_nt_finish), so that round costs a fraction of a tile's time instead of a whole one."""
+        if not tn and splits == 1 and not whole and self.p3_tail_split:
+            nbn = (N + 255) // 256
+            tiles = ((M + 255) // 256) * nbn
+            rem = tiles % 256
+            if tiles > 256 and 0 < rem <= 128 and rem % nbn == 0:
+                m_main = (tiles - rem) // nbn * 256
+                rows = lambda x: None if x is None else (x[0, m_main:] if x.dim() == 3 else x[m_main:])
+                self.gemm_p3(A, a_ps, lda, B, b_ps, ldb, 0, C, ldc, m_main, N, K, bias=bias, act=act, dref_h=dref_h, ldr=ldr, dact=dact, whole=True)
+                self.gemm_p3(rows(A), a_ps, lda, B, b_ps, ldb, 0, rows(C), ldc, M - m_main, N, K, bias=bias, act=act, dref_h=rows(dref_h), ldr=ldr,
+                             dact=dact, splits=256 // rem, whole=True)
+                return
         ws = None
         if splits != 1:
             ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
@@ -890,7 +907,7 @@ class NARModuleModel:
             torch.cuda.current_stream().wait_event(ps[3])
         else:
             self._neg_sample(pl, d, step, pl._samp_cur, s)
-        if rt.dp_mode == 'sparse' and getattr(rt, 'dp_active', rt.dp_world > 1):
+        if rt.dp_mode in ('sparse', 'sparse_rs') and getattr(rt, 'dp_active', rt.dp_world > 1):
             # item rows this step can touch on ANY rank (parallel.py, mode "sparse"): GLOBAL clicked ids + candidate pool + pad item,
             # as int32 row indices in a buffer of the plan (nothing is allocated or freed around the collective)
             n1 = d['aci'].numel()

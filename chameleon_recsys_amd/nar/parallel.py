@@ -45,7 +45,13 @@ class DataParallelNAR:
     integers, so no index exchange is needed: every rank packs those rows (duplicates allowed) into a compact [L, dim] buffer,
     ONE all-reduce of that buffer replaces the all-reduce of the whole [n_items, dim] table (5 M x 378 floats = 7.5 GB ->
     ~86 k rows = 130 MB), and the summed rows are written back; the L2 term of the other rows is local (added inside the Adam
-    kernel).  Everything else in the flat buffer is all-reduced densely."""
+    kernel).  Everything else in the flat buffer is all-reduced densely.
+    mode "sparse_rs": as "sparse", with the touched rows exchanged as SURVEY.md 8e C2 words it - a REDUCE-SCATTER of the packed row
+    buffer (rank r receives the sums of the r-th 1/world of the list: the rows it "owns" this step) followed by an all-gather of the
+    summed chunks, the dense remainder in its own all-reduce.  Adam stays replicated: TF's dense Adam moves every row of the table
+    every step (L2 term + momentum, nar_model.py:740/917), so an owner-only update would have to ship the 7.5 GB table back - the
+    summed gradient rows are what is worth moving.  On a ring the two forms move the same bytes; kept as the literal C2 collective
+    pair and as the RCCL reduce_scatter_tensor / all_gather_into_tensor coverage at the row granularity."""
 
     def __init__(self, model, process_group=None, mode=None):
         import os
@@ -54,8 +60,8 @@ class DataParallelNAR:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.mode = mode or os.environ.get("CHAM_DP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "sharded", "hybrid", "sparse"):
-            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'hybrid' or 'sparse'")
+        if self.mode not in ("allreduce", "sharded", "hybrid", "sparse", "sparse_rs"):
+            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'hybrid', 'sparse' or 'sparse_rs'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
         rt.dp_mode = self.mode
@@ -73,7 +79,7 @@ class DataParallelNAR:
             # all-reduce is issued from the side lane as soon as they are written and overlaps with the rest of the backward
             # (allreduce / sparse modes; matters for strong scaling, where a 32-row step is ~2 ms).  CHAM_DP_EARLY_BUCKET=0: off.
             ents = getattr(L, 'entries', None) or {}
-            if self.mode in ("allreduce", "sparse") and os.environ.get("CHAM_DP_EARLY_BUCKET", "1") == "1" and 'Wf1' in ents and 'Ws4' in ents:
+            if self.mode in ("allreduce", "sparse", "sparse_rs") and os.environ.get("CHAM_DP_EARLY_BUCKET", "1") == "1" and 'Wf1' in ents and 'Ws4' in ents:
                 a, b = L.entries['Wf1'].offset, L.entries['Ws4'].offset + L.entries['Ws4'].size
                 names = [e.name for e in L.entries.values() if a <= e.offset < b]
                 if names == ['Wf1', 'Wf2', 'Ws1', 'Ws2', 'Ws3', 'Ws4']:
@@ -91,10 +97,10 @@ class DataParallelNAR:
                 self.emb_sharded = (rt.layout.emb_end // (self.world * 64)) * (self.world * 64)
                 rt.dp_sharded = self._hybrid_step
                 self._grad_slice = torch.empty(max(1, self.emb_sharded // self.world), dtype=rt.flat.dtype, device=rt.flat.device)
-            elif self.mode == "sparse" and 'items_embedding' in rt.layout.entries:
+            elif self.mode in ("sparse", "sparse_rs") and 'items_embedding' in rt.layout.entries:
                 e = rt.layout.entries['items_embedding']
                 self._item = (e.offset, e.shape[0], e.shape[1])
-                self._compact = None
+                self._compact, self._rs = None, None
                 rt.dp_allreduce = self._sparse_allreduce
             else:
                 rt.dp_allreduce = self._allreduce
@@ -162,7 +168,21 @@ class DataParallelNAR:
             comm[o:o + b - a].copy_(flat_grads[a:b]); o += b - a
         rows = comm[n_dense:].view(L, dim)
         check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
-        dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.mode == "sparse_rs" and dist.get_backend(self.pg) != "gloo":      # (gloo has no reduce_scatter: the all-reduce below)
+            dist.all_reduce(comm[:n_dense], op=dist.ReduceOp.SUM, group=self.pg)
+            # the row list padded to a multiple of the world size (pad rows: zeros, never written back)
+            per = -(-L // self.world)
+            if self._rs is None or self._rs[0].numel() < per * self.world * dim:
+                self._rs = (torch.zeros(per * self.world * dim, dtype=comm.dtype, device=comm.device),
+                            torch.empty(per * dim, dtype=comm.dtype, device=comm.device))
+            packed, mine = self._rs[0][:per * self.world * dim], self._rs[1][:per * dim]
+            packed[:L * dim].copy_(rows.view(-1))
+            packed[L * dim:].zero_()
+            dist.reduce_scatter_tensor(mine, packed, op=dist.ReduceOp.SUM, group=self.pg)       # C2: this rank's rows, summed
+            dist.all_gather_into_tensor(packed, mine, group=self.pg)
+            rows.view(-1).copy_(packed[:L * dim])
+        else:
+            dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
         self.last_exchange_bytes = 4 * need + (self._early_bytes if early else 0)
         self.last_touched_rows = L
         o = 0
@@ -174,7 +194,7 @@ class DataParallelNAR:
     # ---- checkpoints: in the sharded / hybrid modes a rank's Adam slots are only valid on its own slice
     def _gather_slots(self, m, v):
         """Full (m, v) on every rank, for NARRuntime.state_dict(): the owned slices all-gathered (no-op in the replicated modes)."""
-        if not self.active or self.mode in ("allreduce", "sparse"):
+        if not self.active or self.mode in ("allreduce", "sparse", "sparse_rs"):
             return m, v
         total = m.numel()
         E = total if self.mode == "sharded" else self.emb_sharded

@@ -57,7 +57,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "sharded", "hybrid", "sparse"])
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "hybrid", "sparse", "sparse_rs"])
 def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)

@@ -55,7 +55,7 @@ def _worker(rank, port, out_dir):
     batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
     ref = _train(p, batches, None)
     out = {}
-    for mode in ("allreduce", "sharded", "hybrid", "sparse"):
+    for mode in ("allreduce", "sharded", "hybrid", "sparse", "sparse_rs"):
         losses, flat, m, v, active = _train(p, batches, mode)
         assert active, "CHAM_DP_FORCE did not install the exchange hooks"
         out[mode] = (bool(np.array_equal(losses, ref[0])), bool(np.array_equal(flat, ref[1])), bool(np.array_equal(m, ref[2])),

@@ -127,7 +127,7 @@ def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, p3):
     if p3:
         # CAR forward + dgrad (NT) and the W2 weight gradient (TN, split-K) on the plane-resident kernel; scorer layer 1 (row scale),
         # its wgrad and dgrad on the 256x128 on-the-fly instance; nothing wide on the native kernels
-        assert c3[0] == 2 and c3[1] == 1 and c[1] == 0 and c[2] == 0, (c3, x, c)
+        assert c3[0] - c3[4] == 2 and c3[1] == 1 and c[1] == 0 and c[2] == 0, (c3, x, c)
         # (scorer layer 1 forward + its weight gradient; its dgrad lives in the fused kernel csrc/dm_fused.hip)
         assert x[1] >= (2 if length_dist == "full" else 0) and x[0] + x[1] >= 2 and model.rt.dm_fused, x
     elif gemm_dtype == "f32":
@@ -181,7 +181,7 @@ def test_step_parity_adressa_shape(gpu):
     p3_counts(lib, reset=True)
     compare_step_large(model, orc, *batches[3], st)
     x, c3 = x3_counts(lib), p3_counts(lib)
-    assert c3[0] == 2 and c3[1] == 1 and x[1] >= 2, (c3, x)
+    assert c3[0] - c3[4] == 2 and c3[1] == 1 and x[1] >= 2, (c3, x)
 
 
 @pytest.mark.parametrize("dma", [True, False])

@@ -286,3 +286,38 @@ def test_infinite_operand_nan_in_plane_arithmetic_inf_in_native(gpu):
     assert (outs[("native", 2)][7] == 1.0).all()                 # tanh(+inf) = 1: finite
     for name in ("x3", "p3"):
         assert torch.isnan(outs[(name, 0)][7]).all() and torch.isnan(outs[(name, 2)][7]).all(), name
+
+
+@pytest.mark.parametrize("epi", ["plain", "tanh", "bias", "dgrad"])
+@pytest.mark.parametrize("splits", [2, 3, 7, 64])
+def test_nt_split_k_matches_the_single_pass(gpu, epi, splits):
+    """NT with the reduction range in pieces (the partly filled last round of a tall GEMM goes out this way: nar_model.gemm_p3): every
+    epilogue through k_p3_nt_finish, against the one-pass kernel on the same planes (fp32 re-association of the K sum only)."""
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    M, N, K = 2304 + 77, 1024, 1024
+    g = torch.Generator(device=gpu).manual_seed(splits)
+    A = torch.randn(M, K, device=gpu, generator=g)
+    B = torch.randn(N, K, device=gpu, generator=g) * (K ** -0.5)
+    bias = torch.randn(N, device=gpu, generator=g) if epi in ("tanh", "bias") else None
+    Yh = torch.randn(M, N, device=gpu, generator=g).to(torch.bfloat16).contiguous() if epi == "dgrad" else None
+    Ap, Bp = split3(A), split3(B)
+    ws = torch.empty(64 * M * N, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for sp in (1, splits, splits):
+        C = torch.full((M, N), float('nan'), device=gpu)
+        c0 = _counts(lib)
+        check(lib.cham_gemm_p3(ptr(Ap), M * K, K, ptr(Bp), N * K, K, 0, ptr(C), N, M, N, K, ptr(bias), 2 if epi == "tanh" else 0, ptr(Yh), N,
+                               1 if epi == "dgrad" else 0, 0, ptr(ws), ws.numel() * 4, sp, st), "cham_gemm_p3")
+        torch.cuda.synchronize()
+        c1 = _counts(lib)
+        assert c1[4] - c0[4] == (1 if sp > 1 else 0)
+        if sp > 1:
+            assert 1 < c1[7] <= min(sp, K // 16)
+        outs.append(C)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[1], outs[2])
+    err = float((outs[1] - outs[0]).abs().max())
+    assert err < 2e-5 * max(1.0, float(outs[0].abs().max())), err
