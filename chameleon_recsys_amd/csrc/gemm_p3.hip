@@ -138,6 +138,48 @@ __device__ __forceinline__ void p3_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// epilogue of the plane kernels: acc[i][j][e] = element (row wm0 + 32 i + (e & 3) + 8 (e >> 2) + 4 kl, column wn0 + 32 j + fl) of the tile at (m0, n0)
+template <int EPI, int TM, int TNN>
+__device__ __forceinline__ void p3_epilogue(const P3Params& p, floatx16 (&acc)[TM][TNN], int m0, int n0, int wm0, int wn0, int split, int lane) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kl = lane_e >> 5, fl = lane_e & 31;
+    if constexpr (EPI == 3) {
+        // dgrad: x leaky'(saved activation), the activation's sign read from its h plane (bf16 rounding keeps sign and zero)
+        const int limM = p.M - m0, limN = p.N - n0;
+        const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
+        const __amdgpu_buffer_rsrc_t dw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) {
+                const int col = wn0 + j * 32 + fl;
+                const bool cok = col < limN;
+                unsigned short y[16];
+                unsigned offs[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                    const bool ok = cok && row < limM;
+                    offs[e] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
+                    y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u : OOB_OFF, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float yv = __uint_as_float((unsigned)y[e] << 16);
+                    const float v = acc[i][j][e] * (yv > 0.f ? 1.f : 0.2f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
+                }
+            }
+    } else {
+        GemmParams g;
+        g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
+        g.bias = p.bias; g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1;
+        g.accumulate = p.accumulate; g.kchunk = p.kchunk; g.splits = p.splits; g.partial = p.partial; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
+        gemm_epilogue<EPI, TM, TNN>(g, acc, m0, n0, wm0, wn0, split, kl, fl);
+    }
+}
+
 // EPI: 0 plain, 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias, 6 split-K partial
 template <bool TN, int EPI, int VAR>
 __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
@@ -394,43 +436,130 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
     }
 
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int kl = lane_e >> 5, fl = lane_e & 31;
-    if constexpr (EPI == 3) {
-        // dgrad: x leaky'(saved activation), the activation's sign read from its h plane (bf16 rounding keeps sign and zero)
-        const int limM = p.M - m0, limN = p.N - n0;
-        const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
-        const __amdgpu_buffer_rsrc_t dw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
+    p3_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, split, lane);
+}
+
+// ================================================================================================================================
+// NT with TWO workgroups per CU (variant 2): 256 x 128 tile, 4 waves as 2 x 2 (128 x 64 per wave: the same 4 x 2 MFMA tiles), a stage =
+// three A slabs of 8 KB + three B slabs of 4 KB = 36 KB, ring of TWO stages = 72 KB per workgroup.  The one-workgroup-per-CU kernel
+// above leaves the matrix pipe idle while its eight waves run the epilogue (and the prologue of the next tile) in lock step - the TN
+// form, which has no epilogue, is 11 % busier in cycles; here the second workgroup of a CU is somewhere else in its tile.  Price: the
+// B operand is staged once per 128 instead of 256 output columns (1.5x the L2 -> LDS bytes per flop) and a request has one step, not
+// 1.5, to land:
+//   step i (slot i & 1):  P0 A_l x B_h (+ late fragments A_h, B_m) | P1 A_m x B_h | P2 A_h x B_h | s_waitcnt vmcnt(0): stage i + 1 landed,
+//   s_barrier: everyone has read slot i & 1 | DMA of stage i + 2 into slot i & 1 | P3 A_h x B_l (+ early fragments of stage i + 1) | P4 | P5
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_p3h_kernel(P3Params p) {
+    constexpr int BM = 256, BN = 128, BK = 16, TM = 4, TNN = 2;
+    constexpr unsigned SA = 8192, SB = 4096, STAGE = 3 * SA + 3 * SB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
+    const int nwg = p.nbm * p.nbn;
+    const int id = blockIdx.x;
+    const int q8 = nwg / 8, rr = nwg % 8, xcd = id % 8;
+    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + id / 8;
+    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = (p.K + BK - 1) / BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
+
+    u32x4 ra[3], rb[3];
+    const size_t abytes = (size_t)max(p.M - m0, 0) * p.lda * 2, bbytes = (size_t)max(p.N - n0, 0) * p.ldb * 2;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) {
-                const int col = wn0 + j * 32 + fl;
-                const bool cok = col < limN;
-                unsigned short y[16];
-                unsigned offs[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
-                    const bool ok = cok && row < limM;
-                    offs[e] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
-                    y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u : OOB_OFF, 0, 0);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float yv = __uint_as_float((unsigned)y[e] << 16);
-                    const float v = acc[i][j][e] * (yv > 0.f ? 1.f : 0.2f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
-                }
-            }
-    } else {
-        GemmParams g;
-        g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
-        g.bias = p.bias; g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1;
-        g.accumulate = p.accumulate; g.kchunk = p.kchunk; g.splits = p.splits; g.partial = p.partial; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
-        gemm_epilogue<EPI, TM, TNN>(g, acc, m0, n0, wm0, wn0, split, kl, fl);
+    for (int q = 0; q < 3; ++q) {
+        ra[q] = p3_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda, (unsigned)min(abytes, (size_t)0xFFFFFFF0u));
+        rb[q] = p3_rsrc(p.B + q * p.b_ps + (size_t)n0 * p.ldb, (unsigned)min(bbytes, (size_t)0xFFFFFFF0u));
     }
+    // lane l of wave w fills A pieces (row 64 w + l / 2) and (row 64 w + 32 + l / 2), B piece (row 32 w + l / 2); half l & 1 of the LDS row
+    // holds source half (l & 1) ^ bit 3 of the row (the same for a row and the row 32 below it)
+    const unsigned half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1));
+    unsigned va = ((unsigned)(64 * wave + (lane >> 1)) * (unsigned)p.lda + 8u * half) * 2u;
+    unsigned va2 = va + 32u * (unsigned)p.lda * 2u;
+    unsigned vb = ((unsigned)(32 * wave + (lane >> 1)) * (unsigned)p.ldb + 8u * half) * 2u;
+
+    unsigned fa[TM], fb[TNN];
+    {
+        const int l31 = lane & 31;
+        const unsigned fo = (unsigned)l31 * 32u + (unsigned)((lane >> 5) ^ ((l31 >> 3) & 1)) * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)(wm0 + 32 * i) * 32u + fo;
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)(wn0 + 32 * j) * 32u + fo;
+    }
+    floatx16 acc[TM][TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)p3_smem;
+    const unsigned la = (unsigned)wave * 2048u, lb = 3 * SA + (unsigned)wave * 1024u;
+    auto dma = [&](unsigned slot) {
+        const unsigned b = lds_base + slot * STAGE;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            p3_dma_one(b + q * SA + la, va, ra[q]);
+            p3_dma_one(b + q * SA + la + 1024u, va2, ra[q]);
+            p3_dma_one(b + q * SB + lb, vb, rb[q]);
+        }
+        va += BK * 2; va2 += BK * 2; vb += BK * 2;
+    };
+    bf16x8 AH[TM], AM[TM], AL[TM], BH[TNN], BMf[TNN], BL[TNN];
+    constexpr unsigned OAH = 0, OAM = SA, OAL = 2 * SA, OBH = 3 * SA, OBM = 3 * SA + SB, OBL = 3 * SA + 2 * SB;
+    auto mma = [&](const bf16x8 (&X)[TM], const bf16x8 (&Y)[TNN]) {
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ii], Y[j], acc[ii][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nk > 0) {
+        dma(0u);
+        dma(1u);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        p3_barrier();
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<false>(p3_smem + OBH + fb[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) AL[i] = p3_frag<false>(p3_smem + OAL + fa[i]);
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<false>(p3_smem + OBL + fb[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) AM[i] = p3_frag<false>(p3_smem + OAM + fa[i]);
+        for (int i = 0; i < nk; ++i) {
+            const unsigned cur = (unsigned)(i & 1);
+            const unsigned char* Sc = p3_smem + cur * STAGE;
+            const unsigned char* Sn = p3_smem + (cur ^ 1u) * STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AH[ii] = p3_frag<false>(Sc + OAH + fa[ii]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BMf[j] = p3_frag<false>(Sc + OBM + fb[j]);
+            mma(AL, BH);
+            mma(AM, BH);
+            mma(AH, BH);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p3_barrier();
+            dma(cur);           // stage i + 2 (past the reduction range: requested all the same, never consumed)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<false>(Sn + OBH + fb[j]);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AL[ii] = p3_frag<false>(Sn + OAL + fa[ii]);
+            mma(AH, BL);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<false>(Sn + OBL + fb[j]);
+            mma(AM, BMf);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AM[ii] = p3_frag<false>(Sn + OAM + fa[ii]);
+            mma(AH, BMf);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
+    }
+    p3_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, 0, lane);
 }
 
 // ================================================================================================================================
@@ -702,13 +831,13 @@ __global__ __launch_bounds__(256) void k_p3_nt_finish(const float* __restrict__ 
     }
 }
 
-// launch counters: [0] NT launches ([4]: of those, with split-K), [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [6] epilogue and [7] K-splits of the last launch
+// launch counters: [0] NT launches ([4]: of those, with split-K), [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [5] NT launches on the half-tile kernel, [6] epilogue and [7] K-splits of the last launch
 static long long g_p3_launches[8];
 extern "C" void cham_gemm_p3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_p3_launches[i]; if (reset) g_p3_launches[i] = 0; }
 }
 
-static int g_p3_variant = 0;      // 0 = all requests of a stage at the top of a step (default: 2-5 % faster on MI355X), 1 = staggered (A/B arm)
+static int g_p3_variant = 0;      // 0 = all requests of a stage at the top of a step, 1 = staggered (A/B arm: 2-5 % slower), 2 = NT on the half-tile kernel (two workgroups per CU)
 extern "C" void cham_gemm_p3_set_variant(int v) { g_p3_variant = v; }
 
 template <bool TN, int EPI, int VAR>
@@ -726,9 +855,28 @@ static int p3_launch_var(P3Params& p, hipStream_t st) {
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+template <int EPI>
+static int p3h_launch(P3Params p, hipStream_t st) {       // (by value: the column-tile count is this variant's own)
+    g_p3_launches[6] = EPI; g_p3_launches[7] = 1; ++g_p3_launches[5];
+    constexpr int smem = 2 * (3 * 8192 + 3 * 4096);
+    p.nbn = (p.N + 127) / 128;
+    auto k = gemm_p3h_kernel<EPI>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return -CHAM_ERR_LAUNCH;
+        done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(256), smem, st, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
 template <bool TN, int EPI>
 static int p3_launch(P3Params& p, hipStream_t st) {
-    return g_p3_variant == 0 ? p3_launch_var<TN, EPI, 0>(p, st) : p3_launch_var<TN, EPI, 1>(p, st);
+    if constexpr (!TN && EPI != 6) {
+        if (g_p3_variant == 2) return p3h_launch<EPI>(p, st);
+    }
+    return g_p3_variant == 1 ? p3_launch_var<TN, EPI, 1>(p, st) : p3_launch_var<TN, EPI, 0>(p, st);
 }
 
 // C[M,N] = epi(sum of six plane products) - see the header.  A, B: plane 0 (bf16), planes `*_plane_stride` elements apart.

@@ -235,6 +235,10 @@ class NARRuntime:
         # gets a CU meanwhile); 32 (default): two rounds of shorter workgroups, the main lane's PreCAR backward slips in between
         # (11.73-11.75 vs 11.80-11.84 ms/step, two alternating runs each in one gpurun call)
         self.p3_w2_splits = int(os.environ.get("CHAM_P3_W2_SPLITS", "32"))
+        # pipeline variant of the plane-resident GEMMs (csrc/gemm_p3.hip): 0 = all DMA requests of a stage at the top of a step (default),
+        # 1 = staggered per MFMA pass, 2 = NT on 256x128 tiles with two workgroups per CU (A/B arms)
+        if self.p3:
+            self.lib.cham_gemm_p3_set_variant(int(os.environ.get("CHAM_P3_VARIANT", "0")))
         # the partly filled last round of a tall NT plane GEMM as its own split-K launch (see gemm_p3): shortens the kernel by ~2 % stand-alone,
         # neutral in the step (11.85 / 11.82 vs 11.83 / 11.75 ms, alternating runs: other lanes' kernels already use those CUs) - off
         self.p3_tail_split = os.environ.get("CHAM_P3_TAIL_SPLIT", "0") == "1"

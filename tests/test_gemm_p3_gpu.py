@@ -87,7 +87,7 @@ def _tn(gpu, M, N, K, splits=1, accumulate=0, seed=0, reps=1):
     return float((outs[0].double() - R).abs().max()) / float(R.abs().max())
 
 
-@pytest.fixture(params=[1, 0], ids=["staggered", "v1"])
+@pytest.fixture(params=[2, 1, 0], ids=["half_tile_2wg", "staggered", "v1"])
 def variant(request):
     from chameleon_recsys_amd import _lib
     lib = _lib.load()
