@@ -94,7 +94,10 @@ def gemm_symbol(r):
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
         return "k_dm_mulpred_fused(DmfParams)"
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
-        return "void gemm_p3_kernel<%s, %d, 0>(P3Params)" % (tf(bool(r['transA'])), epi)
+        var = int(os.environ.get("CHAM_P3_VARIANT", "0"))
+        if var == 2 and not r['transA'] and epi != 6:
+            return "void gemm_p3h_kernel<%d>(P3Params)" % epi
+        return "void gemm_p3_kernel<%s, %d, %d>(P3Params)" % (tf(bool(r['transA'])), epi, 1 if var == 1 else 0)
     if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
         rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
