@@ -104,6 +104,16 @@ _TORCH_DTYPE = {np.dtype(n).str: t for n, t in (('int64', torch.int64), ('int32'
                                                    ('uint8', torch.uint8))}
 
 
+def pack_offsets(arrays, align=256):
+    """Byte offsets of a dict of numpy arrays packed back to back into one staging block (each start aligned: the device views of
+    upload_batch reinterpret the block per dtype) and the block's size."""
+    offs, total = {}, 0
+    for k, a in arrays.items():
+        offs[k] = total
+        total += (a.nbytes + align - 1) & ~(align - 1)
+    return offs, total
+
+
 class _PinnedRing:
     """Page-locked staging buffers for the per-step host -> device copies: a batch's arrays are packed into one
     pinned arena and copied with truly asynchronous DMA (a copy from pageable memory goes through the driver's bounce buffer and
@@ -821,10 +831,7 @@ class NARModuleModel:
         arrs = {k: np.ascontiguousarray(a) for k, a in host.items()}
         out = {}
         if ring is not None:
-            offs, total = {}, 0
-            for k, a in arrs.items():
-                offs[k] = total
-                total += (a.nbytes + 255) & ~255
+            offs, total = pack_offsets(arrs)
             ring.begin(total)
             arena = ring.bufs[ring.k]
             bytes_view = arena.numpy()

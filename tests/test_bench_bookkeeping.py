@@ -1,0 +1,47 @@
+"""Host-side bookkeeping that the GPU legs rely on, checked on the CPU: the kernel symbols bench.py rebuilds for its roofline entries
+are the names rocprofv3 lists for the same launches (committed summary), its traffic lookup finds the dominant kernel's PMC entry, and
+the staging-block layout of upload_batch."""
+import csv
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stats_names():
+    with open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")) as fh:
+        return {r["Name"] for r in csv.DictReader(fh)}
+
+
+def test_rebuilt_gemm_symbols_are_the_names_rocprof_lists():
+    import bench
+    names = _stats_names()
+    base = dict(transA=0, transB=1, rowscale=False, bf16=False, tile=0)
+    recs = [dict(base, p3=True, epi=3), dict(base, p3=True, epi=2), dict(base, p3=True, epi=6, transA=1, transB=0),
+            dict(base, dmf=True, epi=0),
+            dict(base, x3=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue)
+            dict(base, x3=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient
+            dict(base, x3=True, tile=0, epi=6, transA=1, transB=0)]
+    for r in recs:
+        sym = bench.gemm_symbol(r)
+        assert sym in names, "%s is not a kernel of profiles/r03_kernel_stats.csv" % sym
+
+
+def test_committed_traffic_file_has_the_dominant_kernels():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read())
+    dom = line["roofline"]["kernel"].split(" = ")[0]
+    assert dom in d and d[dom]["traffic_bytes_per_launch"] > line["roofline"]["algorithmic_bytes_per_launch"] * 0.9
+    for g in line["roofline"]["top_gemms"]:
+        assert g["kernel"].split(" = ")[0] in d
+
+
+def test_pack_offsets_layout():
+    from chameleon_recsys_amd.nar.nar_model import pack_offsets
+    arrs = dict(a=np.zeros((3, 5), np.int64), b=np.zeros(7, np.uint8), c=np.zeros((2, 0), np.float32), d=np.zeros(65, np.int32))
+    offs, total = pack_offsets(arrs)
+    assert offs == dict(a=0, b=256, c=512, d=512) and total == 1024
+    for k, a in arrs.items():
+        assert offs[k] % 256 == 0 and offs[k] + a.nbytes <= total
