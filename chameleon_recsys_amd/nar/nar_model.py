@@ -245,6 +245,10 @@ class NARRuntime:
         # gets a CU meanwhile); 32 (default): two rounds of shorter workgroups, the main lane's PreCAR backward slips in between
         # (11.73-11.75 vs 11.80-11.84 ms/step, two alternating runs each in one gpurun call)
         self.p3_w2_splits = int(os.environ.get("CHAM_P3_W2_SPLITS", "32"))
+        # Short (ragged) batches: the CAR GEMMs shrink with the number of valid positions, the recurrent chain of the side lane does not - the
+        # main lane then waits for the clicked-row gradient behind its CAR dgrad.  With at most this many candidate rows the plane-resident W2
+        # weight gradient runs on the MAIN lane in that wait instead of on the side lane behind the chain (0 = never)
+        self.w2_main_rows = int(os.environ.get("CHAM_W2_MAIN_ROWS", "131072"))     # G1-like lengths: 88.1-88.4 k -> 90.5-90.6 k sessions/s
         # pipeline variant of the plane-resident GEMMs (csrc/gemm_p3.hip): 0 = all DMA requests of a stage at the top of a step (default),
         # 1 = staggered per MFMA pass, 2 = NT on 256x128 tiles with two workgroups per CU (A/B arms)
         if self.p3:
@@ -619,6 +623,11 @@ class StepPlan:
         self.neg_slot_c = torch.zeros(BT, N, dtype=torch.int32, device=dev)
         self.Z2f, self.rnn_c, self.drnn_c, self.dxproj_c = f32(BT, C), f32(BT, Hp), f32(BT, Hp), f32(BT, NG * Hp)
         self.pos, self.P = None, BT
+        # The zero fills above run on the stream that built the plan.  A stream that touches these buffers without being ordered behind
+        # that point must wait for this event first: presample() may be the FIRST user of a plan (a padded length T seen for the first
+        # time), it writes the sampler outputs on the state's stream - and the fills, still queued behind the running step, would wipe them.
+        self.created = torch.cuda.Event()
+        self.created.record()
 
     def dropout_buffers(self, rt):
         """Buffers of the dropout path (keep_prob < 1: dense PreCAR input rows, dropped FC1 / recurrent outputs) - allocated on first use."""
@@ -880,6 +889,7 @@ class NARModuleModel:
             return False
         pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
         k, step = 1 - pl._samp_cur, rt.global_step
+        state.stream.wait_event(pl.created)
         state.stream.wait_event(d['uploaded'])
         d['aci'].record_stream(state.stream)
         with torch.cuda.stream(state.stream):      # in order behind the state update it must see
@@ -1249,6 +1259,11 @@ class NARModuleModel:
             else:
                 rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
         e_cdgrad = mark()
+        w2_main = bool(on and use_p3 and not swap and 0 < Rc <= rt.w2_main_rows)
+        e_w2main = None
+        if w2_main:      # candidate rows' share of the W2 weight gradient here, in the main lane's wait for the side lane's recurrent chain
+            rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=0)
+            e_w2main = mark()
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
         with side(e_dZ2c):
@@ -1314,9 +1329,12 @@ class NARModuleModel:
                     elif use_p3:
                         # ... and the CAR layer-2 weight gradient: the candidate rows from their planes (TN, split-K), the clicked-input
                         # rows (fp32) added by the on-the-fly kernel; b2 from the per-position partial sums of k_mulpred_bwd_p3
-                        if on and rt.w2_after_dgrad:
-                            rt.side_stream.wait_event(e_cdgrad)
-                        rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=rt.p3_w2_splits)
+                        if w2_main:       # (the candidate rows' share was written by the main lane: behind e_cdgrad it is complete)
+                            rt.side_stream.wait_event(e_w2main)
+                        else:
+                            if on and rt.w2_after_dgrad:
+                                rt.side_stream.wait_event(e_cdgrad)
+                            rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=rt.p3_w2_splits)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
