@@ -214,3 +214,50 @@ def test_adressa_trainer_main_end_to_end(gpu, tmp_path):
     L = est._store['runtime'].layout
     assert 'meta_emb/category1' in L.entries and 'ctx_emb/city' in L.entries and L.entries['ctx_emb/city'].shape[0] == 40
     assert len(TA.base.eval_sessions_metrics_log) == 2 and 0.0 <= TA.base.eval_sessions_metrics_log[-1]['hitrate_at_n'] <= 1.0
+
+
+def _train_free_running(tmp_path, tag, files, csv, pkl, presample):
+    """Estimator.train over the files with the device-resident state and NO per-step fetches (nothing synchronises the host with the
+    device inside the loop: uploads, negative pre-sampling and state updates of the next batch run ahead on their own streams)."""
+    import os
+    from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
+    os.environ["CHAM_PRESAMPLE"] = "1" if presample else "0"
+    try:
+        argv = ['--batch_size', '32', '--truncate_session_length', '20', '--learning_rate', '1e-3', '--reg_l2', '1e-5', '--softmax_temperature', '0.2',
+                '--recent_clicks_buffer_max_size', '2000', '--recent_clicks_for_normalization', '300', '--eval_metrics_top_n', '3',
+                '--CAR_embedding_size', '256', '--rnn_units', '255', '--train_total_negative_samples', '20', '--train_negative_samples_from_buffer', '300',
+                '--eval_total_negative_samples', '20', '--eval_negative_samples_from_buffer', '300', '--content_embedding_scale_factor', '6.0',
+                '--disable_eval_benchmarks', '--clicked_items_state', 'device', '--model_dir', str(tmp_path / ("model_" + tag)),
+                '--train_set_path_regex', str(tmp_path / "data" / "sessions_hour_*.tfrecord.gz"),
+                '--acr_module_articles_metadata_csv_path', csv, '--acr_module_articles_content_embeddings_pickle_path', pkl]
+        T.FLAGS = T.define_flags().parse_args(argv)
+        meta_df, ace = T.load_acr_module_resources(csv, pkl)
+        ace = T.l2_normalize_rows(ace) * np.float32(6.0)
+        acfg = T.get_articles_features_config(n_items=ace.shape[0])
+        meta = T.process_articles_metadata(meta_df, acfg)
+        scfg = T.get_session_features_config()
+        T.eval_sessions_metrics_log = []
+        T.clicked_items_state = DeviceClickedItemsState(1.0, 2000, 300, ace.shape[0])
+        est = T.build_estimator(str(tmp_path / ("model_" + tag)), ace, meta, acfg, scfg)
+        est.config.log_step_count_steps = 0
+        est.config.save_checkpoints_secs = 0
+        est.train(lambda: datasets.prepare_dataset_iterator(files, scfg, batch_size=32, truncate_session_length=20))
+        rt = est._store['runtime']
+        assert rt.p3 and rt.presample == presample
+        sd = rt.state_dict()
+        return sd['flat'].numpy().copy(), sd['m'].numpy().copy(), int(sd['global_step'])
+    finally:
+        os.environ.pop("CHAM_PRESAMPLE", None)
+
+
+def test_free_running_estimator_is_bit_reproducible_and_independent_of_the_look_ahead(gpu, tmp_path):
+    """Ragged sessions (several padded lengths: every StepPlan is created inside the run, some of them by the look-ahead staging of the NEXT
+    batch), plane-resident GEMMs, device-resident state, no host synchronisation inside Estimator.train: two runs end with bit-identical
+    weights and Adam slots, and so does a run that draws its negatives at the head of each step instead of ahead of it."""
+    files, csv, pkl = synthetic.write_dataset(str(tmp_path / "data"), 4, 160, 3000, 64, seq_len=20, seed=33, length_dist='g1')
+    a = _train_free_running(tmp_path, "a", files, csv, pkl, True)
+    b = _train_free_running(tmp_path, "b", files, csv, pkl, True)
+    c = _train_free_running(tmp_path, "c", files, csv, pkl, False)
+    assert a[2] == b[2] == c[2] >= 15
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "two free-running runs differ"
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), "look-ahead sampling changes the result"
