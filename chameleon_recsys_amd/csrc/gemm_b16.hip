@@ -287,6 +287,40 @@ __global__ __launch_bounds__(256) void gemm_b16_splitk_reduce(const float* __res
     }
 }
 
+// Small outputs with MANY splits (the scorer's weight gradients: a [1024, 128] output has 128 K-splits and the form above walks them with
+// 128 workgroups of dependent loads - 0.32 ms per launch, the largest kernel-time item of the bf16 step in rocprofv3's summary): 16 threads
+// share one group of four columns, thread g sums the splits g, g + 16, ..., the sixteen sums are added in ascending g through LDS (as
+// gemm_shared.h's gemm_splitk_reduce_wide) - a fixed order.
+__global__ __launch_bounds__(256) void gemm_b16_splitk_reduce_wide(const float* __restrict__ partial, int splits, int M, int N,
+                                                                   float* __restrict__ C, int ldc, int accumulate) {
+    __shared__ float4 red[256];
+    const size_t n4 = (size_t)M * N / 4;
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + o;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* src = reinterpret_cast<const float4*>(partial) + i;
+        int s = g;
+        for (; s + 48 < splits; s += 64) {
+            const float4 x0 = src[(size_t)s * n4], x1 = src[(size_t)(s + 16) * n4], x2 = src[(size_t)(s + 32) * n4], x3 = src[(size_t)(s + 48) * n4];
+            v.x += x0.x; v.y += x0.y; v.z += x0.z; v.w += x0.w;
+            v.x += x1.x; v.y += x1.y; v.z += x1.z; v.w += x1.w;
+            v.x += x2.x; v.y += x2.y; v.z += x2.z; v.w += x2.w;
+            v.x += x3.x; v.y += x3.y; v.z += x3.z; v.w += x3.w;
+        }
+        for (; s < splits; s += 16) { const float4 x = src[(size_t)s * n4]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (g != 0 || i >= n4) return;
+    for (int q = 1; q < 16; ++q) { const float4 x = red[q * 16 + o]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    const size_t e = i * 4;
+    const int row = (int)(e / N), col = (int)(e % N);
+    float4* c = reinterpret_cast<float4*>(C + (size_t)row * ldc + col);
+    if (accumulate) { const float4 old = *c; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+    *c = v;
+}
+
 // [0] 128x128, [1] 256x128 / 8 waves, [2] 256x128 / 4 waves, [3] 256x64, [4] 256x32; of the LAST launch: [5] fp32 output, [6] epilogue
 // variant, [7] K-splits (test / bench aid, not thread-safe)
 static long long g_b16_launches[8];
@@ -327,10 +361,15 @@ static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStrea
             const int rc = b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 6, true>(p, st);
             if (rc != CHAM_OK) return rc;
             const size_t n4 = (size_t)p.M * p.N / 4;
-            int blocks = (int)((n4 + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(gemm_b16_splitk_reduce, dim3(blocks), dim3(256), 0, st, p.partial, p.splits, p.M, p.N,
-                               reinterpret_cast<float*>(p.C), p.ldc, p.accumulate);
+            if (n4 <= 65536 && p.splits >= 32) {
+                hipLaunchKernelGGL(gemm_b16_splitk_reduce_wide, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, p.partial, p.splits, p.M, p.N,
+                                   reinterpret_cast<float*>(p.C), p.ldc, p.accumulate);
+            } else {
+                int blocks = (int)((n4 + 255) / 256);
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(gemm_b16_splitk_reduce, dim3(blocks), dim3(256), 0, st, p.partial, p.splits, p.M, p.N,
+                                   reinterpret_cast<float*>(p.C), p.ldc, p.accumulate);
+            }
             CHAM_CHECK_LAUNCH();
             return CHAM_OK;
         }

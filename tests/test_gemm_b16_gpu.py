@@ -68,6 +68,16 @@ def test_nt_forward_and_dgrad(gpu, M, N, K, variant):
     assert _run(gpu, M, N, K, 'nt', dref=True, dact=2, variant=variant) < BF16_OUT
 
 
+def test_tn_wgrad_many_splits_small_output(gpu):
+    """The scorer's weight-gradient shape class: a small output with tens of K-splits goes through the wide fixed-order reduction
+    (16 threads per column group), with and without accumulate, repeatably."""
+    for M, N, K, splits in ((1024, 128, 40000, 0), (1024, 128, 40000, 64), (128, 64, 60000, 0), (64, 32, 33000, 40)):
+        a = _run(gpu, M, N, K, 'tn', out_f32=True, splits=splits)
+        b = _run(gpu, M, N, K, 'tn', out_f32=True, splits=splits)
+        assert a < 1e-4 and a == b, (M, N, K, splits, a, b)
+        assert _run(gpu, M, N, K, 'tn', out_f32=True, splits=splits, accumulate=1) < 1e-4
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 5000), (1024, 128, 3001), (64, 32, 20000), (1024, 1024, 4099), (128, 64, 777)])
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_tn_wgrad_splitk(gpu, M, N, K, variant):
