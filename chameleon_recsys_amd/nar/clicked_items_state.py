@@ -12,6 +12,24 @@ import numpy as np
 MILISECS_BY_HOUR = 1000 * 60 * 60
 
 
+
+_LANE_STREAMS = {}
+
+
+def lane_stream(device, role, priority=0):
+    """The process-wide HIP stream of a lane (side / aux / upload / state) on a device.  Every runtime and state object of a process
+    shares them: torch hands out pool streams round-robin and HIP multiplexes streams onto a few hardware queues, so per-object streams
+    made WHICH lanes share a queue - and with it how well they overlap - depend on how many objects the process had created before
+    (profiles/r03_notes.md section 7).  Work of different objects on one lane is merely stream-ordered."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role, int(priority))
+    st = _LANE_STREAMS.get(key)
+    if st is None:
+        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+    return st
+
+
 class _ColdStartBookkeeping:
     """Item cold-start analysis (--eval_cold_start): the step an item was clicked first and, through evaluation.ColdStartAnalysisState,
     how many steps later it first showed up in a top-n recommendation list (clicked_items_state.py:43-45, 97-104, 196-203; snapshot /
@@ -155,7 +173,7 @@ class DeviceClickedItemsState(_ColdStartBookkeeping):
         self.num_items = num_items
         self._ws = None
         import os
-        self.stream = torch.cuda.Stream(device=self.device) if os.environ.get("CHAM_STATE_ASYNC", "1") == "1" else None
+        self.stream = lane_stream(self.device, "state") if os.environ.get("CHAM_STATE_ASYNC", "1") == "1" else None
         self.updated_event, self.consumed_event, self._consumed_key = None, None, None
         self.reset_state()
 

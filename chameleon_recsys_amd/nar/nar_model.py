@@ -17,6 +17,7 @@ import torch
 
 from .. import _lib
 from .._lib import check, ptr
+from .clicked_items_state import lane_stream
 from .layout import COL_ITEMEMB, ParamLayout
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
@@ -222,9 +223,9 @@ class NARRuntime:
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
         # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
-        self.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
+        self.side_stream = lane_stream(dev, "side", int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
         self._side_raw = self.side_stream.cuda_stream
-        self.aux_stream = torch.cuda.Stream(device=dev, priority=-1)      # second half of k_mulpred_bwd beside the CAR dgrad
+        self.aux_stream = lane_stream(dev, "aux", -1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
         # Side-lane priority, measured on MI355X (profiles/r01_notes.md items 2 and 25): the early builds needed a HIGH-priority
@@ -268,7 +269,7 @@ class NARRuntime:
         self.precar_bwd_native = os.environ.get("CHAM_PRECAR_BWD_NATIVE", "0") == "1"
         self.b2_early = os.environ.get("CHAM_B2_EARLY", "0") == "1"
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
-        self.upload_stream = torch.cuda.Stream(device=dev) if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
+        self.upload_stream = lane_stream(dev, "upload") if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
         self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
         self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
         if os.environ.get("CHAM_RNN_LDS_HOG"):
