@@ -47,6 +47,15 @@ _SIGNATURES = {
     "cham_combine_fwd_p3": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
     "cham_mulpred_bwd_p3": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P]),
     "cham_dm_mulpred_p3": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
+    "cham_h2_scale_absmax": (c_int, [P, c_size_t, P, c_size_t, P, P]),
+    "cham_h2_scale_rownorm": (c_int, [P, c_long, c_int, c_int, P, P, P]),
+    "cham_split2h": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P, c_int, P]),
+    "cham_gemm_h2": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
+                             P, c_size_t, c_int, P]),
+    "cham_gemm_h2_launch_counts": (None, [P, c_int]),
+    "cham_combine_fwd_h2": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, P]),
+    "cham_mulpred_bwd_h2": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P, P]),
+    "cham_dm_mulpred_h2": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
     "cham_gemm_b16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                               P, c_size_t, c_int, P]),
     "cham_gemm_b16_set_variant": (None, [c_int]),

@@ -114,6 +114,37 @@ __device__ __forceinline__ void st4_planes(__bf16* p, long long ps, const float4
     *reinterpret_cast<bf16x4_t*>(p + 2 * ps) = l;
 }
 
+// ---- two fp16 planes + a power-of-two scale ("h2"; csrc/gemm_h2.hip, round 4) ----------------------------------------------------
+// x = (h + l) / s with h = fp16(x s), l = fp16(x s - h) (round to nearest even; x s and the subtraction are exact in fp32): 11 + 11
+// significand bits while l is a normal fp16 number (|x s| >= 2^-3), absolute error <= 2^-25 / s below that (fp16 subnormals are kept:
+// float_denorm_mode_16_64 = 3).  s is an exact power of two chosen by the matrix's producer from a rigorous bound of max |x| so that
+// |x s| <= 2^15 (fp16 max 65 504): see k_h2_scale_* in gemm_h2.hip.  A plane-product GEMM over such operands needs THREE MFMA products
+// (h h + h l + l h; the dropped l l term is <= 2^-22 |a b|) where the bf16 x3 split needs six (tests/test_split2h_cpu.py).
+// The h plane keeps the SIGN of a value that underflows: x > 0 never stores +0 (smallest subnormal instead), so a consumer may take
+// leaky-ReLU's derivative from the h plane's bit pattern alone ((short) bits > 0 <=> x > 0).
+struct H2Scale { float scale, inv, bound, pad; unsigned max_bits, ticket, pad1, pad2; };     // 32-byte device record (zero-initialised)
+__device__ __forceinline__ void split2h(float xs /* already scaled */, _Float16& h, _Float16& l) {
+    h = (_Float16)xs;
+    l = (_Float16)(xs - (float)h);
+}
+__device__ __forceinline__ unsigned short h2_keep_sign(_Float16 h, float x) {
+    const unsigned short b = __builtin_bit_cast(unsigned short, h);
+    return (x > 0.f && b == 0) ? (unsigned short)1 : b;
+}
+// 4 consecutive elements of a row -> the two planes (planes `ps` elements apart): 8-byte stores
+__device__ __forceinline__ void st4_planes_h2(_Float16* p, long long ps, const float4& v, float s) {
+    typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    u16x4_t h; f16x4_t l;
+    _Float16 a, b;
+    split2h(v.x * s, a, b); h[0] = h2_keep_sign(a, v.x); l[0] = b;
+    split2h(v.y * s, a, b); h[1] = h2_keep_sign(a, v.y); l[1] = b;
+    split2h(v.z * s, a, b); h[2] = h2_keep_sign(a, v.z); l[2] = b;
+    split2h(v.w * s, a, b); h[3] = h2_keep_sign(a, v.w); l[3] = b;
+    *reinterpret_cast<u16x4_t*>(p) = h;
+    *reinterpret_cast<f16x4_t*>(p + ps) = l;
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

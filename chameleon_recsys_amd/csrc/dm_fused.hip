@@ -36,7 +36,8 @@ struct DmfParams {
     const float* dS1; int lds1;                 // [Rc, 128]
     const __bf16* W; long long w_ps;            // planes of Ws1 [C, 128] as stored, plane stride in elements
     const float* Z2c; const float* pred;        // [Rc, C], [BT, C]
-    __bf16* out; long long out_ps;              // planes of dZ2 [Rc, C]
+    __bf16* out; long long out_ps;              // planes of dZ2 [Rc, C]: three bf16 planes, or (H2) two fp16 planes x the scale of osc
+    const H2Scale* osc;
     float* dpred; float* b2part;                // [BT, C]
     int C, BT, NC, PW;
 };
@@ -51,6 +52,9 @@ __device__ __forceinline__ void dmf_dma_one(unsigned lds, unsigned voff, const u
         : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r) : "memory");
 }
 
+// H2: the output as two fp16 planes x a power-of-two scale (csrc/gemm_h2.hip) instead of three bf16 planes; the kernel's own products
+// (dS1 x Ws1, K = 128: 12 % of its time) stay six bf16 plane products - its time is the 1 GB of Z2 in and the planes out.
+template <bool H2>
 __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char dmf_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -90,8 +94,10 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                                                                         (unsigned)((size_t)rows_valid * C * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t ow[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-        ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + q * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
+    for (int q = 0; q < 3; ++q)        // (H2: two planes of 16-bit elements - the third descriptor is never used)
+        ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + (H2 && q == 2 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
+    float osc = 1.f;
+    if constexpr (H2) osc = p.osc->scale;
 
     // ---- B: LDS-DMA of Ws1's planes.  Half-stage image per plane: [slot 0..127][64 k] (128 B per slot), slot = j * 32 + n holds Ws1 row
     // n0 + 4 n + j; the eight 16-byte pieces of a slot are XOR-ed with (slot >> 1) & 7 (conflict-free ds_read_b128 fragments).  One
@@ -200,7 +206,15 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                 const float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
                 float2 o;
                 o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
-                {
+                if constexpr (H2) {
+                    _Float16 h0, l0, h1, l1;
+                    split2h(o.x * osc, h0, l0); split2h(o.y * osc, h1, l1);
+                    const unsigned ph = (unsigned)h2_keep_sign(h0, o.x) | ((unsigned)h2_keep_sign(h1, o.y) << 16);
+                    const unsigned pl = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    const unsigned oo = (r * (unsigned)C + (unsigned)col) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b32(ph, ow[0], oo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pl, ow[1], oo, 0, 0);
+                } else {
                     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                     bf16x2_t ph, pm, pl;
                     __bf16 a, b, c;
@@ -260,11 +274,12 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 // dS1 [BT * (1 + N), 128] (row stride lds1), planes of Ws1 [C, 128] (cham_split3 of the weight as stored), Z2c [BT * (1 + N), C], pred
 // [BT, C] -> planes of dZ2 (plane stride out_plane_stride elements), dpred_pre [BT, C], col_part [BT, C] (may be NULL).
 // Takes C % 64 == 0, 32 <= 1 + N <= 256 and K = 128 (the reference's matching_dense_layer_1 width); -EINVAL otherwise (the caller
-// keeps cham_gemm_f32x3 + cham_mulpred_bwd_p3).
-extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
-                                  const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, float* dpred_pre,
-                                  float* col_part, void* stream) {
-    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0) return -CHAM_ERR_ARG;
+// keeps cham_gemm_f32x3 + cham_mulpred_bwd_p3 / _h2).
+template <bool H2>
+static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
+                             const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
+                             float* dpred_pre, float* col_part, void* stream) {
+    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || (H2 && !out_scale_rec)) return -CHAM_ERR_ARG;
     const int NC = N + 1;
     if (K != 128 || (C % DMF_COLS) || C <= 0 || NC < 32 || NC > 256 || (lds1 & 3) || lds1 < K || (out_plane_stride & 3) || (w_plane_stride & 7))
         return -CHAM_ERR_ARG;
@@ -272,16 +287,32 @@ extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void*
     if (BT == 0) return CHAM_OK;
     DmfParams p;
     p.dS1 = dS1; p.lds1 = lds1; p.W = reinterpret_cast<const __bf16*>(Wp); p.w_ps = w_plane_stride; p.Z2c = Z2c; p.pred = pred;
-    p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.dpred = dpred_pre; p.b2part = col_part;
+    p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.osc = reinterpret_cast<const H2Scale*>(out_scale_rec);
+    p.dpred = dpred_pre; p.b2part = col_part;
     p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
     constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
+    auto k = k_dm_mulpred_fused<H2>;
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dm_mulpred_fused), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return -CHAM_ERR_LAUNCH;
         done = true;
     }
-    hipLaunchKernelGGL(k_dm_mulpred_fused, dim3((BT + p.PW - 1) / p.PW), dim3(512), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k, dim3((BT + p.PW - 1) / p.PW), dim3(512), smem, (hipStream_t)stream, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+
+extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
+                                  const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, float* dpred_pre,
+                                  float* col_part, void* stream) {
+    return dm_mulpred_launch<false>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, nullptr, dpred_pre, col_part, stream);
+}
+
+// as cham_dm_mulpred_p3 with dZ2 written as TWO fp16 planes x the scale of `out_scale_rec` (an H2Scale record holding a bound of
+// max |dS1 Ws1^T|: cham_h2_scale_rownorm)
+extern "C" int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
+                                  const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
+                                  float* dpred_pre, float* col_part, void* stream) {
+    return dm_mulpred_launch<true>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream);
 }

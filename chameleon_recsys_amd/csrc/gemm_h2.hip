@@ -1,0 +1,552 @@
+// fp32-grade GEMM over operands that live in HBM as TWO fp16 planes + a power-of-two scale (round 4; gfx950, wave64).
+//
+//   x = (x_h + x_l) / s_x  (split2h of common.h),   C = (a_h b_h + a_h b_l + a_l b_h) / (s_a s_b), fp32 accumulate
+//
+// Why: the three candidate-row CAR GEMMs of the step (nar_model.py:374-405 of the reference: CAR forward, its dgrad, the W2 weight
+// gradient - 86 % of the step's FLOPs) ran as SIX bf16 plane products per fp32 product (csrc/gemm_p3.hip) with the matrix pipe busy
+// 73-81 % of the cycles and the chip clocking at 1.6 GHz: power-limited, so the only lever left was issuing fewer MFMAs
+// (profiles/r03_notes.md section 1).  fp16 carries 11 significand bits against bf16's 8: two planes hold 22 bits and THREE products
+// (the dropped a_l b_l term is <= 2^-22 |a b|) give a dot-product error of the native fp32 MFMA's class - what that costs is fp16's
+// 5-bit exponent, paid by a per-matrix power-of-two scale that the matrix's PRODUCER derives on the device from a rigorous bound of
+// max |x| (k_h2_scale_* below; no host synchronisation): |x s| <= 2^15 < 65 504, elements within 2^-18 of the bound keep all 22
+// bits, smaller ones an absolute error <= 2^-40 of the bound (fp16 subnormals are kept).  Planes are 4 B / element - the footprint
+// of the fp32 matrix they replace, 2/3 of the three bf16 planes.  tests/test_split2h_cpu.py (arithmetic), tests/test_gemm_h2_gpu.py
+// (error next to the native fp32 MFMA on the same operands, against float64).
+//
+//   NT  C[M,N] = epi(A[M,K] B[N,K]^T)    planes k-contiguous: CAR forward (B = planes of W2^T), CAR dgrad (B = planes of W2)
+//   TN  C[M,N] = A[K,M]^T B[K,N]         planes with the FREE index contiguous (W2 wgrad: Z1^T dZ2, K = candidate rows); split-K
+//
+// Core = the LDS-DMA core of gemm_p3.hip (256 x 256 x 16 tile, 8 waves as 2 x 4, 4 x 2 MFMA tiles of 32x32x16 per wave, slabs of
+// 8 KB with the same source-side swizzles, `buffer_load_dwordx4 ... lds`), re-cut for four slabs per 16-k chunk:
+//   stage = (A_h, A_l, B_h, B_l) = 32 KB; ring of FOUR stages = 128 KB of LDS, one workgroup per CU.
+//   step i (slot i & 3):
+//     top   DMA of chunk i + 3 into slot (i + 3) & 3 (its last reader was P0 of step i - 1, separated by that step's barrier)
+//     P0    A_l x B_h | reads the LATE fragments of chunk i (A_h, B_l)
+//     P1    A_h x B_h
+//     mid   s_waitcnt vmcnt(8) - this wave's requests for chunk i + 1 have landed, the eight of chunks i + 2, i + 3 stay in flight -
+//           then s_barrier
+//     P2    A_h x B_l | reads the EARLY fragments of chunk i + 1 (B_h, A_l) into the registers whose last use has passed
+//   Per step and wave: 24 MFMAs, 12 ds_read_b128 (24 ds_read_b64_tr_b16 for TN), 4 DMA requests, one barrier; 128 accumulator + 48
+//   fragment registers.  A request has 2.5 steps (~3 800 cycles at two waves per SIMD) to land.
+// Epilogues: x 1/(s_a s_b), then plain | + bias | + bias -> tanh (CAR forward) | x leaky'(sign of the saved activation's h plane) (CAR
+// dgrad) | split-K partial (wgrad; partials are stored unscaled-back, i.e. in true units: the shared fixed-order reduction adds them).
+#include "gemm_shared.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef short h2_s16x4 __attribute__((ext_vector_type(4)));
+
+struct H2Params {
+    const _Float16* A; const _Float16* B;      // plane 0 (h) of each operand; plane 1 (l) `*_ps` elements further
+    long long a_ps, b_ps;
+    int lda, ldb;
+    const float* sa; const float* sb;          // H2Scale records of the operands (device): [1] = 1 / scale
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const unsigned short* dref; int ldr;       // h plane of the saved activation (dgrad)
+    int kchunk, splits; float* partial;
+    int nbm, nbn, xcd_split, accumulate;
+};
+
+#define H2_SLAB 8192
+#define H2_STAGE (4 * H2_SLAB)
+#define H2_RING 4
+
+__device__ __forceinline__ u32x4 h2_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r.x = (unsigned)a; r.y = (unsigned)(a >> 32) & 0xFFFFu; r.z = bytes; r.w = 0x00020000u;
+    return r;
+}
+
+// four LDS-DMA requests of one stage: 16 bytes per lane, LDS destination = M0 + lane * 16 (wave-uniform), source = descriptor base +
+// voffset (per lane; the K advance is part of it so that the descriptor's range check sees it).  M0 is compiler-reserved: saved and
+// restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void h2_dma_stage(unsigned lds0, unsigned va, unsigned vb, const u32x4& ra0, const u32x4& ra1, const u32x4& rb0,
+                                             const u32x4& rb1) {
+    unsigned keep;
+    const unsigned l1 = lds0 + H2_SLAB, l2 = lds0 + 2 * H2_SLAB, l3 = lds0 + 3 * H2_SLAB;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, 0 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, 0 offen lds\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %9, 0 offen lds\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %10, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds0), "s"(l1), "s"(l2), "s"(l3), "v"(va), "v"(vb), "s"(ra0), "s"(ra1), "s"(rb0), "s"(rb1)
+        : "memory");
+}
+
+template <bool TN>
+__device__ __forceinline__ half8 h2_frag(const unsigned char* __restrict__ s) {
+    if constexpr (!TN) {
+        return *reinterpret_cast<const half8*>(s);
+    } else {
+        typedef __attribute__((address_space(3))) h2_s16x4 lds_s4;
+        const h2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(s));
+        const h2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(s + 4 * 512));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(half8, v);
+    }
+}
+
+// LDS-only barrier: builtins so that the wait-count pass sees the drain; vmcnt is handled by hand (the DMA requests are invisible to
+// the compiler).
+__device__ __forceinline__ void h2_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[i][j][e] = element (row wm0 + 32 i + (e & 3) + 8 (e >> 2) + 4 kl, column wn0 + 32 j + fl) of the tile at (m0, n0)
+template <int EPI, int TM, int TNN>
+__device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[TM][TNN], int m0, int n0, int wm0, int wn0, int split, int lane) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kl = lane_e >> 5, fl = lane_e & 31;
+    // back to true units: two exact power-of-two factors, applied one after the other (their product could leave the fp32 range)
+    const float ia = p.sa[1], ib = p.sb[1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * ia) * ib;
+    if constexpr (EPI == 3) {
+        // dgrad: x leaky'(saved activation); the activation's sign is the h plane's bit pattern read as a signed 16-bit integer
+        // (positive and non-zero <=> > 0; split2h keeps the sign of a value that underflows)
+        const int limM = p.M - m0, limN = p.N - n0;
+        const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
+        const __amdgpu_buffer_rsrc_t dw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) {
+                const int col = wn0 + j * 32 + fl;
+                const bool cok = col < limN;
+                unsigned short y[16];
+                unsigned offs[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                    const bool ok = cok && row < limM;
+                    offs[e] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
+                    y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u : OOB_OFF, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
+                }
+            }
+    } else {
+        GemmParams g;
+        g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
+        g.bias = p.bias; g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1;
+        g.accumulate = p.accumulate; g.kchunk = p.kchunk; g.splits = p.splits; g.partial = p.partial; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
+        gemm_epilogue<EPI, TM, TNN>(g, acc, m0, n0, wm0, wn0, split, kl, fl);
+    }
+}
+
+// EPI: 0 plain (/ accumulate), 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias, 6 split-K partial
+template <bool TN, int EPI>
+__global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
+    constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TNN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char h2_smem[];
+
+    const int nwg = p.nbm * p.nbn;
+    int tile_m, tile_n, split;
+    if (p.xcd_split) {                                 // one K-split per XCD (gemm.hip): every K panel is fetched from HBM once
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+        split = (lin & 7) + 8 * (slot / nwg);
+        const int t = slot % nwg;
+        tile_m = t / p.nbn; tile_n = t % p.nbn;
+    } else {                                           // XCD-aware bijective swizzle: the column tiles of an A panel share an L2
+        const int id = blockIdx.x;
+        const int q = nwg / 8, rr = nwg % 8, xcd = id % 8;
+        const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + id / 8;
+        tile_m = swz / p.nbn; tile_n = swz % p.nbn;
+        split = blockIdx.y;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+    // ---- descriptors (one per plane: rows / k-rows beyond the operand arrive as zeros) and per-lane source offsets
+    u32x4 ra[2], rb[2];
+    unsigned va, vb, stepa, stepb;
+    if constexpr (!TN) {
+        // (the window starts kbeg elements into the first row: it ends that much earlier, so that requests past the reduction range
+        // - issued, never consumed - cannot leave the operand's allocation)
+        const size_t aall = (size_t)max(p.M - m0, 0) * p.lda * 2, ball = (size_t)max(p.N - n0, 0) * p.ldb * 2, koff = (size_t)kbeg * 2;
+        const size_t abytes = aall > koff ? aall - koff : 0, bbytes = ball > koff ? ball - koff : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda + kbeg, (unsigned)min(abytes, (size_t)0xFFFFFFF0u));
+            rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)n0 * p.ldb + kbeg, (unsigned)min(bbytes, (size_t)0xFFFFFFF0u));
+        }
+        // lane l of wave w fills LDS piece (row 32 w + l / 2, half l & 1); that piece holds source half (l & 1) ^ bit 3 of the row
+        const int row = 32 * wave + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+        va = ((unsigned)row * (unsigned)p.lda + 8u * half) * 2u;
+        vb = ((unsigned)row * (unsigned)p.ldb + 8u * half) * 2u;
+        stepa = stepb = BK * 2;
+    } else {
+        const size_t abytes = (size_t)max(kend - kbeg, 0) * p.lda * 2, bbytes = (size_t)max(kend - kbeg, 0) * p.ldb * 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {      // (M, N multiples of 256: the m / n extent of a tile never leaves its k-row)
+            ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)kbeg * p.lda + m0, (unsigned)min(abytes > (size_t)m0 * 2 ? abytes - (size_t)m0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+            rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)kbeg * p.ldb + n0, (unsigned)min(bbytes > (size_t)n0 * 2 ? bbytes - (size_t)n0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+        }
+        // lane l of wave w fills LDS piece (k-row 2 w + l / 32, piece l & 31); its 64-byte group index is XOR-ed with k & 3
+        const int k = 2 * wave + (lane >> 5), jp = lane & 31, j = ((((jp >> 2) ^ (k & 3)) << 2) | (jp & 3));
+        va = ((unsigned)k * (unsigned)p.lda + 8u * j) * 2u;
+        vb = ((unsigned)k * (unsigned)p.ldb + 8u * j) * 2u;
+        stepa = (unsigned)BK * (unsigned)p.lda * 2u; stepb = (unsigned)BK * (unsigned)p.ldb * 2u;
+    }
+
+    // ---- per-lane fragment offsets inside a slab (gemm_p3.hip's layouts: 16-bit elements, the element type does not matter)
+    unsigned fa[TM], fb[TNN];
+    if constexpr (!TN) {
+        const int l31 = lane & 31;
+        const unsigned fo = (unsigned)l31 * 32u + (unsigned)((lane >> 5) ^ ((l31 >> 3) & 1)) * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)(wm0 + 32 * i) * 32u + fo;
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)(wn0 + 32 * j) * 32u + fo;
+    } else {
+        const int i16 = lane & 15, kq = 8 * (lane >> 5) + (i16 >> 2);
+        const unsigned within = 32u * ((lane >> 4) & 1) + 8u * (i16 & 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)kq * 512u + (unsigned)((((wm0 >> 5) + i) ^ (kq & 3))) * 64u + within;
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)kq * 512u + (unsigned)((((wn0 >> 5) + j) ^ (kq & 3))) * 64u + within;
+    }
+
+    floatx16 acc[TM][TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)h2_smem;
+    const unsigned wave_off = (unsigned)wave * 1024u;
+    half8 AH[TM], AL[TM], BH[TNN], BL[TNN];
+
+    auto mma = [&](const half8 (&X)[TM], const half8 (&Y)[TNN]) {
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[ii], Y[j], acc[ii][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nk > 0) {
+        // prologue: chunks 0, 1, 2 (a chunk beyond the reduction range is requested all the same - it is never consumed, and the wait
+        // counts stay the same in every step)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            h2_dma_stage(lds_base + (unsigned)s * H2_STAGE + wave_off, va, vb, ra[0], ra[1], rb[0], rb[1]);
+            va += stepa; vb += stepb;
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        h2_barrier();
+        {   // early fragments of chunk 0
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(h2_smem + 2 * H2_SLAB + fb[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) AL[i] = h2_frag<TN>(h2_smem + 1 * H2_SLAB + fa[i]);
+        }
+        int cur = 0;                                    // slot of chunk i
+        for (int i = 0; i < nk; ++i) {
+            const int nxt = (cur + 1) & (H2_RING - 1), nx3 = (cur + 3) & (H2_RING - 1);
+            const unsigned char* Sc = h2_smem + cur * H2_STAGE;
+            const unsigned char* Sn = h2_smem + nxt * H2_STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            // top: chunk i + 3
+            h2_dma_stage(lds_base + (unsigned)nx3 * H2_STAGE + wave_off, va, vb, ra[0], ra[1], rb[0], rb[1]);
+            va += stepa; vb += stepb;
+            __builtin_amdgcn_sched_barrier(0);
+            // P0: A_l x B_h; late fragments of this chunk
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AH[ii] = h2_frag<TN>(Sc + 0 * H2_SLAB + fa[ii]);
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BL[j] = h2_frag<TN>(Sc + 3 * H2_SLAB + fb[j]);
+            mma(AL, BH);
+            // P1: A_h x B_h
+            mma(AH, BH);
+            // mid: this wave's requests for chunk i + 1 have landed (the eight of chunks i + 2, i + 3 stay in flight); after the barrier
+            // every wave's have
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            h2_barrier();
+            // P2: A_h x B_l; early fragments of chunk i + 1 into the registers that are dead
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(Sn + 2 * H2_SLAB + fb[j]);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AL[ii] = h2_frag<TN>(Sn + 1 * H2_SLAB + fa[ii]);
+            mma(AH, BL);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
+    }
+
+    h2_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, split, lane);
+}
+
+// ================================================================================================================================
+// Scales.  A record (H2Scale, 32 bytes, zero-initialised once by the caller) receives {scale, 1 / scale, bound}; words 4-6 are the
+// kernels' scratch (running maxima as the bit patterns of non-negative floats - monotone as unsigned integers - and a ticket): every
+// workgroup folds its maximum in with atomicMax (order-independent: bit-reproducible), the LAST one to finish - atomic ticket behind a
+// __threadfence - derives the scale and clears the scratch for the next launch on the same record.
+__device__ __forceinline__ void h2_finish_scale(H2Scale* rec, float bound) {
+    float s = 1.f, inv = 1.f;
+    if (bound > 0.f && bound < __builtin_inff()) {
+        int e;
+        (void)frexpf(bound, &e);                       // bound = m 2^e, 0.5 <= m < 1  ->  bound 2^(15 - e) in [2^14, 2^15)
+        int k = 15 - e;
+        k = k < -110 ? -110 : (k > 110 ? 110 : k);     // scale and 1 / scale stay normal fp32 numbers
+        s = ldexpf(1.f, k); inv = ldexpf(1.f, -k);
+    }
+    rec->scale = s; rec->inv = inv; rec->bound = bound;
+}
+
+__device__ __forceinline__ float h2_block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, red[i]);
+    __syncthreads();
+    return t;
+}
+
+// bound = max |x0| + max |x1| (x1 may be NULL): a sum of two matrices (PreCAR output = leaky(U + V), |leaky(t)| <= |t|), or one matrix
+__global__ __launch_bounds__(256) void k_h2_scale_absmax(const float* __restrict__ x0, size_t n0, const float* __restrict__ x1, size_t n1,
+                                                         H2Scale* __restrict__ rec) {
+    __shared__ float red[4];
+    __shared__ unsigned last;
+    float m0 = 0.f, m1 = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n0 / 4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x0)[i];
+        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (x1)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n1 / 4; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x1)[i];
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    m0 = h2_block_max(m0, red);
+    m1 = h2_block_max(m1, red);
+    if (threadIdx.x == 0) {
+        atomicMax(&rec->max_bits, __float_as_uint(m0));
+        atomicMax(&rec->pad1, __float_as_uint(m1));
+        __threadfence();
+        last = atomicAdd(&rec->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        if (last) {
+            __threadfence();
+            const float a = __uint_as_float(atomicMax(&rec->max_bits, 0u)), b = __uint_as_float(atomicMax(&rec->pad1, 0u));
+            h2_finish_scale(rec, a + b);
+            rec->max_bits = 0u; rec->pad1 = 0u; rec->ticket = 0u;
+        }
+    }
+}
+
+// bound = max over rows of ||X[r, 0:K]||_2, times *factor when given: the Cauchy-Schwarz bound of |d[r,:] . w[c,:]| over all (r, c) is
+// (max row norm of d) x (max row norm of w).  K == 128: half a wave per row; otherwise a wave per row.
+__global__ __launch_bounds__(256) void k_h2_scale_rownorm(const float* __restrict__ X, long R, int K, int ld, const float* __restrict__ factor,
+                                                          H2Scale* __restrict__ rec) {
+    __shared__ float red[4];
+    __shared__ unsigned last;
+    const int lane = threadIdx.x & 63;
+    const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    float mx = 0.f;
+    if (K == 128) {
+        const int hl = lane & 31, hw = lane >> 5;
+        for (long r = 2 * wave_g + hw; r < R; r += 2 * nwaves) {
+            const float4 v = reinterpret_cast<const float4*>(X + (size_t)r * ld)[hl];
+            float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            mx = fmaxf(mx, s);
+        }
+    } else {
+        for (long r = wave_g; r < R; r += nwaves) {
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) { const float v = X[(size_t)r * ld + k]; s += v * v; }
+            mx = fmaxf(mx, wave_sum(s));
+        }
+    }
+    mx = h2_block_max(mx, red);
+    if (threadIdx.x == 0) {
+        atomicMax(&rec->max_bits, __float_as_uint(mx));
+        __threadfence();
+        last = atomicAdd(&rec->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        if (last) {
+            __threadfence();
+            const float sq = __uint_as_float(atomicMax(&rec->max_bits, 0u));
+            // (1 + 2^-10): the row norms are fp32 sums and the product they bound is computed in plane arithmetic - a bound must not
+            // be missed by a rounding
+            const float b = sqrtf(sq) * (factor ? *factor : 1.f) * 1.0009765625f;
+            h2_finish_scale(rec, b);
+            rec->max_bits = 0u; rec->ticket = 0u;
+        }
+    }
+}
+
+extern "C" int cham_h2_scale_absmax(const float* x0, size_t n0, const float* x1, size_t n1, void* rec, void* stream) {
+    if (!x0 || !rec || (n0 & 3) || (x1 && (n1 & 3)) || (((uintptr_t)x0 | (uintptr_t)x1) & 15) || ((uintptr_t)rec & 15)) return -CHAM_ERR_ARG;
+    size_t n = n0 > n1 ? n0 : n1;
+    int blocks = (int)((n / 4 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(k_h2_scale_absmax, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x0, n0, x1, x1 ? n1 : (size_t)0, reinterpret_cast<H2Scale*>(rec));
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream) {
+    if (!X || !rec || R < 0 || K <= 0 || ld < K || ((uintptr_t)rec & 15)) return -CHAM_ERR_ARG;
+    if (K == 128 && ((ld & 3) || ((uintptr_t)X & 15))) return -CHAM_ERR_ARG;
+    const long per = K == 128 ? 8 : 4;                 // rows per workgroup and pass
+    long blocks = (R + per - 1) / per;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_h2_scale_rownorm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, R, K, ld, factor, reinterpret_cast<H2Scale*>(rec));
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// ---- split of an fp32 matrix into its two planes with the scale of `rec` (weights, once per step; test helper for whole operands)
+// dst[q][r][c] (plane stride ps) = plane q of X[r][c] * scale; dstT[q][c][r] likewise for the transposed matrix (either may be NULL)
+__global__ __launch_bounds__(256) void k_split2h(const float* __restrict__ X, int R, int Cc, int ld, _Float16* __restrict__ dst, long long ps,
+                                                 int ldd, _Float16* __restrict__ dstT, long long psT, int lddT, const H2Scale* __restrict__ rec) {
+    const float s = rec->scale;
+    const size_t n = (size_t)R * Cc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / Cc), c = (int)(i % Cc);
+        const float x = X[(size_t)r * ld + c];
+        _Float16 h, l;
+        split2h(x * s, h, l);
+        const unsigned short hb = h2_keep_sign(h, x);
+        if (dst) { _Float16* d = dst + (size_t)r * ldd + c; *reinterpret_cast<unsigned short*>(d) = hb; d[ps] = l; }
+        if (dstT) { _Float16* d = dstT + (size_t)c * lddT + r; *reinterpret_cast<unsigned short*>(d) = hb; d[psT] = l; }
+    }
+}
+
+// scale from max |X| into rec (recompute = 1; 0: rec already holds the scale to use), then the split
+extern "C" int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT,
+                            long long plane_strideT, int lddT, void* rec, int recompute, void* stream) {
+    if (!X || R <= 0 || Cc <= 0 || (!dst && !dstT) || !rec || ((uintptr_t)rec & 15)) return -CHAM_ERR_ARG;
+    const size_t n = (size_t)R * Cc;
+    if (recompute) {
+        if (ld != Cc || (n & 3) || ((uintptr_t)X & 15)) return -CHAM_ERR_ARG;
+        const int rc = cham_h2_scale_absmax(X, n, nullptr, 0, rec, stream);
+        if (rc != CHAM_OK) return rc;
+    }
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_split2h, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, Cc, ld, reinterpret_cast<_Float16*>(dst), plane_stride,
+                       ldd, reinterpret_cast<_Float16*>(dstT), plane_strideT, lddT, reinterpret_cast<const H2Scale*>(rec));
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// launch counters: [0] NT launches, [1] TN launches, [6] epilogue and [7] K-splits of the last launch
+static long long g_h2_launches[8];
+extern "C" void cham_gemm_h2_launch_counts(long long* out8, int reset) {
+    for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_h2_launches[i]; if (reset) g_h2_launches[i] = 0; }
+}
+
+template <bool TN, int EPI>
+static int h2_launch(H2Params& p, hipStream_t st) {
+    g_h2_launches[6] = EPI; g_h2_launches[7] = p.splits;
+    constexpr int smem = H2_RING * H2_STAGE;
+    auto k = gemm_h2_kernel<TN, EPI>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return -CHAM_ERR_LAUNCH;
+        done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+// C[M,N] = epi((sum of the three plane products) / (s_a s_b)) - see the header.  A, B: plane 0 (fp16 h plane), the l plane
+// `*_plane_stride` elements further; a_scale / b_scale: the operands' H2Scale records (device memory, written by the kernels above).
+//   tn = 0 (NT): A [M, lda], B [N, ldb], k contiguous; K % 16 == 0.  bias (+ act = CHAM_ACT_TANH), or dref_h + dact = CHAM_ACT_LEAKY:
+//     x leaky'(saved activation) with dref_h the h plane [M, ldr] of that activation.
+//   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N]; M % 256 == 0, N % 256 == 0, any K; split-K through `workspace`
+//     (splits_hint: 1 none, 0 automatic, n at most n; fixed-order reduction), accumulate adds to C.
+// Returns -CHAM_ERR_ARG for shapes it does not take (the caller keeps cham_gemm_p3 / cham_gemm_f32x3 for those).
+extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                            int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                            const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                            void* stream) {
+    if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0) return -CHAM_ERR_ARG;
+    if ((lda & 7) || (ldb & 7) || (a_plane_stride & 7) || (b_plane_stride & 7) || (N & 3) || (ldc & 3)) return -CHAM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return -CHAM_ERR_ARG;
+    if ((size_t)ldc * 4 * 256 >= WINDOW_BYTES || (size_t)ldr * 2 * 256 >= WINDOW_BYTES) return -CHAM_ERR_ARG;
+    H2Params p;
+    p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(B); p.a_ps = a_plane_stride; p.b_ps = b_plane_stride;
+    p.lda = lda; p.ldb = ldb; p.sa = a_scale; p.sb = b_scale; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.dref = reinterpret_cast<const unsigned short*>(dref_h); p.ldr = ldr; p.partial = workspace; p.xcd_split = 0; p.accumulate = 0;
+    p.nbm = (M + 255) / 256; p.nbn = (N + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (!tn) {
+        if ((K & 15) || accumulate) return -CHAM_ERR_ARG;
+        if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
+        p.kchunk = K; p.splits = 1;
+        if (dref_h && (bias || act != ACT_NONE || dact != ACT_LEAKY)) return -CHAM_ERR_ARG;
+        if (act != ACT_NONE && !(bias && act == ACT_TANH)) return -CHAM_ERR_ARG;
+        ++g_h2_launches[0];
+        if (dref_h) return h2_launch<false, 3>(p, st);
+        if (bias) return act == ACT_TANH ? h2_launch<false, 2>(p, st) : h2_launch<false, 5>(p, st);
+        return h2_launch<false, 0>(p, st);
+    }
+    if ((M & 255) || (N & 255) || bias || act != ACT_NONE || dref_h) return -CHAM_ERR_ARG;
+    if ((size_t)16 * lda * 2 >= (1ull << 31) || (size_t)16 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
+    const long tiles = (long)p.nbm * p.nbn;
+    int splits = 1;
+    if (splits_hint != 1 && workspace) {
+        long want = splits_hint > 1 ? splits_hint : (tiles >= 192 ? 1 : (256 + tiles - 1) / tiles);      // one workgroup per CU
+        const long maxk = (K + 511) / 512;
+        if (want > maxk) want = maxk;
+        const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));
+        if (want > maxw) want = maxw;
+        if (splits_hint <= 0 && want >= 8) want = want / 8 * 8;      // (an explicit count is taken as given)
+        if (want > 1) splits = (int)want;
+    }
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = ((kchunk + 15) / 16) * 16;
+    p.kchunk = kchunk;
+    p.splits = (K + kchunk - 1) / kchunk;
+    if ((size_t)kchunk * (lda > ldb ? lda : ldb) * 2 >= 0xFFFFFFF0ull) return -CHAM_ERR_ARG;
+    ++g_h2_launches[1];
+    if (p.splits > 1) {
+        p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
+        const int rc = h2_launch<true, 6>(p, st);
+        if (rc != CHAM_OK) return rc;
+        GemmParams g;
+        g.A = nullptr; g.B = nullptr; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = 0; g.ldb = 0; g.ldc = ldc; g.bias = nullptr; g.act = ACT_NONE;
+        g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1; g.accumulate = accumulate;
+        g.kchunk = kchunk; g.splits = p.splits; g.partial = workspace; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
+        launch_splitk_reduce(g, st);
+        CHAM_CHECK_LAUNCH();
+        return CHAM_OK;
+    }
+    p.accumulate = accumulate;
+    return h2_launch<true, 0>(p, st);
+}

@@ -103,6 +103,37 @@ __global__ __launch_bounds__(256) void k_combine_fwd_cand_p3(const float* __rest
     }
 }
 
+// The same rows as TWO fp16 PLANES x the scale of `rec` (csrc/gemm_h2.hip; the record was filled from max |U| + max |V| by
+// cham_h2_scale_absmax): 4 bytes stored per element, no fp32 copy.
+__global__ __launch_bounds__(256) void k_combine_fwd_cand_h2(const float* __restrict__ U, const float* __restrict__ V, int C,
+                                                             int BT, int N, int pmax, const int* __restrict__ neg_slot,
+                                                             _Float16* __restrict__ Z1p /* plane 0, candidate rows */, long long ps,
+                                                             const H2Scale* __restrict__ rec) {
+    const int bt = blockIdx.x, NC = N + 1;
+    const float sc = rec->scale;
+    const float4* pu = reinterpret_cast<const float4*>(U + (size_t)bt * C);
+    _Float16* po = Z1p + (size_t)bt * NC * C;
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 a = pu[k];
+        for (int c0 = 0; c0 < NC; c0 += 4) {
+            float4 b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i < NC ? c0 + i : NC - 1;
+                b[i] = reinterpret_cast<const float4*>(V + (size_t)cand_vrow(bt, c, BT, N, pmax, neg_slot) * C)[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i >= NC) break;
+                float4 o;
+                o.x = act_fwd(a.x + b[i].x, ACT_LEAKY); o.y = act_fwd(a.y + b[i].y, ACT_LEAKY);
+                o.z = act_fwd(a.z + b[i].z, ACT_LEAKY); o.w = act_fwd(a.w + b[i].w, ACT_LEAKY);
+                st4_planes_h2(po + (size_t)(c0 + i) * C + 4 * k, ps, o, sc);
+            }
+        }
+    }
+}
+
 // dU[bt] = dpre[input bt] + sum_c dpre[cand (bt,c)];  dV_in[bt] = dpre[input bt];  dV_pos[bt] = dpre[cand (bt,0)]
 // (T = element type of the candidate rows: fp32, or bf16 in the bf16 configuration; the clicked-input rows are fp32 in both)
 template <typename T>
@@ -379,6 +410,37 @@ __global__ __launch_bounds__(256) void k_mulpred_bwd_p3(const float* __restrict_
     }
 }
 
+// The two-fp16-plane form (csrc/gemm_h2.hip): as k_mulpred_bwd_p3, the gradient at the CAR tanh stored as (h, l) planes x the scale of
+// `rec` (a bound of max |dM|: |pred| <= 1 and 1 - z^2 <= 1 only shrink it).
+__global__ __launch_bounds__(256) void k_mulpred_bwd_h2(const float* __restrict__ dM, const float* __restrict__ Z2c,
+                                                        const float* __restrict__ pred, int C, int N, float* __restrict__ dpred_pre,
+                                                        _Float16* __restrict__ dZ2p, long long ps, float* __restrict__ col_part,
+                                                        const H2Scale* __restrict__ rec) {
+    const int bt = blockIdx.x;
+    const float sc = rec->scale;
+    const float4* pp = reinterpret_cast<const float4*>(pred + (size_t)bt * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 p = pp[k];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c <= N; ++c) {
+            const size_t off = ((size_t)bt * (N + 1) + c) * C + 4 * k;
+            const float4 g = ld4(dM + off);
+            const float4 z = ld4(Z2c + off);
+            acc.x += g.x * z.x; acc.y += g.y * z.y; acc.z += g.z * z.z; acc.w += g.w * z.w;
+            float4 o;
+            o.x = g.x * p.x * (1.f - z.x * z.x); o.y = g.y * p.y * (1.f - z.y * z.y);
+            o.z = g.z * p.z * (1.f - z.z * z.z); o.w = g.w * p.w * (1.f - z.w * z.w);
+            cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+            st4_planes_h2(dZ2p + off, ps, o, sc);
+        }
+        float4 o;
+        o.x = acc.x * (1.f - p.x * p.x); o.y = acc.y * (1.f - p.y * p.y);
+        o.z = acc.z * (1.f - p.z * p.z); o.w = acc.w * (1.f - p.w * p.w);
+        reinterpret_cast<float4*>(dpred_pre + (size_t)bt * C)[k] = o;
+        if (col_part) reinterpret_cast<float4*>(col_part + (size_t)bt * C)[k] = cs;
+    }
+}
+
 // bf16 configuration: Mc[row] = bf16(Z2c[row] * pred[bt]) - the `cand (.) pred` product of nar_model.py:478-495 as the bf16 operand
 // of the scorer's first layer and of its weight gradient (the fp32 path fuses it into the GEMM's staging as a row scale)
 __global__ __launch_bounds__(256) void k_mul_rows_b16(const __bf16* __restrict__ Z2c, const float* __restrict__ pred, int C, int NC,
@@ -635,6 +697,26 @@ extern "C" int cham_mulpred_bwd_p3(const float* dM, const float* Z2c, const floa
     if (BT == 0) return CHAM_OK;
     hipLaunchKernelGGL(k_mulpred_bwd_p3, dim3(BT), dim3(256), 0, (hipStream_t)stream, dM, Z2c, pred, C, N, dpred_pre,
                        reinterpret_cast<__bf16*>(dZ2p), plane_stride, col_part);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                                   long long plane_stride, const void* scale_rec, void* stream) {
+    if (!U || !V || !neg_slot || !Z1p || !scale_rec || C <= 0 || (C & 3) || BT < 0 || N < 0 || (plane_stride & 3)) return -CHAM_ERR_ARG;
+    if (BT == 0) return CHAM_OK;
+    hipLaunchKernelGGL(k_combine_fwd_cand_h2, dim3(BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
+                       reinterpret_cast<_Float16*>(Z1p), plane_stride, reinterpret_cast<const H2Scale*>(scale_rec));
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
+extern "C" int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,
+                                   long long plane_stride, float* col_part, const void* scale_rec, void* stream) {
+    if (!dM || !Z2c || !pred || !dpred_pre || !dZ2p || !scale_rec || C <= 0 || (C & 3) || BT < 0 || N < 0 || (plane_stride & 3)) return -CHAM_ERR_ARG;
+    if (BT == 0) return CHAM_OK;
+    hipLaunchKernelGGL(k_mulpred_bwd_h2, dim3(BT), dim3(256), 0, (hipStream_t)stream, dM, Z2c, pred, C, N, dpred_pre,
+                       reinterpret_cast<_Float16*>(dZ2p), plane_stride, col_part, reinterpret_cast<const H2Scale*>(scale_rec));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

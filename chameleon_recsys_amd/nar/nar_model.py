@@ -191,6 +191,10 @@ class NARRuntime:
         # their producers, W2 / W2^T get plane shadows once per step; same six plane products as gemm_x3.hip.  CHAM_GEMM_P3=0: the
         # on-the-fly split for those three GEMMs too (A/B arm; also what shapes gemm_p3 does not take fall back to)
         self.p3 = self.x3 and os.environ.get("CHAM_GEMM_P3", "1") == "1" and self.layout.C % 256 == 0
+        # two-fp16-plane form of those three GEMMs (csrc/gemm_h2.hip, round 4): planes (h, l) x a power-of-two scale derived on the device
+        # from a bound of the matrix, THREE plane products instead of six - the kernels were power-limited, so halving the MFMA count is
+        # what moves them; same float64-error bar as the six-product form (tests/test_gemm_h2_gpu.py).  CHAM_GEMM_H2=0: the three-bf16-plane arm
+        self.h2 = self.p3 and os.environ.get("CHAM_GEMM_H2", "1") == "1"
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -291,8 +295,12 @@ class NARRuntime:
         self.b16_dma = self.gemm_dtype == 'bf16' and os.environ.get("CHAM_B16_DMA", "1") == "1" and L.C % 256 == 0
         if self.p3:
             C_ = L.C
-            self.w2p = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)       # planes of W2 as stored (CAR dgrad)
-            self.w2tp = torch.zeros(3, C_, C_, dtype=torch.bfloat16, device=dev)      # planes of W2^T (CAR forward)
+            npl, pdt = (2, torch.float16) if self.h2 else (3, torch.bfloat16)
+            self.w2p = torch.zeros(npl, C_, C_, dtype=pdt, device=dev)       # planes of W2 as stored (CAR dgrad)
+            self.w2tp = torch.zeros(npl, C_, C_, dtype=pdt, device=dev)      # planes of W2^T (CAR forward)
+            if self.h2:      # H2Scale records (32 bytes each, zero-initialised): W2's scale; max row norm of Ws1 (factor of the dZ2 bound)
+                self.sc_w2 = torch.zeros(8, dtype=torch.float32, device=dev)
+                self.sc_ws1n = torch.zeros(8, dtype=torch.float32, device=dev)
             # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip); CHAM_DM_FUSED=0: the two separate kernels
             self.dm_fused = os.environ.get("CHAM_DM_FUSED", "1") == "1" and L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
             self.ws1p = torch.zeros(3, C_, 128, dtype=torch.bfloat16, device=dev)     # planes of Ws1 as stored
@@ -338,9 +346,17 @@ class NARRuntime:
         key = (self.global_step, self.weights_version)
         if not (self.b16 or self.p3) or key == self._shadow_key:
             return
-        if self.p3:
+        if self.h2:
+            C = self.layout.C
+            check(self.lib.cham_split2h(ptr(self.p('W2')), C, C, C, ptr(self.w2p), C * C, C, ptr(self.w2tp), C * C, C, ptr(self.sc_w2), 1, _stream()),
+                  "cham_split2h")
+            k1 = self.layout.entries['Ws1'].shape[1]
+            check(self.lib.cham_h2_scale_rownorm(ptr(self.p('Ws1')), C, k1, k1, None, ptr(self.sc_ws1n), _stream()), "cham_h2_scale_rownorm")
+        elif self.p3:
             C = self.layout.C
             check(self.lib.cham_split3(ptr(self.p('W2')), C, C, C, ptr(self.w2p), C * C, C, ptr(self.w2tp), C * C, C, _stream()), "cham_split3")
+        if self.p3:
+            C = self.layout.C
             if self.dm_fused:
                 check(self.lib.cham_split3(ptr(self.p('Ws1')), C, 128, 128, ptr(self.ws1p), C * 128, 128, None, 0, 0, _stream()), "cham_split3")
         if self.b16:
@@ -374,15 +390,15 @@ class NARRuntime:
     def plan(self, B, T, N, n_buf, Bg=None):
         """Buffers for one batch shape, cached: ragged hourly files produce a handful of padded lengths T.  Least-recently-used
         plans are dropped one at a time (count / byte budget), never all at once."""
-        key = (B, T, N, n_buf, Bg or B)
+        key = (B, T, N, n_buf, Bg or B, self.p3, self.h2)      # (the plane buffers of a plan follow the arithmetic it was built for)
         pl = self._plans.pop(key, None)
         if pl is None:
-            need = StepPlan.estimate_bytes(self.layout, B, T, N)
+            need = StepPlan.estimate_bytes(self.layout, B, T, N, self)
             while self._plans and (len(self._plans) >= self.max_plans or
                                    need + sum(p.nbytes for p in self._plans.values()) > self.plan_bytes_budget):
                 self._plans.pop(next(iter(self._plans)))          # oldest entry (dicts keep insertion order)
             pl = StepPlan(self, B, T, N, n_buf, Bg or B)
-            pl.nbytes = need
+            pl.nbytes = pl.allocated_bytes()                       # what the eviction above counts for the plans already cached
         self._plans[key] = pl                                      # (re)insert as most recently used
         return pl
 
@@ -497,6 +513,26 @@ class NARRuntime:
             prof.append(dict(M=M, N=N, K=K, transA=tn, transB=0 if tn else 1, splits=int(c[7]), act=act, dref=dref_h is not None, dact=dact,
                              bias=bias is not None, rowscale=False, bf16=False, p3=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
 
+    def gemm_h2(self, A, a_ps, lda, a_sc, B, b_ps, ldb, b_sc, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
+                accumulate=0, splits=1):
+        """Plane-product GEMM over two fp16 planes + scale records (csrc/gemm_h2.hip): NT (tn=0) or TN (tn=1, split-K)."""
+        ws = None
+        if splits != 1:
+            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+        prof = self.profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(self.lib.cham_gemm_h2(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
+                                    ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_h2")
+        if prof is not None:
+            e1.record()
+            import ctypes
+            c = (ctypes.c_longlong * 8)()
+            self.lib.cham_gemm_h2_launch_counts(c, 0)
+            prof.append(dict(M=M, N=N, K=K, transA=tn, transB=0 if tn else 1, splits=int(c[7]), act=act, dref=dref_h is not None, dact=dact,
+                             bias=bias is not None, rowscale=False, bf16=False, h2=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
+
     def _tile_counts_b16(self):
         import ctypes
         out = (ctypes.c_longlong * 8)()
@@ -526,10 +562,38 @@ class StepPlan:
     """Device buffers for one (B, T, N) shape.  Row layouts: see csrc/scorer.hip."""
 
     @staticmethod
-    def estimate_bytes(L, B, T, N):
-        """Dominant buffers only: Z1, Z2, dZ1, dZ2 over all CAR rows + the scorer activations over the candidate rows."""
+    def estimate_bytes(L, B, T, N, rt=None):
+        """Dominant buffers only (decides what to evict BEFORE the plan exists; the plan then records what it really allocated):
+        Z1, Z2, dZ1, dZ2 over all CAR rows + the scorer activations over the candidate rows + the plane-resident operands of the
+        candidate-row CAR GEMMs (Z1 and dZ2 as two fp16 / three bf16 planes), the b2 partial sums and the segment table."""
         rows = B * T * (N + 2)
-        return 4 * (4 * rows * L.C + 2 * rows * (128 + 64 + 32))        # (the bf16 configuration needs ~5/8 of this)
+        need = 4 * (4 * rows * L.C + 2 * rows * (128 + 64 + 32))        # (the bf16 configuration needs ~5/8 of this)
+        if rt is not None and rt.p3:
+            rc = B * T * (N + 1)
+            need += 2 * (2 if rt.h2 else 3) * 2 * rc * L.C + 4 * B * T * L.C
+            need += 4 * int(rt.lib.cham_group_rows_segments_len(2 * B * T + 20 * N + 1))
+        return need
+
+    def allocated_bytes(self):
+        """Bytes of device memory this plan holds (every tensor attribute, lists and dicts of tensors included)."""
+        seen, total = set(), 0
+
+        def walk(x):
+            nonlocal total
+            if torch.is_tensor(x):
+                st = x.untyped_storage()
+                if st.data_ptr() not in seen:
+                    seen.add(st.data_ptr())
+                    total += st.nbytes()
+            elif isinstance(x, (list, tuple)):
+                for y in x:
+                    walk(y)
+            elif isinstance(x, dict):
+                for y in x.values():
+                    walk(y)
+        for v in vars(self).values():
+            walk(v)
+        return total
 
     def __init__(self, rt, B, T, N, n_buf, Bg):
         L, dev = rt.layout, rt.device
@@ -579,13 +643,23 @@ class StepPlan:
             self.Z1, self.Z2, self.dZ2, self.dZ1 = f32(BT, C), f32(BT, C), f32(BT, C), f32(BT, C)
             self.Z1c, self.Z2c, self.dZ2c, self.dZ1c, self.Mc = bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C)
         else:         # one [BT + Rc, C] matrix each: clicked-input rows first (Z1c ... are views taken per step: BT = valid positions)
-            self.Z1 = f32(Rall, C)
+            # With the plane-resident CAR GEMMs the candidate rows of Z1 exist as planes only, and with the fused scorer dgrad those of
+            # dZ2 too: the fp32 matrices keep the clicked-input rows (ensure_rows() grows them on the paths that do need all rows -
+            # dropout, NC outside the fused kernel's range)
+            fused = rt.p3 and rt.dm_fused and 32 <= NC <= 256
+            self.Z1 = f32(BT if rt.p3 else Rall, C)
             self.Z2 = f32(Rall, C)
-            self.dZ2 = f32(Rall, C)
+            self.dZ2 = f32(BT if fused else Rall, C)
             self.dZ1 = f32(Rall, C)
         self.p3 = rt.p3
+        self.h2 = rt.h2
         if rt.p3:     # plane-resident operands of the three candidate-row CAR GEMMs (planes Rc * C elements apart) + b2 partial sums
-            self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
+            if rt.h2:      # two fp16 planes + the scale records of the two matrices
+                self.Z1p, self.dZ2p = (torch.empty(2, Rc, C, dtype=torch.float16, device=dev) for _ in range(2))
+                self.sc_z1 = torch.zeros(8, dtype=torch.float32, device=dev)
+                self.sc_dz2 = torch.zeros(8, dtype=torch.float32, device=dev)
+            else:
+                self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
             self.p3_ps = Rc * C
             self.b2part = f32(BT, C)
         # RNN
@@ -630,8 +704,19 @@ class StepPlan:
         self.created = torch.cuda.Event()
         self.created.record()
 
+    def ensure_rows(self, name):
+        """The fp32 matrix `name` with one row per CAR row ([BT + Rc, C]): allocated in full on first need (see __init__).  Called before
+        the step's first write to it."""
+        t = getattr(self, name)
+        if t.shape[0] < self.Rall:
+            t = torch.empty(self.Rall, t.shape[1], dtype=t.dtype, device=t.device)
+            setattr(self, name, t)
+        return t
+
     def dropout_buffers(self, rt):
         """Buffers of the dropout path (keep_prob < 1: dense PreCAR input rows, dropped FC1 / recurrent outputs) - allocated on first use."""
+        if not rt.b16:
+            self.ensure_rows('Z1'); self.ensure_rows('dZ2')
         if getattr(self, 'Xd', None) is None:
             L, dev = rt.layout, rt.device
             f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -651,6 +736,8 @@ class StepPlan:
         n = P * self.NC
         if getattr(self, 'used_p3', False):
             z = self.Z1p[:, :n].float()
+            if self.h2:
+                return (z[0] + z[1]) * self.sc_z1[1]
             return z[0] + z[1] + z[2]
         if self.Z1.shape[0] == self.BT and hasattr(self, 'Z1c'):
             return self.Z1c[:n].float()
@@ -1070,11 +1157,17 @@ class NARModuleModel:
             use_p3 = pl.used_p3 = rt.p3 and not drop and Rc > 0
             if drop:
                 rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
+            elif use_p3 and rt.h2:      # candidate rows straight into two fp16 planes x 2^k, k from the bound max|U| + max|V| (no fp32 copy)
+                check(lib.cham_h2_scale_absmax(ptr(pl.U), BT * C, ptr(pl.V), RV * C, ptr(pl.sc_z1), s), "cham_h2_scale_absmax")
+                check(lib.cham_combine_fwd_h2(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, ptr(pl.sc_z1), s),
+                      "cham_combine_fwd_h2")
             elif use_p3:      # candidate rows straight into three bf16 planes (no fp32 copy)
                 check(lib.cham_combine_fwd_p3(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, s), "cham_combine_fwd_p3")
             else:
                 check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
-            if use_p3:
+            if use_p3 and rt.h2:
+                rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
+            elif use_p3:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, rt.w2tp, C * C, C, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
             else:
                 rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
@@ -1161,7 +1254,13 @@ class NARModuleModel:
         else:
             rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
             rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+            if not (use_p3 and rt.dm_fused and 32 <= NC <= 256):
+                pl.ensure_rows('dZ2')          # the scorer layer-1 dgrad goes through HBM
             Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
+        h2 = use_p3 and rt.h2
+        if h2:      # scale of the gradient at the CAR tanh from the Cauchy-Schwarz bound of dS1 Ws1^T: max row norm of dS1 x max row norm of Ws1
+            check(lib.cham_h2_scale_rownorm(ptr(pl.dS1), Rc, pl.dS1.shape[1], pl.dS1.shape[1], rt.sc_ws1n.data_ptr() + 8, ptr(pl.sc_dz2), s),
+                  "cham_h2_scale_rownorm")
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
         fused = False      # (round 1's fused scorer-dgrad + mulpred epilogue measured slower than the two passes and was removed in round 2)
@@ -1218,12 +1317,19 @@ class NARModuleModel:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(lib.cham_dm_mulpred_p3(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
-                                         ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_p3")
+            if h2:
+                check(lib.cham_dm_mulpred_h2(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
+                                             ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2")
+            else:
+                check(lib.cham_dm_mulpred_p3(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
+                                             ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_p3")
             if prof is not None:
                 e1.record()
                 prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=False,
                                  dmf=True, tile=0, epi=0, ev=(e0, e1)))
+        elif h2:          # gradient at the CAR tanh straight into two fp16 planes + this position's share of the b2 gradient
+            check(lib.cham_mulpred_bwd_h2(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part),
+                                          ptr(pl.sc_dz2), s), "cham_mulpred_bwd_h2")
         elif use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_p3(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part), s),
                   "cham_mulpred_bwd_p3")
@@ -1248,7 +1354,14 @@ class NARModuleModel:
             check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
         if b16:
             rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY, dma=rt.b16_dma)
-        if use_p3:      # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
+        def w2_wgrad_planes(splits):      # candidate rows' share of the W2 weight gradient from the planes (TN, split-K)
+            if h2:
+                rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, 1, g('W2'), C, C, C, Rc, splits=splits)
+            else:
+                rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=splits)
+        if h2:          # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
+            rt.gemm_h2(pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
+        elif use_p3:
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
             if r1 <= r0 or b16 or use_p3:
@@ -1263,7 +1376,7 @@ class NARModuleModel:
         w2_main = bool(on and use_p3 and not swap and 0 < Rc <= rt.w2_main_rows)
         e_w2main = None
         if w2_main:      # candidate rows' share of the W2 weight gradient here, in the main lane's wait for the side lane's recurrent chain
-            rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=0)
+            w2_wgrad_planes(0)
             e_w2main = mark()
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
@@ -1335,7 +1448,7 @@ class NARModuleModel:
                         else:
                             if on and rt.w2_after_dgrad:
                                 rt.side_stream.wait_event(e_cdgrad)
-                            rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=rt.p3_w2_splits)
+                            w2_wgrad_planes(rt.p3_w2_splits)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)

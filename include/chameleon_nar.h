@@ -174,6 +174,40 @@ void cham_gemm_p3_set_variant(int variant);
 int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
                 int lddT, void* stream);
 
+/* fp32-grade GEMM over operands that live in HBM as TWO fp16 PLANES + a power-of-two scale (csrc/gemm_h2.hip, round 4): three plane
+ * products (a_h b_h + a_h b_l + a_l b_h) per fp32 product instead of cham_gemm_p3's six.  Replaces the same three matmuls - the CAR
+ * layer-2 matmul over the candidate rows (nar_model.py:384-388), its dgrad and its weight gradient (autodiff of :384-388 under
+ * tf.train.AdamOptimizer.compute_gradients, :718) - when the runtime's default arithmetic is on.
+ *   An H2Scale RECORD is 32 bytes of device memory, zero-initialised once by the caller: {float scale, float inv_scale, float bound,
+ *   pad, 3 words of kernel scratch, pad}.  x is stored as h = fp16(x * scale), l = fp16(x * scale - h); scale = 2^k with
+ *   bound * scale in [2^14, 2^15).  cham_h2_scale_absmax: bound = max|x0| + max|x1| (x1 may be NULL; n0, n1 element counts, % 4 == 0).
+ *   cham_h2_scale_rownorm: bound = (max over rows of ||X[r, 0:K]||_2) * (*factor if factor != NULL) - the Cauchy-Schwarz bound of a
+ *   product of two matrices' rows (factor = &other_record.bound).  Both are stream-ordered, order-independent (bit-reproducible) and need no
+ *   host synchronisation.  cham_split2h: planes of an fp32 matrix X [R, Cc] (dst[q][r][c] and / or the transposed dstT[q][c][r]) with the
+ *   scale of `rec`, computed from max|X| first when recompute != 0 (then ld == Cc).
+ *   cham_gemm_h2: A, B = plane 0 (h) of each operand, the l plane `*_plane_stride` ELEMENTS further; a_scale / b_scale = the operands'
+ *   records; tn / epilogues / split-K / return codes exactly as cham_gemm_p3 (dref_h = the fp16 h plane of the saved activation: its sign
+ *   is kept even where the value underflows).  cham_gemm_h2_launch_counts: out8[0] / out8[1] = NT / TN launches since the last reset,
+ *   out8[6] / out8[7] = epilogue variant / K-splits of the last launch. */
+int cham_h2_scale_absmax(const float* x0, size_t n0, const float* x1, size_t n1, void* rec, void* stream);
+int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream);
+int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
+                 int lddT, void* rec, int recompute, void* stream);
+int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride, int ldb,
+                 const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr,
+                 int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
+void cham_gemm_h2_launch_counts(long long* out8, int reset);
+/* producers of two-plane matrices (csrc/scorer.hip, csrc/dm_fused.hip): cham_combine_fwd_p3 / cham_mulpred_bwd_p3 / cham_dm_mulpred_p3
+ * with the output written as (h, l) fp16 planes x the scale of `scale_rec` (filled BEFORE the call: max|U| + max|V| for the PreCAR output,
+ * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */
+int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                        long long plane_stride, const void* scale_rec, void* stream);
+int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,
+                        long long plane_stride, float* col_part, const void* scale_rec, void* stream);
+int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c, const float* pred,
+                       int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec, float* dpred_pre,
+                       float* col_part, void* stream);
+
 /* producers of plane-resident matrices (csrc/scorer.hip): the candidate rows of the PreCAR output leaky(U[b,t] + V[item])
  * (nar_model.py:356-405) and the gradient at the CAR tanh (autodiff of nar_model.py:478-495: dM * pred * (1 - Z2^2)) written as three
  * bf16 planes `plane_stride` elements apart; cham_mulpred_bwd_p3 also writes dpred_pre (as cham_mulpred_bwd) and, when col_part !=

@@ -13,7 +13,7 @@ import torch
 
 from chameleon_recsys_amd.nar import synthetic
 from tests import helpers as H
-from tests.test_g1shape_parity_gpu import LOGIT_TOL, compare_step_large, p3_counts, x3_counts
+from tests.test_g1shape_parity_gpu import LOGIT_TOL, car_gemm_counts, compare_step_large, reset_counts, x3_counts
 
 pytestmark = pytest.mark.gpu
 
@@ -36,12 +36,12 @@ def test_step_parity_config5_shape(gpu, length_dist):
     L = model.rt.layout
     assert L.entries['items_embedding'].shape == (N_ITEMS, EMB) and L.D == ACE_DIM and L.f_item == 37 + ACE_DIM + EMB + 2
     lib = model.rt.lib
-    x3_counts(lib, reset=True); p3_counts(lib, reset=True)
+    reset_counts(lib)
     compare_step_large(model, orc, *batches[3], st)
     pl = model._plan
     assert pl.NC == NEG + 1 and pl.pmax == 20 * NEG and pl.pool.numel() == 4000
-    c3, x = p3_counts(lib), x3_counts(lib)
-    assert c3[0] - c3[4] == 2 and c3[1] == 1, (c3, x)          # the three candidate-row CAR GEMMs ran on the plane-resident kernel
+    x = x3_counts(lib)
+    assert car_gemm_counts(model) == (2, 1), (car_gemm_counts(model), x)          # the three candidate-row CAR GEMMs ran on the plane-resident kernel
     if length_dist == "full":
         assert pl.P == B * 19 and x[0] + x[1] >= 3, (pl.P, x)    # 61 104 candidate rows; scorer layer 1 & co on the on-the-fly split kernels
 

@@ -18,15 +18,17 @@ pytestmark = pytest.mark.gpu
 STEPS = 3
 
 
-def _params():
-    return H.tiny_params(C=128, H=100, neg=8, batch_size=48)
+def _params(**over):
+    kw = dict(C=128, H=100, neg=8, batch_size=48)
+    kw.update(over)
+    return H.tiny_params(**kw)
 
 
-def _run(dp_world, rank, batches, p):
+def _run(dp_world, rank, batches, p, mode=None):
     from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
     from chameleon_recsys_amd.nar.parallel import DataParallelNAR
     model, _ = H.make_pair(p, seed=7)
-    dp = DataParallelNAR(model)
+    dp = DataParallelNAR(model, mode=mode)
     st = DeviceClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'],
                                  p['recent_clicks_for_normalization'], 1000)
     for f, l in batches[:2]:          # warm state (identical on every rank)
@@ -85,3 +87,50 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     # every kernel of the step is deterministic (no float atomics), so that is the only difference
     from chameleon_recsys_amd.nar.nar_model import NARRuntime
     H.assert_flat_close(NARRuntime(p).layout, r0['flat'], m_dp, flat, m, p['lr'], n_steps=STEPS, m_tol=1e-4)
+
+
+# ---- BASELINE configs[2] as written: bf16 AND data parallel (and the fp32 default with its plane shadows of W2) ------------------------
+ARITH = [("f32", 256), ("bf16", 256)]          # C = 256: the plane-resident CAR GEMMs (fp32) / the LDS-DMA bf16 core are active, weight shadows in use
+MODES = ["allreduce", "sharded", "hybrid", "sparse", "sparse_rs"]
+
+
+def _worker_arith(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for dtype, C in ARITH:
+        p = _params(C=C, gemm_dtype=dtype)
+        batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
+        for mode in MODES:
+            losses, flat, m, E, m_ckpt, ckpt_mode = _run(world, rank, batches, p, mode=mode)
+            assert ckpt_mode == mode
+            out["%s/%s/losses" % (dtype, mode)] = losses
+            out["%s/%s/flat" % (dtype, mode)] = flat
+            out["%s/%s/m" % (dtype, mode)] = m_ckpt          # complete slots (gathered) whatever the mode
+    np.savez(os.path.join(out_dir, "arith_rank%d.npz" % rank), **out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_in_every_arithmetic_and_exchange_mode(gpu, tmp_path):
+    """gemm_dtype x exchange mode: the bf16 configuration (bf16 weight shadows, refreshed per weight version - in the sharded / hybrid
+    modes the weights are REWRITTEN by an all-gather after Adam) and the fp32 default at a width where the W2 plane shadows are in use,
+    two ranks, three optimizer steps: replicas bit-identical, equal to the single-process run of the same arithmetic."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_arith, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(str(tmp_path / "arith_rank0.npz")), np.load(str(tmp_path / "arith_rank1.npz"))
+    from chameleon_recsys_amd.nar.nar_model import NARRuntime
+    for dtype, C in ARITH:
+        p = _params(C=C, gemm_dtype=dtype)
+        batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
+        losses, flat, m, _, _, _ = _run(1, 0, batches, p)
+        rt = NARRuntime(p)
+        assert (rt.gemm_dtype == 'bf16' and rt.b16_dma) if dtype == 'bf16' else (rt.p3 and rt.h2)
+        for mode in MODES:
+            k = "%s/%s/" % (dtype, mode)
+            assert np.array_equal(r0[k + 'flat'], r1[k + 'flat']), k                 # replicas stay bit-identical
+            assert np.array_equal(r0[k + 'm'], r1[k + 'm']), k
+            assert np.abs(losses - r0[k + 'losses']).max() < (2e-4 if dtype == 'bf16' else 2e-5), (k, losses, r0[k + 'losses'])
+            # fp32 summation order of the two row shards is the only difference - in bf16 too: the per-row matrices are rounded per element,
+            # independent of the sharding; the weight shadows are fresh after every exchange or the trajectories part at step 2
+            H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=1e-3 if dtype == 'bf16' else 1e-4)

@@ -20,8 +20,14 @@ pytestmark = pytest.mark.gpu
 STEPS = 3
 
 
-def _params():
-    return H.tiny_params(C=128, H=100, neg=8, batch_size=48)
+def _params(**over):
+    kw = dict(C=128, H=100, neg=8, batch_size=48)
+    kw.update(over)
+    return H.tiny_params(**kw)
+
+
+# (C = 128: the small-tile kernels; C = 256: the plane-resident CAR GEMMs with their W2 plane shadows / the bf16 LDS-DMA core with bf16 shadows)
+ARITH = [("f32", 128), ("f32", 256), ("bf16", 256)]
 
 
 def _train(p, batches, dp_mode):
@@ -51,15 +57,16 @@ def _worker(rank, port, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     assert dist.get_backend() == "nccl"
-    p = _params()
-    batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
-    ref = _train(p, batches, None)
     out = {}
-    for mode in ("allreduce", "sharded", "hybrid", "sparse", "sparse_rs"):
-        losses, flat, m, v, active = _train(p, batches, mode)
-        assert active, "CHAM_DP_FORCE did not install the exchange hooks"
-        out[mode] = (bool(np.array_equal(losses, ref[0])), bool(np.array_equal(flat, ref[1])), bool(np.array_equal(m, ref[2])),
-                     bool(np.array_equal(v, ref[3])), float(np.abs(losses - ref[0]).max()))
+    for dtype, C in ARITH:
+        p = _params(C=C, gemm_dtype=dtype)
+        batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
+        ref = _train(p, batches, None)
+        for mode in ("allreduce", "sharded", "hybrid", "sparse", "sparse_rs"):
+            losses, flat, m, v, active = _train(p, batches, mode)
+            assert active, "CHAM_DP_FORCE did not install the exchange hooks"
+            out["%s/C%d/%s" % (dtype, C, mode)] = (bool(np.array_equal(losses, ref[0])), bool(np.array_equal(flat, ref[1])), bool(np.array_equal(m, ref[2])),
+                                                   bool(np.array_equal(v, ref[3])), float(np.abs(losses - ref[0]).max()))
     # the 33.6 MB-class two-bucket exchange itself, timed on this rank's stream (bench.py reports the same as dp_self_exchange_ms)
     g = torch.zeros(8 << 20, device="cuda")
     for _ in range(3):
@@ -73,5 +80,6 @@ def test_every_exchange_mode_on_rccl_world_of_one_is_bit_identical(gpu, tmp_path
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     out = np.load(str(tmp_path / "result.npy"), allow_pickle=True)[0]
+    assert len(out) == 15          # three arithmetics x five exchange modes (bf16 x data parallel = BASELINE configs[2] as written)
     for mode, (l_ok, w_ok, m_ok, v_ok, dl) in out.items():
         assert l_ok and w_ok and m_ok and v_ok, "mode %s on RCCL: losses %s (max diff %g) weights %s m %s v %s" % (mode, l_ok, dl, w_ok, m_ok, v_ok)

@@ -1,5 +1,6 @@
-"""BASELINE configs[1] at FULL size (46k articles, 250-d ACE, seq_len 20, batch 256, 50 negatives, C=1024, H=255) where the
-dense CPU oracle would need minutes per step: size-independent properties of the HIP path.
+"""BASELINE configs[1] at FULL size (46k articles, 250-d ACE, seq_len 20, batch 256, 50 negatives, C=1024, H=255): the
+size-independent properties of the HIP path (the oracle comparison at this very batch size - ~10 s of oracle time per evaluation - is
+tests/test_g1shape_parity_gpu.py::test_step_parity_g1_shape_headline_batch).
   * row-shard additivity: two half-batches (global ids / denominators) reproduce the full batch's negatives and logits, their
     gradient buffers sum to the full-batch gradient (the property data parallelism and micro-batching rest on);
   * softmax rows sum to 1, padded clicks contribute nothing, negatives never contain the session's own items and are unique

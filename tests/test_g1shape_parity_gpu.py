@@ -30,7 +30,14 @@ def tile_counts(lib, reset=False):
     return list(out)
 
 
-def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, grad_max=2e-4):
+def _oracle_grads(orc):
+    return {k: (v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in orc.w.items()}
+
+
+def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, grad_max=2e-4, unpinned_max=None):
+    """unpinned_max: also bound the gradient error against the oracle's OWN leaky-ReLU branches (no re-run on the HIP path's branches),
+    as a fraction of each tensor's max - loose, because a branch decided differently within an ulp of zero is a real O(1e-3) difference
+    of two correct evaluations; printed so the un-pinned number is on record."""
     buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
     model.feed_state(pop, buf)
     model.forward(model.upload_batch(f, l))
@@ -48,6 +55,12 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, 
     assert abs(out['loss'][2] - float(ref['reg_loss'])) < 1e-5
     flips = _kink_flips(model, orc, mask)
     orc.debug_taps = None
+    g_unpinned = None
+    if unpinned_max is not None and flips:
+        ref['xe_loss'].backward(retain_graph=False)
+        g_unpinned = _oracle_grads(orc)
+        for v in orc.w.values():
+            v.grad = None
     if flips:
         # a handful of the 63 M leaky-ReLU pre-activations lie within an fp32 ulp of zero and take the other branch in the two
         # evaluations; which ones is luck, and one on a high-gradient element moves a small tensor's gradient by ~1e-3.  The
@@ -64,6 +77,16 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, 
     g = model.rt.logical_grads()
     worst = {}
     gmax = max(float(v.grad.abs().max()) for v in orc.w.values() if v.grad is not None)
+    if unpinned_max is not None:
+        gu = g_unpinned if g_unpinned is not None else _oracle_grads(orc)
+        wu = ("", 0.0)
+        for k, rg in gu.items():
+            if float(np.abs(rg).max()) < 1e-5 * gmax:
+                continue
+            e = float(np.abs(g[k].astype(np.float64) - rg).max()) / float(np.abs(rg).max())
+            wu = max(wu, (k, e), key=lambda kv: kv[1])
+            assert e < unpinned_max, "grad %s against the oracle's own branches: max err %g of max (%d kink flips)" % (k, e, flips)
+        print("un-pinned gradient error (oracle on its own leaky branches): worst %.2e of max (%s), %d kink flips" % (wu[1], wu[0], flips))
     for k, v in orc.w.items():
         rg = v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)
         d = g[k].astype(np.float64) - rg
@@ -103,31 +126,52 @@ def p3_counts(lib, reset=False):
     return list(out)
 
 
-@pytest.mark.parametrize("length_dist,gemm_dtype,p3", [("full", "f32", True), ("full", "f32", False), ("full", "f32_native", False), ("g1", "f32", True)])
-def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, p3):
+def h2_counts(lib, reset=False):
+    out = (ctypes.c_longlong * 8)()
+    lib.cham_gemm_h2_launch_counts(out, int(reset))
+    return list(out)
+
+
+def car_gemm_counts(model):
+    """(NT launches, TN launches) of the three candidate-row CAR GEMMs on the plane-resident kernel the runtime's arithmetic selects."""
+    lib = model.rt.lib
+    if model.rt.h2:
+        c = h2_counts(lib)
+        return c[0], c[1]
+    c = p3_counts(lib)
+    return c[0] - c[4], c[1]
+
+
+def reset_counts(lib):
+    tile_counts(lib, reset=True); x3_counts(lib, reset=True); p3_counts(lib, reset=True); h2_counts(lib, reset=True)
+
+
+@pytest.mark.parametrize("length_dist,gemm_dtype,arith", [("full", "f32", "h2"), ("full", "f32", "p3"), ("full", "f32", "x3"), ("full", "f32_native", None),
+                                                          ("g1", "f32", "h2"), ("g1", "f32", "p3")])
+def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, arith):
     """BASELINE configs[1] shape, 72 sessions: forward + full backward vs the dense oracle, on the big-tile GEMM instances - the
-    default arithmetic (wide GEMMs as bf16 plane products: the three candidate-row CAR GEMMs over planes resident in HBM,
-    csrc/gemm_p3.hip, the rest split while staged, csrc/gemm_x3.hip), the same with every plane-product GEMM split on the fly
+    default arithmetic (the three candidate-row CAR GEMMs over two fp16 planes + a power-of-two scale resident in HBM, three plane
+    products: csrc/gemm_h2.hip; the other wide GEMMs as six bf16 plane products split while staged: csrc/gemm_x3.hip), the same with
+    the CAR GEMMs over three bf16 planes (CHAM_GEMM_H2=0: csrc/gemm_p3.hip), with every plane-product GEMM split on the fly
     (CHAM_GEMM_P3=0), and every GEMM on the native fp32 MFMA - same tolerances."""
-    monkeypatch.setenv("CHAM_GEMM_P3", "1" if p3 else "0")
+    monkeypatch.setenv("CHAM_GEMM_P3", "0" if arith == "x3" else "1")
+    monkeypatch.setenv("CHAM_GEMM_H2", "1" if arith == "h2" else "0")
     B = 72
     p = _g1_params(B, gemm_dtype=gemm_dtype)
     batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B)
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p, seed=7)
     lib = model.rt.lib
-    tile_counts(lib, reset=True)
-    x3_counts(lib, reset=True)
-    p3_counts(lib, reset=True)
+    reset_counts(lib)
     compare_step_large(model, orc, *batches[3], st)
     c = tile_counts(lib)
     x = x3_counts(lib)
-    c3 = p3_counts(lib)
-    assert model.rt.p3 == (p3 and gemm_dtype == "f32")
-    if p3:
+    assert model.rt.p3 == (arith in ("h2", "p3")) and model.rt.h2 == (arith == "h2")
+    if arith in ("h2", "p3"):
         # CAR forward + dgrad (NT) and the W2 weight gradient (TN, split-K) on the plane-resident kernel; scorer layer 1 (row scale),
-        # its wgrad and dgrad on the 256x128 on-the-fly instance; nothing wide on the native kernels
-        assert c3[0] - c3[4] == 2 and c3[1] == 1 and c[1] == 0 and c[2] == 0, (c3, x, c)
+        # its wgrad on the 256x128 on-the-fly instance; nothing wide on the native kernels
+        assert car_gemm_counts(model) == (2, 1) and c[1] == 0 and c[2] == 0, (car_gemm_counts(model), x, c)
+        assert (h2_counts(lib)[0] == 0) == (arith == "p3") and (p3_counts(lib)[0] == 0) == (arith == "h2")
         # (scorer layer 1 forward + its weight gradient; its dgrad lives in the fused kernel csrc/dm_fused.hip)
         assert x[1] >= (2 if length_dist == "full" else 0) and x[0] + x[1] >= 2 and model.rt.dm_fused, x
     elif gemm_dtype == "f32":
@@ -140,6 +184,25 @@ def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, p3):
         assert c[1] >= 3 and c[2] >= 2, "expected the 256x128 and 256x256 instances to run: %r" % (c,)
     else:
         assert c[1] >= 1, c
+
+
+@pytest.mark.parametrize("length_dist", ["full", "g1"])
+def test_step_parity_g1_shape_headline_batch(gpu, length_dist):
+    """BASELINE configs[1] AT THE HEADLINE BATCH ITSELF (B = 256, scripts/run_nar_train_gcom_mlengine.sh:29 of the reference): the step
+    bench.py times - 256 x 19 x 51 = 248 064 candidate rows - forward + full backward against the dense oracle (~10 s of oracle time
+    per evaluation on the box's host cores), default arithmetic, same tolerances as the 72-session case; plus the gradient error
+    against the oracle's own leaky-ReLU branches, bounded at 5e-3 of each tensor's max."""
+    B = 256
+    p = _g1_params(B)
+    batches = synthetic.make_batches(4, B, 20, 46000, p['session_features_config'], length_dist=length_dist, sessions_per_hour=4 * B)
+    st = H.warm_state(p, batches[:3])
+    model, orc = H.make_pair(p, seed=11)
+    lib = model.rt.lib
+    reset_counts(lib)
+    compare_step_large(model, orc, *batches[3], st, unpinned_max=5e-3)
+    assert model.rt.h2 and car_gemm_counts(model) == (2, 1)          # the three candidate-row CAR GEMMs ran on the default (two-plane) kernels
+    rows = model._plan.P * model._plan.NC
+    assert rows == (B * 19 * 51 if length_dist == "full" else rows) and rows > 0
 
 
 def test_training_curve_g1_shape(gpu):
@@ -177,11 +240,10 @@ def test_step_parity_adressa_shape(gpu):
     st = H.warm_state(p, batches[:3])
     model, orc = H.make_pair(p, seed=2)
     lib = model.rt.lib
-    x3_counts(lib, reset=True)
-    p3_counts(lib, reset=True)
+    reset_counts(lib)
     compare_step_large(model, orc, *batches[3], st)
-    x, c3 = x3_counts(lib), p3_counts(lib)
-    assert c3[0] - c3[4] == 2 and c3[1] == 1 and x[1] >= 2, (c3, x)
+    x = x3_counts(lib)
+    assert car_gemm_counts(model) == (2, 1) and x[1] >= 2, (car_gemm_counts(model), x)
 
 
 @pytest.mark.parametrize("dma", [True, False])
@@ -251,45 +313,65 @@ def test_step_parity_g1_shape_bf16(gpu, dma):
         assert e_hip < 3.0 * e_emu + 2e-2, (k, e_hip, e_emu)
 
 
-def test_loss_curve_50_steps_g1_shape_and_hitrate(gpu):
-    """north_star: "loss curve matching CPU reference within 1e-3" - 50 consecutive optimizer steps at the G1 shape (64 sessions of
-    G1-like lengths per step, shipped lr 1e-4, the recent-clicks state evolving, nar_trainer_gcom.py:511-525) from the same initial
-    weights.  The oracle runs ONE trajectory; two HIP runtimes follow it free-running (no re-synchronisation of weights): the default
-    arithmetic (plane-product GEMMs) and every GEMM on the native fp32 MFMA.  Negatives bit-exact at every step on both.
-    Loss: two correct fp32 trainers drift apart under Adam (an entry whose gradient is roundoff moves by +-lr per step in either
-    run; a leaky-ReLU branch decided differently within an ulp of zero moves a small tensor's gradient by 1e-3), so the bound is
-    1e-3 for the first 30 steps and 3e-3 through step 50 (measured on MI355X, round 3: 1e-3 held for 41 steps, worst 1.2e-3), and the
-    default arithmetic must not drift more than the native one does (x 1.5 + 3e-4): the drift is fp32 training, not the plane split.
-    Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric):
-    the HIP path, the oracle trained separately, and the oracle evaluating the HIP-trained weights (the eval path alone: must agree
-    to the last hit)."""
+def _dump_curve(name, payload):
+    """Loss-curve records for profiles/ (gpurun_out/ is merged back from the GPU box)."""
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as fh:
+            json.dump(payload, fh)
+    except OSError:
+        pass
+
+
+def test_loss_curve_200_steps_g1_shape_and_hitrate(gpu):
+    """north_star: "loss curve matching CPU reference within 1e-3" over the horizon SURVEY 7.5 names - 200 consecutive optimizer steps at
+    the G1 widths (32 sessions of G1-like lengths per step, shipped lr 1e-4, the recent-clicks state evolving, nar_trainer_gcom.py:511-525)
+    from the same initial weights.  The oracle runs ONE trajectory; two HIP runtimes follow it free-running (no re-synchronisation of
+    weights): the default arithmetic (two-fp16-plane CAR GEMMs + bf16x3 elsewhere) and every GEMM on the native fp32 MFMA.  Negatives
+    bit-exact at every step on both.
+    Loss: two correct fp32 trainers drift apart under Adam (an entry whose gradient is roundoff moves by +-lr per step in either run; a
+    leaky-ReLU branch decided differently within an ulp of zero moves a small tensor's gradient by 1e-3), so the absolute bound is 1e-3
+    for the first 30 steps, 3e-3 through step 50 and 2e-2 (a sanity bound) to step 200, and AT EVERY STEP the default arithmetic's
+    worst deviation so far must not exceed 1.5 x the native arm's + 3e-4: the drift is fp32 training, not the plane split.  The curve
+    is written to gpurun_out/loss_curve_200.json.
+    Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric): the
+    HIP path, the oracle trained separately, and the oracle evaluating the HIP-trained weights (the eval path alone: must agree to the
+    last hit)."""
     from chameleon_recsys_amd.nar import metrics
     from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel
     from oracle.nar_oracle import NAROracle
-    B, STEPS = 64, 50
+    B, STEPS = 32, 200
     p = _g1_params(B)
     batches = synthetic.make_batches(2 + STEPS + 4, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=21)
     st = H.warm_state(p, batches[:2])
     model, orc = H.make_pair(p, seed=13)
     native, _ = H.make_pair(_g1_params(B, gemm_dtype='f32_native'), seed=13)
-    assert model.rt.p3 and not native.rt.x3
+    assert model.rt.h2 and not native.rt.x3
     dev = {"default": [], "native": []}
+    oracle_loss = []
     for i, (f, l) in enumerate(batches[2:2 + STEPS]):
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         ref = orc.train_step(f, l, buf, pop)
+        oracle_loss.append(float(ref['total_loss']))
         for name, m in (("default", model), ("native", native)):
             m.feed_state(pop, buf)
             loss = m.train_step(m.upload_batch(f, l)).cpu().numpy()
             assert np.array_equal(m._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy()), "step %d (%s): negative samples differ" % (i, name)
             d = abs(float(loss[0]) - float(ref['total_loss']))
             dev[name].append(d)
-            assert d < (LOGIT_TOL if i < 30 else 3 * LOGIT_TOL), "step %d (%s): loss %r vs oracle %g" % (i, name, loss, float(ref['total_loss']))
+            bound = LOGIT_TOL if i < 30 else (3 * LOGIT_TOL if i < 50 else 20 * LOGIT_TOL)
+            assert d < bound, "step %d (%s): loss %r vs oracle %g" % (i, name, loss, float(ref['total_loss']))
+        assert max(dev["default"]) < 1.5 * max(dev["native"]) + 3e-4, "step %d: default arithmetic drifted %.2e, native fp32 %.2e" % (
+            i, max(dev["default"]), max(dev["native"]))
         H.update_state(st, f, l)
     w_def, w_nat = max(dev["default"]), max(dev["native"])
     within = lambda x: next((i for i, d in enumerate(x) if d >= LOGIT_TOL), STEPS)
-    print("50-step loss curve: worst |loss - oracle| default %.2e (1e-3 held for %d steps), native fp32 MFMA %.2e (%d steps); final loss %.5f"
+    print("200-step loss curve: worst |loss - oracle| default %.2e (1e-3 held for %d steps), native fp32 MFMA %.2e (%d steps); final loss %.5f"
           % (w_def, within(dev["default"]), w_nat, within(dev["native"]), float(loss[0])))
-    assert w_def < 1.5 * w_nat + 3e-4, (w_def, w_nat)
+    _dump_curve("loss_curve_200.json", dict(batch=B, steps=STEPS, oracle_loss=oracle_loss, abs_dev_default=dev["default"], abs_dev_native=dev["native"],
+                                            held_1e3_default=within(dev["default"]), held_1e3_native=within(dev["native"])))
     ev = NARModuleModel(ModeKeys.EVAL, None, None, p['session_features_config'], p['articles_features_config'], B, p['lr'], 1.0,
                         p['eval_total_negative_samples'], p['eval_negative_samples_from_buffer'], p['content_article_embeddings_matrix'],
                         softmax_temperature=p['softmax_temperature'], reg_weight_decay=p['reg_weight_decay'],
@@ -314,3 +396,35 @@ def test_loss_curve_50_steps_g1_shape_and_hitrate(gpu):
     n_pos = sum(int((l['label_next_item'] != 0).sum()) for _, l in batches[2 + STEPS:])
     assert abs(hr["hip"] - hr["oracle_on_hip_weights"]) <= 1.5 / n_pos, hr          # same weights: at most one tie broken differently
     assert abs(hr["hip"] - hr["oracle"]) < 0.02 and abs(mrr["hip"] - mrr["oracle"]) < 0.02, (hr, mrr)
+
+
+def test_loss_curve_50_steps_bf16_g1_shape(gpu):
+    """BASELINE configs[2] arithmetic over 50 consecutive optimizer steps (32 sessions of G1-like lengths, state evolving): the HIP bf16
+    path free-running against the oracle that emulates the bf16 operand / storage rounding (oracle/nar_oracle.py _BF16MatMul, _StoreBF16)
+    on its own trajectory.  Negatives bit-exact every step; loss within 2e-3 for the first 10 steps and 1e-2 through step 50 (a value that
+    lands on the other side of a bf16 rounding boundary moves by 2^-8 relative - the two runs are two roundings of the same trajectory,
+    not the same sequence of bits), and the bf16 run stays within 5e-2 of the FP32 oracle's loss.  Curve -> gpurun_out/loss_curve_bf16_50.json."""
+    from oracle.nar_oracle import NAROracle
+    B, STEPS = 32, 50
+    p = _g1_params(B, gemm_dtype='bf16')
+    batches = synthetic.make_batches(2 + STEPS, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=23)
+    st = H.warm_state(p, batches[:2])
+    model, orc = H.make_pair(p, seed=17)
+    assert model.rt.gemm_dtype == 'bf16' and orc.gemm_dtype == 'bf16' and model.rt.b16_dma
+    p32 = dict(p); p32['gemm_dtype'] = 'f32'
+    orc32 = NAROracle(p32, weights=orc.weights_numpy())
+    dev, dev32, ol = [], [], []
+    for i, (f, l) in enumerate(batches[2:2 + STEPS]):
+        buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
+        ref = orc.train_step(f, l, buf, pop)
+        ref32 = orc32.train_step(f, l, buf, pop)
+        model.feed_state(pop, buf)
+        loss = model.train_step(model.upload_batch(f, l)).cpu().numpy()
+        assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy()), "step %d: negative samples differ" % i
+        d, d32 = abs(float(loss[0]) - float(ref['total_loss'])), abs(float(loss[0]) - float(ref32['total_loss']))
+        dev.append(d); dev32.append(d32); ol.append(float(ref['total_loss']))
+        assert d < (2e-3 if i < 10 else 1e-2), "step %d: bf16 loss %r vs the rounding-emulating oracle %g" % (i, loss, float(ref['total_loss']))
+        assert d32 < 5e-2, "step %d: bf16 loss %r vs the fp32 oracle %g" % (i, loss, float(ref32['total_loss']))
+        H.update_state(st, f, l)
+    print("50-step bf16 loss curve: worst |loss - emulating oracle| %.2e, worst |loss - fp32 oracle| %.2e, final loss %.5f" % (max(dev), max(dev32), float(loss[0])))
+    _dump_curve("loss_curve_bf16_50.json", dict(batch=B, steps=STEPS, oracle_bf16_loss=ol, abs_dev_vs_bf16_oracle=dev, abs_dev_vs_fp32_oracle=dev32))

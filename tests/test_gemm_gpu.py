@@ -272,3 +272,13 @@ def test_big_tiles_rowscale_scorer_layer1(gpu, bf16):
     for splits in (0, 16):
         assert wg.run(lib, -1, bf16, splits=splits) < 1e-4
         assert wg.run(lib, 2, bf16, splits=splits) < 1e-4
+
+
+@pytest.mark.parametrize("N", [6, 2, 10])
+@pytest.mark.parametrize("x3,bf16", [(False, False), (True, False), (False, True)])
+def test_nt_narrow_output_with_split_hint(gpu, N, x3, bf16):
+    """transB with an output width that is not a multiple of four and automatic split-K asked for: the vectorised
+    split-K reductions walk float4 groups of a row, so such a shape must take the unsplit kernel - through every public entry point."""
+    tol = 2e-2 if bf16 else 1e-4
+    assert _run(gpu, 96, N, 4096, transB=1, splits=0, x3=x3, bf16=bf16) < tol
+    assert _run(gpu, 96, N, 4096, transB=1, bias=True, splits=5, x3=x3, bf16=bf16) < tol

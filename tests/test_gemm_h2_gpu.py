@@ -1,0 +1,351 @@
+"""Two-fp16-plane GEMM (csrc/gemm_h2.hip: three plane products per fp32 product, LDS-DMA staging, 256x256 tile, four-stage ring) against a
+float64 reference: the device-side scales, both layouts, every epilogue, ragged rows / columns / K tails (descriptor range checks), one-
+to four-step reductions (pipeline prologue), split-K placements, repeatability (race screen), operands with wide dynamic range and fp16
+subnormal low planes, and - on the step's own shapes - its error next to the native fp32 MFMA's on the same operands: the bar the
+two-plane arithmetic must clear to be the default (<= 1.5 x native, as tests/test_gemm_p3_gpu.py demands of the six-product bf16 split)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 248064          # B * T * (1 + N) at the G1 shape
+
+
+def _lib_():
+    from chameleon_recsys_amd import _lib
+    return _lib.load()
+
+
+def new_rec(gpu):
+    return torch.zeros(8, dtype=torch.float32, device=gpu)
+
+
+def split2h_dev(x, rec=None, transposed=False):
+    """fp32 [R, C] -> ([2, R, C] fp16 planes (and [2, C, R] of the transpose), record) through cham_split2h (scale from max |x|)."""
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib_()
+    R, C = x.shape
+    rec = new_rec(x.device) if rec is None else rec
+    P = torch.zeros(2, R, C, dtype=torch.float16, device=x.device)
+    PT = torch.zeros(2, C, R, dtype=torch.float16, device=x.device) if transposed else None
+    check(lib.cham_split2h(ptr(x), R, C, C, ptr(P), R * C, C, ptr(PT), C * R, R, ptr(rec), 1, torch.cuda.current_stream().cuda_stream), "cham_split2h")
+    return (P, PT, rec) if transposed else (P, rec)
+
+
+def split2h_ref(x, scale):
+    xs = x * scale
+    h = xs.to(torch.float16)
+    l = (xs - h.float()).to(torch.float16)
+    hb = h.view(torch.int16).clone()
+    hb[(x > 0) & (hb == 0)] = 1
+    return torch.stack([hb.view(torch.float16), l])
+
+
+def _counts(lib, reset=False):
+    out = (ctypes.c_longlong * 8)()
+    lib.cham_gemm_h2_launch_counts(out, 1 if reset else 0)
+    return list(out)
+
+
+def _gemm(lib, Ap, a_ps, lda, ra, Bp, b_ps, ldb, rb, tn, C, ldc, M, N, K, bias=None, act=0, dref=None, ldr=0, dact=0, accumulate=0, ws=None, splits=1):
+    from chameleon_recsys_amd._lib import check, ptr
+    check(lib.cham_gemm_h2(ptr(Ap), a_ps, lda, ptr(ra), ptr(Bp), b_ps, ldb, ptr(rb), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref), ldr, dact,
+                           accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream), "cham_gemm_h2")
+
+
+def _nt(gpu, M, N, K, bias=False, act=0, dref=False, seed=0, scale=1.0, check_ref=True, reps=1, row_spread=0.0):
+    lib = _lib_()
+    g = torch.Generator(device=gpu).manual_seed(seed)
+    A = torch.randn(M, K, device=gpu, generator=g) * scale
+    if row_spread:
+        A = A * torch.exp2(-row_spread * torch.rand(M, 1, device=gpu, generator=g))
+    B = torch.randn(N, K, device=gpu, generator=g) * (K ** -0.5)
+    bias_t = torch.randn(N, device=gpu, generator=g) * scale if bias else None
+    Y = torch.randn(M, N, device=gpu, generator=g) if dref else None
+    (Ap, ra), (Bp, rb) = split2h_dev(A), split2h_dev(B)
+    Yh = split2h_dev(Y)[0][0].contiguous() if dref else None
+    C = torch.full((M, N), float('nan'), device=gpu)
+    outs = []
+    for _ in range(reps):
+        C.fill_(float('nan'))
+        _gemm(lib, Ap, M * K, K, ra, Bp, N * K, K, rb, 0, C, N, M, N, K, bias=bias_t, act=act, dref=Yh, ldr=N, dact=1 if dref else 0)
+        torch.cuda.synchronize()
+        outs.append(C.clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "plane GEMM is not repeatable (race?)"
+    if not check_ref:
+        return outs[0]
+    R = A.double() @ B.double().t()
+    if bias:
+        R = R + bias_t.double()
+    if act == 2:
+        R = torch.tanh(R)
+    if dref:
+        R = R * torch.where(Y.double() > 0, 1.0, 0.2)
+    return float((outs[0].double() - R).abs().max()) / max(scale if not row_spread else 0.0, float(R.abs().max()))
+
+
+def _tn(gpu, M, N, K, splits=1, accumulate=0, seed=0, reps=1):
+    lib = _lib_()
+    g = torch.Generator(device=gpu).manual_seed(seed)
+    A = torch.randn(K, M, device=gpu, generator=g)
+    B = torch.randn(K, N, device=gpu, generator=g)
+    C0 = torch.randn(M, N, device=gpu, generator=g)
+    (Ap, ra), (Bp, rb) = split2h_dev(A), split2h_dev(B)
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=gpu) if splits != 1 else None
+    outs = []
+    for _ in range(reps):
+        C = C0.clone() if accumulate else torch.full((M, N), float('nan'), device=gpu)
+        _gemm(lib, Ap, K * M, M, ra, Bp, K * N, N, rb, 1, C, N, M, N, K, accumulate=accumulate, ws=ws, splits=splits)
+        torch.cuda.synchronize()
+        outs.append(C)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "plane GEMM is not repeatable (race?)"
+    R = A.double().t() @ B.double()
+    if accumulate:
+        R = R + C0.double()
+    return float((outs[0].double() - R).abs().max()) / float(R.abs().max())
+
+
+def test_scale_records_and_split_kernel(gpu):
+    """cham_h2_scale_absmax (one and two arrays), cham_h2_scale_rownorm (K = 128 and generic, with a factor), cham_split2h (planes + transposed
+    planes bit-exact against the host formula, sign kept on underflow), and that a record can be re-used (the kernels clear their scratch)."""
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib_()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=gpu).manual_seed(5)
+    X = torch.randn(300, 264, device=gpu, generator=g) * torch.exp2(-30 * torch.rand(300, 1, device=gpu, generator=g))
+    Y = torch.randn(1000, 128, device=gpu, generator=g) * 3.0
+    rec = new_rec(gpu)
+    for _ in range(3):          # re-use of the record
+        check(lib.cham_h2_scale_absmax(ptr(X), X.numel(), None, 0, ptr(rec), st), "absmax")
+        torch.cuda.synchronize()
+        r = rec.cpu().numpy()
+        b = float(X.abs().max())
+        assert r[2] == np.float32(b) and 2.0 ** 14 <= b * r[0] < 2.0 ** 15 and r[0] * r[1] == 1.0 and not rec.view(torch.int32)[4:7].any()
+    check(lib.cham_h2_scale_absmax(ptr(X), X.numel(), ptr(Y), Y.numel(), ptr(rec), st), "absmax2")
+    torch.cuda.synchronize()
+    assert rec.cpu().numpy()[2] == np.float32(float(X.abs().max()) + float(Y.abs().max()))
+    rn, rn2 = new_rec(gpu), new_rec(gpu)
+    check(lib.cham_h2_scale_rownorm(ptr(Y), 1000, 128, 128, None, ptr(rn), st), "rownorm")
+    check(lib.cham_h2_scale_rownorm(ptr(X), 300, 264, 264, rn.data_ptr() + 8, ptr(rn2), st), "rownorm2")
+    torch.cuda.synchronize()
+    ny, nx = float(Y.double().norm(dim=1).max()), float(X.double().norm(dim=1).max())
+    assert ny <= rn.cpu().numpy()[2] <= ny * 1.002
+    assert nx * ny <= rn2.cpu().numpy()[2] <= nx * ny * 1.004
+    P, PT, r = split2h_dev(X, transposed=True)
+    torch.cuda.synchronize()
+    ref = split2h_ref(X, float(r[0]))
+    assert torch.equal(P.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(PT.view(torch.int16), ref.transpose(1, 2).contiguous().view(torch.int16))
+    assert torch.equal(P[0].view(torch.int16) > 0, X > 0)          # sign of the h plane == sign of x everywhere (leaky' is read from it)
+    back = (P[0].double() + P[1].double()) / float(r[0])
+    big = X.abs() * float(r[0]) >= 2.0 ** -3
+    assert float(((back - X.double()).abs()[big] / X.double().abs()[big]).max()) <= 2.0 ** -22
+    assert float((back - X.double()).abs()[~big].max()) <= 2.0 ** -24 / float(r[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 32), (256, 256, 48), (256, 256, 64), (256, 256, 80), (512, 512, 64), (300, 260, 96),
+                                   (1000, 1024, 1024), (77, 520, 416), (1, 4, 16), (513, 256, 1024)])
+def test_h2_nt(gpu, M, N, K):
+    assert _nt(gpu, M, N, K) < 5e-5
+    assert _nt(gpu, M, N, K, bias=True, act=2) < 5e-5
+    assert _nt(gpu, M, N, K, bias=True) < 5e-5
+    assert _nt(gpu, M, N, K, dref=True) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 40), (256, 256, 70), (256, 512, 777), (512, 256, 3001), (1024, 1024, 5000), (256, 256, 1)])
+def test_h2_tn_wgrad_splitk(gpu, M, N, K):
+    assert _tn(gpu, M, N, K) < 1e-4
+    assert _tn(gpu, M, N, K, splits=0) < 1e-4
+    assert _tn(gpu, M, N, K, splits=7) < 1e-4
+    assert _tn(gpu, M, N, K, splits=8) < 1e-4          # multiples of 8: one-K-split-per-XCD placement
+    assert _tn(gpu, M, N, K, splits=0, accumulate=1) < 1e-4
+
+
+def test_h2_exact_on_small_integers_and_layout(gpu):
+    """Operands that ARE fp16 numbers have empty low planes and small-integer products are exact; A = I against an asymmetric B catches row /
+    column swaps of the fragment maps, the swizzles and the C/D map, in both layouts."""
+    lib = _lib_()
+    n = 512
+    I = torch.eye(n, device=gpu)
+    B = (torch.arange(n * n, dtype=torch.float32, device=gpu).reshape(n, n) % 97 - 31.0)
+    (Ip, ri), (Bp, rb) = split2h_dev(I), split2h_dev(B)
+    assert not Ip[1].any() and not Bp[1].any()
+    C = torch.zeros(n, n, device=gpu)
+    _gemm(lib, Ip, n * n, n, ri, Bp, n * n, n, rb, 0, C, n, n, n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C, B.t())              # C = I B^T
+    C.zero_()
+    _gemm(lib, Ip, n * n, n, ri, Bp, n * n, n, rb, 1, C, n, n, n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C, B)                  # C = I^T B
+    C.zero_()
+    _gemm(lib, Bp, n * n, n, rb, Ip, n * n, n, ri, 1, C, n, n, n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C, B.t())              # C = B^T I
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1e12, 1e30])
+def test_h2_dynamic_range_of_the_scale(gpu, scale):
+    """The whole operand far from fp16's range: the power-of-two scale brings it back, results as accurate as at unit scale."""
+    assert _nt(gpu, 300, 260, 96, scale=scale) < 5e-5
+
+
+@pytest.mark.parametrize("spread", [12.0, 24.0, 36.0])
+def test_h2_rows_of_very_different_magnitude(gpu, spread):
+    """Rows spread over `spread` binary orders of magnitude under ONE per-tensor scale (what the gradient at the CAR tanh looks like): the
+    error is bounded relative to the LARGEST output (absolute error of the small rows <= 2^-40 of the bound per element), which is what a
+    sum over rows - the W2 weight gradient - and the max-normalised gradient checks of the parity tests see."""
+    assert _nt(gpu, 1000, 512, 256, row_spread=spread, seed=3) < 5e-5
+
+
+def test_h2_is_repeatable_under_load(gpu):
+    """Race screen: the same launch five times, bit-identical (a fragment read that overtakes its DMA shows up as run-to-run noise)."""
+    _nt(gpu, 4096, 1024, 1024, bias=True, act=2, check_ref=False, reps=5)
+    assert _tn(gpu, 1024, 1024, 40000, splits=0, reps=5) < 1e-4
+
+
+def test_h2_argument_errors(gpu):
+    from chameleon_recsys_amd._lib import ptr
+    lib = _lib_()
+    P = torch.zeros(2, 256, 256, dtype=torch.float16, device=gpu)
+    r = new_rec(gpu); r[0] = 1.0; r[1] = 1.0
+    C = torch.zeros(256, 256, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    ok = lambda *a: lib.cham_gemm_h2(*a, st)
+    assert ok(ptr(P), 65536, 256, ptr(r), ptr(P), 65536, 256, ptr(r), 0, ptr(C), 256, 256, 256, 24, None, 0, None, 0, 0, 0, None, 0, 1) < 0      # NT: K % 16
+    assert ok(ptr(P), 65536, 256, ptr(r), ptr(P), 65536, 256, ptr(r), 1, ptr(C), 256, 250, 256, 256, None, 0, None, 0, 0, 0, None, 0, 1) < 0     # TN: M % 256
+    assert ok(ptr(P), 65536, 250, ptr(r), ptr(P), 65536, 256, ptr(r), 0, ptr(C), 256, 256, 256, 16, None, 0, None, 0, 0, 0, None, 0, 1) < 0      # lda % 8
+    assert ok(None, 65536, 256, ptr(r), ptr(P), 65536, 256, ptr(r), 0, ptr(C), 256, 256, 256, 16, None, 0, None, 0, 0, 0, None, 0, 1) < 0
+    assert ok(ptr(P), 65536, 256, None, ptr(P), 65536, 256, ptr(r), 0, ptr(C), 256, 256, 256, 16, None, 0, None, 0, 0, 0, None, 0, 1) < 0        # no scale record
+    assert ok(ptr(P), 65536, 256, ptr(r), ptr(P), 65536, 256, ptr(r), 0, ptr(C), 256, 256, 256, 16, None, 1, None, 0, 0, 0, None, 0, 1) < 0      # act without bias
+
+
+# ---- the benchmarked step's own shapes: error next to the native fp32 MFMA on the same operands ----------------------------------------
+def _native(lib, A, lda, tA, B, ldb, tB, C, M, N, K, bias, act, dref, dact, ws, splits):
+    from chameleon_recsys_amd._lib import check, ptr
+    check(lib.cham_gemm_f32(ptr(A), lda, tA, ptr(B), ldb, tB, ptr(C), N, M, N, K, ptr(bias), act, ptr(dref), N, dact, None, 0, 1, 0, ptr(ws),
+                            ws.numel() * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream), "native")
+    torch.cuda.synchronize()
+
+
+def test_h2_big_car_forward_and_dgrad(gpu):
+    lib = _lib_()
+    R, Cw = ROWS, 1024
+    g = torch.Generator(device=gpu).manual_seed(1)
+    A = torch.randn(R, Cw, device=gpu, generator=g)
+    W = torch.randn(Cw, Cw, device=gpu, generator=g) * 0.03
+    bias = torch.randn(Cw, device=gpu, generator=g)
+    Y = torch.randn(R, Cw, device=gpu, generator=g)
+    Ap, ra = split2h_dev(A)
+    Wp, WTp, rw = split2h_dev(W, transposed=True)
+    Yh = split2h_dev(Y)[0][0].contiguous()
+    rows = torch.arange(0, R, R // 2048, device=gpu)[:2048]
+    out = torch.empty(R, Cw, device=gpu)
+    _counts(lib, reset=True)
+    # forward: tanh(A W + b), B operand = planes of W^T
+    _gemm(lib, Ap, R * Cw, Cw, ra, WTp, Cw * Cw, Cw, rw, 0, out, Cw, R, Cw, Cw, bias=bias, act=2)
+    torch.cuda.synchronize()
+    ref = torch.tanh(A[rows].double() @ W.double() + bias.double())
+    e_h2 = float((out[rows].double() - ref).abs().max())
+    _native(lib, A, Cw, 0, W, Cw, 0, out, R, Cw, Cw, bias, 2, None, 0, None, 1)
+    e_nat = float((out[rows].double() - ref).abs().max())
+    print("CAR forward: two-plane fp16 %.2e, native fp32 MFMA %.2e (abs, tanh outputs)" % (e_h2, e_nat))
+    assert e_h2 < 3e-4 and e_h2 < 1.5 * e_nat + 1e-7, (e_h2, e_nat)
+    # dgrad: (A W^T) * leaky'(Y), B operand = planes of W as stored
+    _gemm(lib, Ap, R * Cw, Cw, ra, Wp, Cw * Cw, Cw, rw, 0, out, Cw, R, Cw, Cw, dref=Yh, ldr=Cw, dact=1)
+    torch.cuda.synchronize()
+    ref = (A[rows].double() @ W.double().t()) * torch.where(Y[rows].double() > 0, 1.0, 0.2)
+    scale = float(ref.abs().max())
+    e_h2 = float((out[rows].double() - ref).abs().max()) / scale
+    _native(lib, A, Cw, 0, W, Cw, 1, out, R, Cw, Cw, None, 0, Y, 1, None, 1)
+    e_nat = float((out[rows].double() - ref).abs().max()) / scale
+    print("CAR dgrad: two-plane fp16 %.2e, native fp32 MFMA %.2e (of max)" % (e_h2, e_nat))
+    assert e_h2 < 5e-5 and e_h2 < 1.5 * e_nat + 1e-7, (e_h2, e_nat)
+    c = _counts(lib)
+    assert c[0] == 2 and c[1] == 0, c
+
+
+def test_h2_big_w2_wgrad_splitk(gpu):
+    lib = _lib_()
+    R, Cw = ROWS, 1024
+    g = torch.Generator(device=gpu).manual_seed(4)
+    A = torch.randn(R, Cw, device=gpu, generator=g)
+    # a gradient-like second operand: rows spread over 30 binary orders of magnitude
+    D = torch.randn(R, Cw, device=gpu, generator=g) * torch.exp2(-30 * torch.rand(R, 1, device=gpu, generator=g))
+    (Ap, ra), (Dp, rd) = split2h_dev(A), split2h_dev(D)
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=gpu)
+    out = torch.empty(Cw, Cw, device=gpu)
+    ref = A.double().t() @ D.double()
+    scale = float(ref.abs().max())
+    _native(lib, A, Cw, 1, D, Cw, 0, out, Cw, Cw, R, None, 0, None, 0, ws, 0)
+    e_nat = float((out.double() - ref).abs().max()) / scale
+    for splits in (0, 8, 16, 32):
+        out.fill_(float('nan'))
+        _gemm(lib, Ap, R * Cw, Cw, ra, Dp, R * Cw, Cw, rd, 1, out, Cw, Cw, Cw, R, ws=ws, splits=splits)
+        torch.cuda.synchronize()
+        e_h2 = float((out.double() - ref).abs().max()) / scale
+        print("W2 wgrad (%d splits): two-plane fp16 %.2e, native fp32 MFMA %.2e (of max)" % (splits, e_h2, e_nat))
+        assert e_h2 < 1e-4 and e_h2 < 1.5 * e_nat + 1e-7, (splits, e_h2, e_nat)
+
+
+def test_h2_producers_match_the_three_plane_ones(gpu):
+    """cham_combine_fwd_h2 / cham_mulpred_bwd_h2 / cham_dm_mulpred_h2 against their three-bf16-plane twins on the same inputs: the planes of
+    either format sum back to the same fp32 values (to the formats' own resolution), dpred / b2 partial sums identical."""
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib_()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=gpu).manual_seed(9)
+    C, BT, N, pmax = 256, 37, 50, 1000
+    NC, RV = N + 1, 2 * 37 + 1000 + 1
+    Rc = BT * NC
+    U = torch.randn(BT, C, device=gpu, generator=g)
+    V = torch.randn(RV, C, device=gpu, generator=g)
+    neg_slot = torch.randint(0, pmax, (BT, N), device=gpu, generator=g, dtype=torch.int32)
+    Z3 = torch.zeros(3, Rc, C, dtype=torch.bfloat16, device=gpu)
+    Z2h = torch.zeros(2, Rc, C, dtype=torch.float16, device=gpu)
+    rec = new_rec(gpu)
+    check(lib.cham_combine_fwd_p3(ptr(U), ptr(V), C, BT, N, pmax, ptr(neg_slot), ptr(Z3), Rc * C, st), "p3")
+    check(lib.cham_h2_scale_absmax(ptr(U), U.numel(), ptr(V), V.numel(), ptr(rec), st), "scale")
+    check(lib.cham_combine_fwd_h2(ptr(U), ptr(V), C, BT, N, pmax, ptr(neg_slot), ptr(Z2h), Rc * C, ptr(rec), st), "h2")
+    torch.cuda.synchronize()
+    z3 = Z3.double().sum(0)
+    z2 = Z2h.double().sum(0) * float(rec[1])
+    assert float(Z2h[0].float().abs().max()) <= 2.0 ** 15
+    assert float((z3 - z2).abs().max()) <= 2.0 ** -21 * float(z3.abs().max())
+    assert torch.equal(Z2h[0].view(torch.int16) > 0, z3 > 0)
+    # gradient at the CAR tanh: unfused and fused forms
+    dS1 = torch.randn(Rc, 128, device=gpu, generator=g) * torch.exp2(-20 * torch.rand(Rc, 1, device=gpu, generator=g))
+    Ws1 = torch.randn(C, 128, device=gpu, generator=g) * 0.05
+    Z2c = torch.tanh(torch.randn(Rc, C, device=gpu, generator=g))
+    pred = torch.tanh(torch.randn(BT, C, device=gpu, generator=g))
+    Wp = torch.zeros(3, C, 128, dtype=torch.bfloat16, device=gpu)
+    check(lib.cham_split3(ptr(Ws1), C, 128, 128, ptr(Wp), C * 128, 128, None, 0, 0, st), "split3")
+    rn, rd = new_rec(gpu), new_rec(gpu)
+    check(lib.cham_h2_scale_rownorm(ptr(Ws1), C, 128, 128, None, ptr(rn), st), "rownorm")
+    check(lib.cham_h2_scale_rownorm(ptr(dS1), Rc, 128, 128, rn.data_ptr() + 8, ptr(rd), st), "rownorm")
+    D3 = torch.zeros(3, Rc, C, dtype=torch.bfloat16, device=gpu)
+    D2 = torch.zeros(2, Rc, C, dtype=torch.float16, device=gpu)
+    dp3, dp2, b3, b2 = (torch.zeros(BT, C, device=gpu) for _ in range(4))
+    check(lib.cham_dm_mulpred_p3(ptr(dS1), 128, 128, ptr(Wp), C * 128, ptr(Z2c), ptr(pred), C, BT, N, ptr(D3), Rc * C, ptr(dp3), ptr(b3), st), "dm p3")
+    check(lib.cham_dm_mulpred_h2(ptr(dS1), 128, 128, ptr(Wp), C * 128, ptr(Z2c), ptr(pred), C, BT, N, ptr(D2), Rc * C, ptr(rd), ptr(dp2), ptr(b2), st), "dm h2")
+    torch.cuda.synchronize()
+    d3 = D3.double().sum(0)
+    d2 = D2.double().sum(0) * float(rd[1])
+    dM = dS1.double() @ Ws1.double().t()
+    assert float(dM.abs().max()) <= float(rd[2]), "the Cauchy-Schwarz bound must hold"
+    assert float(D2[0].float().abs().max()) <= 2.0 ** 15 and torch.isfinite(D2.float()).all()
+    assert float((d3 - d2).abs().max()) <= 2.0 ** -21 * float(d3.abs().max()) + 2.0 ** -24 * float(rd[1])
+    assert torch.equal(dp3, dp2) and torch.equal(b3, b2)
+    # unfused form on the fp32 dM
+    dMf = dM.float().contiguous()
+    D2u = torch.zeros(2, Rc, C, dtype=torch.float16, device=gpu)
+    dpu, bu = torch.zeros(BT, C, device=gpu), torch.zeros(BT, C, device=gpu)
+    check(lib.cham_mulpred_bwd_h2(ptr(dMf), ptr(Z2c), ptr(pred), C, BT, N, ptr(dpu), ptr(D2u), Rc * C, ptr(bu), ptr(rd), st), "mulpred h2")
+    torch.cuda.synchronize()
+    d2u = D2u.double().sum(0) * float(rd[1])
+    assert float((d2u - d3).abs().max()) <= 1e-5 * float(d3.abs().max())

@@ -7,11 +7,16 @@ from chameleon_recsys_amd.nar import nar_model
 class _FakePlan:
     def __init__(self, rt, B, T, N, n_buf, Bg):
         self.key = (B, T, N, n_buf, Bg)
+        self._bytes = nar_model.StepPlan.estimate_bytes(rt.layout, B, T, N, rt)
+
+    def allocated_bytes(self):
+        return self._bytes
 
 
 def _runtime(max_plans, budget, monkeypatch):
     rt = object.__new__(nar_model.NARRuntime)            # no device: only the cache fields plan() touches
     rt._plans, rt.max_plans, rt.plan_bytes_budget = {}, max_plans, budget
+    rt.p3 = rt.h2 = False
 
     class _L:
         C = 1024
@@ -34,6 +39,15 @@ def test_plan_cache_evicts_least_recently_used_shape(monkeypatch):
 def test_plan_cache_respects_byte_budget(monkeypatch):
     one = nar_model.StepPlan.estimate_bytes(type("L", (), {"C": 1024}), 256, 19, 50)
     assert 4.0e9 < one < 6.0e9                              # G1 shape: ~4.4 GB of CAR / scorer activations
+    # the plane-resident operands of the candidate-row CAR GEMMs are part of the estimate: Z1 and dZ2 as two fp16 /
+    # three bf16 planes
+    class _Lib:
+        @staticmethod
+        def cham_group_rows_segments_len(n):
+            return n
+    planes = lambda h2: nar_model.StepPlan.estimate_bytes(type("L", (), {"C": 1024}), 256, 19, 50,
+                                                          type("RT", (), {"p3": True, "h2": h2, "lib": _Lib})) - one
+    assert 2.0e9 < planes(True) < 2.2e9 and 3.0e9 < planes(False) < 3.2e9
     rt = _runtime(24, int(2.5 * one), monkeypatch)
     for T in (19, 18, 17, 16):
         rt.plan(256, T, 50, 3000)
