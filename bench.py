@@ -31,6 +31,7 @@ ADRESSA = dict(n_items=13000, ace_dim=250, seq_len=30, batch=256, neg=100, neg_f
                reg_weight_decay=1e-4)
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 X3_MATRIX_PEAK_TFLOPS = 2500.0 / 6    # fp32 GEMM as six bf16-plane products per fp32 product (csrc/gemm_x3.hip): the bf16 dense peak / 6
+H2_MATRIX_PEAK_TFLOPS = 2500.0 / 3    # fp32-grade GEMM as three fp16-plane products per fp32 product (csrc/gemm_h2.hip): the fp16 dense peak / 3
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PFLOP/s headline includes 2:1 sparsity)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 
@@ -93,6 +94,8 @@ def gemm_symbol(r):
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
         return "k_dm_mulpred_fused(DmfParams)"
+    if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
+        return "void gemm_h2_kernel<%s, %d>(H2Params)" % (tf(bool(r['transA'])), epi)
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
         var = int(os.environ.get("CHAM_P3_VARIANT", "0"))
         if var == 2 and not r['transA'] and epi != 6:
@@ -452,8 +455,11 @@ def main():
         sh[0] += 1; sh[1] += t_ms
         # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
         # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
-        if r.get('dmf'):      # dS1 in, Z2c in, three planes out, pred / dpred / b2 partials per position
-            e['bytes'] += 4.0 * r['M'] * r['K'] + 6.0 * r['K'] * r['N'] + 4.0 * r['M'] * r['N'] + 6.0 * r['M'] * r['N']
+        if r.get('dmf'):      # dS1 in, Z2c in, the planes out (6 B per element as three bf16 planes, 4 B as two fp16 planes), pred / dpred / b2 partials per position
+            e['bytes'] += 4.0 * r['M'] * r['K'] + 6.0 * r['K'] * r['N'] + 4.0 * r['M'] * r['N'] + (4.0 if r.get('h2out') else 6.0) * r['M'] * r['N']
+        elif r.get('h2'):       # operands as two fp16 planes (4 B per element), fp32 output, the dgrad reads the activation's h plane
+            e['bytes'] += 4.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
+                (4.0 * r['N'] if r['bias'] else 0)
         elif r.get('p3'):       # operands as three bf16 planes (6 B per element), fp32 output, the dgrad reads the activation's h plane
             e['bytes'] += 6.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
                 (4.0 * r['N'] if r['bias'] else 0)
@@ -472,7 +478,9 @@ def main():
                                                                  ("NT (dgrad)" if r['dref'] or not r['bias'] else "NT (forward, transposed weight shadow)"))
         return "%s = %s MFMA GEMM, %s, %s%s; M,N,K of its largest launch %d,%d,%d" % (
             sym, ("bf16-resident, LDS-DMA staging" if r.get('b1') else "bf16-resident" if r.get('b16') else "bf16 (fp32 storage, rounded while staged)") if r['bf16'] else
-            ("fp32-grade (operands resident in HBM as three bf16 planes written by their producers, six bf16 MFMA products per fp32 product, "
+            ("fp32-grade (operands resident in HBM as two fp16 planes x a power-of-two scale written by their producers, three fp16 MFMA "
+             "products per fp32 product, fp32 accumulate, LDS-DMA staging)" if r.get('h2') else
+             "fp32-grade (operands resident in HBM as three bf16 planes written by their producers, six bf16 MFMA products per fp32 product, "
              "fp32 accumulate, LDS-DMA staging)" if r.get('p3') else
              "fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])
@@ -480,7 +488,8 @@ def main():
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3') or e['r'].get('dmf')) else FP32_MATRIX_PEAK_TFLOPS)
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (H2_MATRIX_PEAK_TFLOPS if e['r'].get('h2') else
+                                                               X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3') or e['r'].get('dmf')) else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
                 "mfma_peak_tflops": round(peak, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBPS, 4),
@@ -491,8 +500,9 @@ def main():
                              for (m, n_, k), (c, t) in sorted(e['shapes'].items(), key=lambda kv: -kv[1][1])[:3]]}
     DOM_SYMBOL, dom = ranked[0] if ranked else ("", dict(n=1, ms=1.0, flop=0.0, bytes=0.0, r=None))
     n_nn, ms_nn, fl_nn = dom['n'], dom['ms'], dom['flop']
+    dom_h2 = bool(dom['r'] and dom['r'].get('h2'))
     dom_x3 = bool(dom['r'] and (dom['r'].get('x3') or dom['r'].get('p3')))
-    dom_peak = X3_MATRIX_PEAK_TFLOPS if dom_x3 else FP32_MATRIX_PEAK_TFLOPS
+    dom_peak = H2_MATRIX_PEAK_TFLOPS if dom_h2 else (X3_MATRIX_PEAK_TFLOPS if dom_x3 else FP32_MATRIX_PEAK_TFLOPS)
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
     traffic, traffic_src = None, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
@@ -573,17 +583,24 @@ def main():
                        "sessions_per_gpu_per_step": Bl, "global_batch": Bg, "negatives": cfg['neg'],
                        "CAR_embedding_size": cfg['C'], "rnn_units": cfg['H'], "rnn_cell": cfg.get('rnn_cell', 'ugrnn'), "rnn_layers": cfg.get('rnn_num_layers', 1),
                        "session_lengths": args.length_dist, "parallelism": "dp%d" % world, "clicked_items_state": args.state,
-                       "gemm": {"f32": "fp32 accumulate / epilogues; GEMMs with N > 64 as six bf16-plane products per fp32 product on "
-                                       "v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py, tests/test_gemm_p3_gpu.py) - the three candidate-row "
-                                       "CAR GEMMs over planes their producers wrote to HBM (csrc/gemm_p3.hip), the others split while staged "
-                                       "(csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32",
+                       "gemm": {"f32": ("fp32 accumulate / epilogues, fp32-grade error (float64-error bar next to the native fp32 MFMA: tests/test_gemm_h2_gpu.py, "
+                                        "tests/test_gemm_x3_gpu.py): the three candidate-row CAR GEMMs as THREE fp16-plane products per fp32 product over "
+                                        "(h, l) fp16 planes x a device-derived power-of-two scale that their producers wrote to HBM (csrc/gemm_h2.hip, "
+                                        "v_mfma_f32_32x32x16_f16); the other GEMMs with N > 64 as six bf16-plane products split while staged "
+                                        "(csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32") if getattr(rt, 'h2', False) else
+                                       ("fp32 accumulate / epilogues; GEMMs with N > 64 as six bf16-plane products per fp32 product on "
+                                        "v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py, tests/test_gemm_p3_gpu.py) - the three candidate-row "
+                                        "CAR GEMMs over planes their producers wrote to HBM (csrc/gemm_p3.hip), the others split while staged "
+                                        "(csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32"),
                                 "f32_native": "every GEMM on v_mfma_f32_32x32x2_f32",
                                 "bf16": "bf16-resident candidate-row matrices, fp32 accumulate"}[args.dtype],
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",
                          "achieved": round(achieved, 2), "peak": round(dom_peak, 1), "unit": "TFLOP/s",
-                         "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 plane products per fp32 product; algorithmic fp32 FLOPs in `achieved` "
+                         "peak_note": ("fp16 dense MFMA peak 2500 TFLOP/s / 3 plane products per fp32 product; algorithmic fp32 FLOPs in `achieved` "
+                                       "(the native fp32 MFMA peak is %.1f)" % FP32_MATRIX_PEAK_TFLOPS) if dom_h2 else
+                                      ("bf16 dense MFMA peak 2500 TFLOP/s / 6 plane products per fp32 product; algorithmic fp32 FLOPs in `achieved` "
                                        "(the native fp32 MFMA peak is %.1f)" % FP32_MATRIX_PEAK_TFLOPS) if dom_x3 else "fp32 dense MFMA peak",
                          "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": round(n_nn / nprof, 2), "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),

@@ -1326,7 +1326,7 @@ class NARModuleModel:
             if prof is not None:
                 e1.record()
                 prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=False,
-                                 dmf=True, tile=0, epi=0, ev=(e0, e1)))
+                                 dmf=True, h2out=bool(h2), tile=0, epi=0, ev=(e0, e1)))
         elif h2:          # gradient at the CAR tanh straight into two fp16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_h2(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part),
                                           ptr(pl.sc_dz2), s), "cham_mulpred_bwd_h2")
