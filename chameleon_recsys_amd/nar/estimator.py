@@ -163,10 +163,19 @@ class Estimator:
         return due
 
     def get_variable_value(self, name):
-        return self._store['runtime'].logical_weights()[name]
+        """tf.estimator.Estimator.get_variable_value: by the reference graph's TF variable name (layout.tf_variable_names(), ':0' and the
+        alias spellings accepted) or by the short logical name; the reference's shapes (un-padded, UGRNN kernel as [I + H, 2 H])."""
+        L = self._store['runtime'].layout
+        w = self._store['runtime'].logical_weights()
+        if name in w:
+            return w[name]
+        k = name[:-2] if name.endswith(':0') else name
+        k = L.tf_variable_aliases().get(k, k)
+        return w[L.tf_variable_names()[k]]
 
     def get_variable_names(self):
-        return list(self._store['runtime'].layout.logical_specs().keys())
+        """tf.estimator.Estimator.get_variable_names: the trainable variables of the reference graph under their TF names."""
+        return list(self._store['runtime'].layout.tf_variable_names().keys())
 
     @property
     def global_step(self):

@@ -261,6 +261,92 @@ class ParamLayout:
             specs['match%d/bias' % (i + 1)] = ((dims[i + 1],), 'zeros', False)
         return specs
 
+    # ------------------------------------------------------------------ TF variable names
+    def tf_variable_names(self):
+        """OrderedDict: TensorFlow variable name of the reference graph -> logical tensor name (same shapes: the logical tensors ARE the
+        reference's variables - un-padded, the UGRNN kernel re-assembled to [I + H, 2 H] from the Wx / Wh blocks of the flat buffer by
+        unpack()).  So that weights can be cross-loaded from / exported to a real TF 1.12 checkpoint of nar_module (tf.train.load_variable
+        / tf.train.list_variables give name -> array), should one ever be available; TF itself cannot run here.
+        Scopes follow nar_model.py: "main" (:210) / "user_items_contextual_features" (:314) / "features" (:744) /
+        "{name}_cat_embedding/{name}_embedding" (:737-739); "item_features" (:922) / "item_cat_embedding/items_embedding" (:913-916);
+        "input_features_center_scale/{gamma_scale, beta_center}" (:890-895); "CAR/{PreCAR,CAR}_representation" (:374-387);
+        "RNN/rnn/multi_rnn_cell/cell_l/ugrnn_cell" (:1309-1342; tf.nn.rnn_cell.GRUCell: "gru_cell/{gates, candidate}");
+        "session_representation/{FC1, FC2}" (:410-425); "recommendations_ranking/matching_dense_layer_{1..4}" (:444-472).
+        tf.layers.Dense OBJECTS (PreCAR / CAR / matching layers) are created in one scope and first CALLED in another; which of the two
+        TF 1.12 puts in the variable name cannot be verified here - tf_variable_aliases() lists the other spelling and
+        from_tf_variables() accepts either."""
+        m = OrderedDict()
+        ucf = 'main/user_items_contextual_features/'
+        for name in self.entries:
+            if name.startswith('ctx_emb/'):
+                f = name.split('/', 1)[1]
+                m[ucf + 'features/%s_cat_embedding/%s_embedding' % (f, f)] = name
+            elif name.startswith('meta_emb/'):
+                f = name.split('/', 1)[1]
+                m[ucf + 'item_features/features/%s_cat_embedding/%s_embedding' % (f, f)] = name
+            elif name == 'items_embedding':
+                m[ucf + 'item_features/item_cat_embedding/items_embedding'] = name
+        m[ucf + 'input_features_center_scale/gamma_scale'] = 'gamma'
+        m[ucf + 'input_features_center_scale/beta_center'] = 'beta'
+        for tf_l, lg in (('PreCAR_representation', 'PreCAR'), ('CAR_representation', 'CAR')):
+            m['main/CAR/%s/kernel' % tf_l] = lg + '/kernel'
+            m['main/CAR/%s/bias' % tf_l] = lg + '/bias'
+        for l in range(self.L):
+            cell = 'main/RNN/rnn/multi_rnn_cell/cell_%d/' % l
+            if self.cell == 'ugrnn':
+                m[cell + 'ugrnn_cell/kernel'] = 'rnn/%d/kernel' % l
+                m[cell + 'ugrnn_cell/bias'] = 'rnn/%d/bias' % l
+            else:
+                for part in ('gates', 'candidate'):
+                    m[cell + 'gru_cell/%s/kernel' % part] = 'rnn/%d/%s/kernel' % (l, part)
+                    m[cell + 'gru_cell/%s/bias' % part] = 'rnn/%d/%s/bias' % (l, part)
+        for fc in ('FC1', 'FC2'):
+            m['main/session_representation/%s/kernel' % fc] = fc + '/kernel'
+            m['main/session_representation/%s/bias' % fc] = fc + '/bias'
+        for i in range(1, 5):
+            m['main/recommendations_ranking/matching_dense_layer_%d/kernel' % i] = 'match%d/kernel' % i
+            m['main/recommendations_ranking/matching_dense_layer_%d/bias' % i] = 'match%d/bias' % i
+        assert set(m.values()) == set(self.logical_specs())
+        return m
+
+    def tf_variable_aliases(self):
+        """Alternative spelling -> canonical TF name for the Dense layers whose first call happens in a nested scope (nar_model.py:390-392:
+        "user_personalized_contextual_article_embedding/input"; :476: "recommendations_ranking/cos_sim_positive")."""
+        a = OrderedDict()
+        for tf_l in ('PreCAR_representation', 'CAR_representation'):
+            for v in ('kernel', 'bias'):
+                a['main/user_personalized_contextual_article_embedding/input/%s/%s' % (tf_l, v)] = 'main/CAR/%s/%s' % (tf_l, v)
+        for i in range(1, 5):
+            for v in ('kernel', 'bias'):
+                a['main/recommendations_ranking/cos_sim_positive/matching_dense_layer_%d/%s' % (i, v)] = \
+                    'main/recommendations_ranking/matching_dense_layer_%d/%s' % (i, v)
+        return a
+
+    def to_tf_variables(self, logical):
+        """logical dict (unpack / logical_weights) -> {TF variable name: array of the reference's shape}."""
+        return OrderedDict((tf_name, np.asarray(logical[lg])) for tf_name, lg in self.tf_variable_names().items())
+
+    def from_tf_variables(self, tf_vars, strict=True):
+        """{TF variable name (with or without ':0', canonical or alias spelling): array} -> logical dict for pack() /
+        NARRuntime.load_logical_weights.  Optimizer slots (".../Adam", ".../Adam_1"), global_step and beta power accumulators of a real
+        checkpoint are ignored; strict: every model variable must be present with the reference's shape."""
+        names, alias, specs = self.tf_variable_names(), self.tf_variable_aliases(), self.logical_specs()
+        out = OrderedDict()
+        for k, v in tf_vars.items():
+            k = k[:-2] if k.endswith(':0') else k
+            k = alias.get(k, k)
+            if k not in names:
+                continue
+            lg = names[k]
+            v = np.asarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(specs[lg][0]):
+                raise ValueError("TF variable %s has shape %r, the model expects %r" % (k, tuple(v.shape), tuple(specs[lg][0])))
+            out[lg] = v
+        missing = [t for t, lg in names.items() if lg not in out]
+        if strict and missing:
+            raise KeyError("TF checkpoint lacks %d model variables, e.g. %s" % (len(missing), missing[:3]))
+        return OrderedDict((k, out[k]) for k in specs if k in out)
+
     def init_logical(self, seed=42, max_random_elems=None):
         """TF-1.12 initialiser distributions (xavier_initializer, variance_scaling_initializer(), lecun_uniform;
         nar_model.py:210, 377, 413, 449-470).  TF's own random streams are not reproducible."""

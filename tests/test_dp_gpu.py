@@ -24,6 +24,23 @@ def _params(**over):
     return H.tiny_params(**kw)
 
 
+def _assert_shadows_fresh(rt):
+    """The weight shadows the candidate-row GEMMs read (bf16 copies / fp16 plane pairs of W2) are images of the CURRENT fp32 master
+    weights after refresh_shadows() - also when the weights were last written by a collective (broadcast at start-up, all-gather after the
+    sharded / hybrid Adam) rather than by this rank's own Adam kernel."""
+    rt.refresh_shadows()
+    if rt.b16:
+        for name in ('W2', 'Ws1'):
+            w = rt.p(name)
+            assert torch.equal(rt.shadow[name], w.bfloat16()) and torch.equal(rt.shadow[name + 'T'], w.t().bfloat16()), name
+    if getattr(rt, 'h2', False):
+        w = rt.p('W2').double()
+        back = (rt.w2p[0].double() + rt.w2p[1].double()) * float(rt.sc_w2[1])
+        backT = (rt.w2tp[0].double() + rt.w2tp[1].double()) * float(rt.sc_w2[1])
+        tol = 2.0 ** -21 * float(w.abs().max())
+        assert float((back - w).abs().max()) <= tol and float((backT - w.t()).abs().max()) <= tol
+
+
 def _run(dp_world, rank, batches, p, mode=None):
     from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
     from chameleon_recsys_amd.nar.parallel import DataParallelNAR
@@ -36,6 +53,7 @@ def _run(dp_world, rank, batches, p, mode=None):
         st.update_from_device_batch(torch.from_numpy(aci).cuda(), torch.from_numpy(f['event_timestamp']).cuda())
     losses = []
     for f, l in batches[2:2 + STEPS]:
+        _assert_shadows_fresh(model.rt)
         model.feed_state(st, st)
         d = dp.upload(f, l)
         model.train_step(d)
@@ -130,7 +148,15 @@ def test_two_rank_training_in_every_arithmetic_and_exchange_mode(gpu, tmp_path):
             k = "%s/%s/" % (dtype, mode)
             assert np.array_equal(r0[k + 'flat'], r1[k + 'flat']), k                 # replicas stay bit-identical
             assert np.array_equal(r0[k + 'm'], r1[k + 'm']), k
-            assert np.abs(losses - r0[k + 'losses']).max() < (2e-4 if dtype == 'bf16' else 2e-5), (k, losses, r0[k + 'losses'])
-            # fp32 summation order of the two row shards is the only difference - in bf16 too: the per-row matrices are rounded per element,
-            # independent of the sharding; the weight shadows are fresh after every exchange or the trajectories part at step 2
-            H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=1e-3 if dtype == 'bf16' else 1e-4)
+            # fp32 summation order of the two row shards is the only difference in the FIRST step (bit-identical losses there in bf16 too).
+            # From the second step on, bf16 amplifies it: a weight that differs in its last fp32 bit can round to the other bf16 neighbour
+            # (2^-8 relative) in the shadow - measured on MI355X: losses apart by 9e-5 at step 2, 6e-4 at step 3 (fp32: < 2e-5).  The
+            # freshness of the shadows themselves is asserted directly in every step (_assert_shadows_fresh).
+            assert np.abs(losses[0] - r0[k + 'losses'][0]).max() < 2e-5, (k, losses, r0[k + 'losses'])
+            assert np.abs(losses - r0[k + 'losses']).max() < (3e-3 if dtype == 'bf16' else 2e-5), (k, losses, r0[k + 'losses'])
+            # (bf16: first moments within 5 % of the largest; weights compared where |m| is above 25 % of the largest - an entry below the
+            # m tolerance can have its sign decided by the amplified noise, and Adam moves it by +-lr per step either way)
+            if dtype == 'bf16':
+                H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=5e-2, w_tol=0.5, floor=0.25)
+            else:
+                H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=1e-4)

@@ -118,6 +118,14 @@ def test_estimator_train_evaluate_matches_oracle(gpu, tmp_path):
     T.clicked_items_state = st_again
     res3 = est3.evaluate(input_fn(files[4]))
     assert est3.global_step == est.global_step and abs(res3['loss'] - res1['loss']) < 1e-6
+    # tf.estimator.Estimator.get_variable_names / get_variable_value under the reference graph's TF variable names
+    names = est.get_variable_names()
+    assert 'main/CAR/PreCAR_representation/kernel' in names and 'main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/kernel' in names
+    k = est.get_variable_value('main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/kernel:0')
+    rtl = est._store['runtime'].layout
+    assert k.shape == (rtl.C + rtl.H, 2 * rtl.H) and np.array_equal(k, est.get_variable_value('rnn/0/kernel'))
+    assert np.array_equal(est.get_variable_value('main/user_personalized_contextual_article_embedding/input/CAR_representation/kernel'),
+                          est.get_variable_value('main/CAR/CAR_representation/kernel'))
     # a checkpoint written for another parameter layout is refused (same flat size would otherwise load silently)
     rt = est._store['runtime']
     sd = rt.state_dict()

@@ -1,0 +1,85 @@
+"""the TF-variable-name <-> tensor map of the reference graph (nar_model.py:210, 375-388, 411-426, 447-473,
+737-739, 890-895, 913-916, 1317): names, shapes, the [I + H, 2 H] UGRNN kernel re-assembled from the Wx / Wh blocks of the flat buffer,
+pad stripping, and the round trip flat buffer -> TF-named arrays -> flat buffer (no GPU needed)."""
+import numpy as np
+import pytest
+
+from chameleon_recsys_amd.nar import synthetic
+from chameleon_recsys_amd.nar.layout import ParamLayout
+
+
+def _layout(p, **kw):
+    ace = p['content_article_embeddings_matrix']
+    return ParamLayout(p['session_features_config'], p['articles_features_config'], ace.shape[0], ace.shape[1], p['CAR_embedding_size'],
+                       p['rnn_units'], **kw)
+
+
+def test_g1_variable_inventory_matches_survey_a10():
+    p = synthetic.default_params(46000, 250, C=1024, H=255)
+    L = _layout(p)
+    names = L.tf_variable_names()
+    shapes = {tf: tuple(L.logical_specs()[lg][0]) for tf, lg in names.items()}
+    ucf = 'main/user_items_contextual_features/'
+    expect = {
+        ucf + 'features/os_cat_embedding/os_embedding': (23, 17),
+        ucf + 'features/country_cat_embedding/country_embedding': (12, 14),
+        ucf + 'features/region_cat_embedding/region_embedding': (29, 18),
+        ucf + 'item_features/features/category_id_cat_embedding/category_id_embedding': (461, 37),
+        ucf + 'item_features/item_cat_embedding/items_embedding': (46000, 117),
+        ucf + 'input_features_center_scale/gamma_scale': (477,),
+        ucf + 'input_features_center_scale/beta_center': (477,),
+        'main/CAR/PreCAR_representation/kernel': (477, 1024), 'main/CAR/PreCAR_representation/bias': (1024,),
+        'main/CAR/CAR_representation/kernel': (1024, 1024), 'main/CAR/CAR_representation/bias': (1024,),
+        'main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/kernel': (1279, 510), 'main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/bias': (510,),
+        'main/session_representation/FC1/kernel': (255, 512), 'main/session_representation/FC1/bias': (512,),
+        'main/session_representation/FC2/kernel': (512, 1024), 'main/session_representation/FC2/bias': (1024,),
+        'main/recommendations_ranking/matching_dense_layer_1/kernel': (1024, 128), 'main/recommendations_ranking/matching_dense_layer_1/bias': (128,),
+        'main/recommendations_ranking/matching_dense_layer_2/kernel': (128, 64), 'main/recommendations_ranking/matching_dense_layer_2/bias': (64,),
+        'main/recommendations_ranking/matching_dense_layer_3/kernel': (64, 32), 'main/recommendations_ranking/matching_dense_layer_3/bias': (32,),
+        'main/recommendations_ranking/matching_dense_layer_4/kernel': (32, 1), 'main/recommendations_ranking/matching_dense_layer_4/bias': (1,),
+    }
+    assert shapes == expect
+    n_dense = sum(int(np.prod(s)) for k, s in shapes.items() if 'embedding' not in k)
+    assert 2.9e6 < n_dense < 3.1e6 and sum(int(np.prod(s)) for s in shapes.values()) == n_dense + 46000 * 117 + 461 * 37 + 23 * 17 + 12 * 14 + 29 * 18
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rnn_num_layers=2), dict(rnn_cell='gru', rnn_num_layers=2)])
+def test_round_trip_flat_buffer_tf_names_flat_buffer(kw):
+    p = synthetic.default_params(1000, 64, C=128, H=100)          # H = 100 -> padded to 128 in the flat buffer
+    L = _layout(p, **kw)
+    rng = np.random.default_rng(0)
+    logical = L.init_logical(3)
+    for k in logical:          # nothing left at an initialiser's zeros / ones: a swapped block would go unnoticed otherwise
+        logical[k] = rng.standard_normal(logical[k].shape).astype(np.float32)
+    flat = L.pack(logical)
+    tfv = L.to_tf_variables(L.unpack(flat))
+    assert list(tfv) == list(L.tf_variable_names())
+    if kw.get('rnn_cell') == 'gru':
+        assert tfv['main/RNN/rnn/multi_rnn_cell/cell_1/gru_cell/gates/kernel'].shape == (200, 200)
+        assert tfv['main/RNN/rnn/multi_rnn_cell/cell_0/gru_cell/candidate/kernel'].shape == (228, 100)
+    else:
+        k0 = tfv['main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/kernel']
+        assert k0.shape == (128 + 100, 200)
+        # rows [0, C) are the input block (Wx), rows [C, C + H) the recurrent block (Wh); columns [0, H) the gate, [H, 2 H) the candidate
+        e_x, e_h = L.entries['rnn0/Wx'], L.entries['rnn0/Wh']
+        Wx = flat[e_x.offset:e_x.offset + int(np.prod(e_x.shape))].reshape(e_x.shape)
+        Wh = flat[e_h.offset:e_h.offset + int(np.prod(e_h.shape))].reshape(e_h.shape)
+        assert np.array_equal(k0[:128, :100], Wx[:128, :100]) and np.array_equal(k0[:128, 100:], Wx[:128, L.Hp:L.Hp + 100])
+        assert np.array_equal(k0[128:, :100], Wh[:100, :100]) and np.array_equal(k0[128:, 100:], Wh[:100, L.Hp:L.Hp + 100])
+    # a "checkpoint" as TF would list it: ':0' suffixes, the alias spelling of the Dense layers, optimizer slots and counters mixed in
+    inv_alias = {v: k for k, v in L.tf_variable_aliases().items()}
+    ckpt = {}
+    for i, (k, v) in enumerate(tfv.items()):
+        name = inv_alias.get(k, k) if i % 2 else k
+        ckpt[name + (':0' if i % 3 == 0 else '')] = v
+        ckpt[name + '/Adam'] = np.zeros_like(v)
+    ckpt['global_step'] = np.int64(7); ckpt['main/loss/training/beta1_power'] = np.float32(0.9)
+    back = L.from_tf_variables(ckpt)
+    assert list(back) == list(logical) and all(np.array_equal(back[k], logical[k]) for k in logical)
+    assert np.array_equal(L.pack(back), flat)
+    del ckpt[next(iter(ckpt))]
+    with pytest.raises(KeyError):
+        L.from_tf_variables(ckpt)
+    bad = dict(tfv); bad['main/session_representation/FC1/kernel'] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        L.from_tf_variables(bad)
