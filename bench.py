@@ -49,37 +49,83 @@ def dense_step_flops(B, T, N, F, C, H, L=1):
     return fwd
 
 
-def cpu_baseline(params, cfg, length_dist, seed, n_steps=20):
-    """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of the same workload: n_steps timed
-    optimizer steps of 64-session batches (same shape), with the per-stage breakdown SURVEY 8d asks for."""
+def boundary_setup(cfg, d, n_steps, length_dist, seed, state="device", gemm_dtype="f32"):
+    """What both legs that go through the drop-in boundary start from: GZIP TFRecord session files for n_steps batches (written by the
+    synthetic generator under directory d: the same seed gives the same files), the ACR-module resources loaded the way the trainer loads
+    them, and the Estimator the trainer's build_estimator returns for them.  -> (trainer module, estimator, files, session features config)"""
+    from chameleon_recsys_amd.nar import nar_trainer_gcom as T, synthetic
+    from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, DeviceClickedItemsState
+    B = cfg['batch']
+    per_file = 50 * B
+    n_files = -(-n_steps * B // per_file)
+    files, csv, pkl = synthetic.write_dataset(d, n_files, per_file, cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'],
+                                              seed=seed, length_dist=length_dist)
+    argv = ['--batch_size', str(B), '--truncate_session_length', str(cfg['seq_len']), '--learning_rate', '1e-4', '--reg_l2', '1e-5',
+            '--softmax_temperature', '0.1', '--recent_clicks_buffer_max_size', str(cfg['buffer']),
+            '--recent_clicks_for_normalization', str(cfg['for_norm']), '--eval_metrics_top_n', '5',
+            '--CAR_embedding_size', str(cfg['C']), '--rnn_units', str(cfg['H']),
+            '--train_total_negative_samples', str(cfg['neg']), '--train_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
+            '--eval_total_negative_samples', str(cfg['neg']), '--eval_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
+            '--content_embedding_scale_factor', '6.0', '--disable_eval_benchmarks', '--model_dir', os.path.join(d, 'model'),
+            '--clicked_items_state', state, '--gemm_dtype', gemm_dtype]
+    T.FLAGS = T.define_flags().parse_args(argv)
+    meta_df, ace = T.load_acr_module_resources(csv, pkl)
+    ace = T.l2_normalize_rows(ace) * np.float32(6.0)
+    acfg = T.get_articles_features_config(n_items=ace.shape[0])
+    meta = T.process_articles_metadata(meta_df, acfg)
+    scfg = T.get_session_features_config()
+    T.eval_sessions_metrics_log = []
+    T.clicked_items_state = (DeviceClickedItemsState if state == "device" else ClickedItemsState)(1.0, cfg['buffer'], cfg['for_norm'], ace.shape[0])
+    est = T.build_estimator(os.path.join(d, 'model'), ace, meta, acfg, scfg)
+    est.config.log_step_count_steps = 0
+    est.config.save_checkpoints_secs = 0
+    return T, est, files, scfg
+
+
+def cpu_baseline(cfg, length_dist, seed, n_steps=5):
+    """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of THE SAME JOB the through-boundary leg runs
+    (SURVEY 8d): the first batches of the same GZIP TFRecord session files (same generator, same seed), decoded by the same input_fn
+    (datasets.SessionDataset), at the workload's own batch size, with the Estimator params the trainer builds - 1 warm-up + n_steps timed
+    optimizer steps (forward, backward, TF-Adam, recent-clicks state update), with the per-stage breakdown."""
+    import shutil
+    import tempfile
     import torch
-    from chameleon_recsys_amd.nar import synthetic
+    from chameleon_recsys_amd.nar import datasets
     from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
     from oracle.nar_oracle import NAROracle
     cores = min(len(os.sched_getaffinity(0)), 32)     # beyond ~32 threads the oracle's many small ops only get slower
     torch.set_num_threads(cores)
-    Bs = 64                                    # sample: 64-session batches of the same shape
-    p = dict(params); p['batch_size'] = Bs
-    batches = synthetic.make_batches(n_steps + 1, Bs, cfg['seq_len'], cfg['n_items'], p['session_features_config'], seed=seed,
-                                     length_dist=length_dist, sessions_per_hour=Bs * 4)
-    orc = NAROracle(p, seed=seed)
-    st = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
-    times = []
-    for i, (f, l) in enumerate(batches):
-        if i == 1:
-            orc.timers = {}                    # first step = warm-up
-        t0 = time.perf_counter()
-        orc.train_step(f, l, st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm())
-        with orc._stage('state_update'):
-            ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
-            st.update_items_state(ids, ts)
-        times.append(time.perf_counter() - t0)
+    B = cfg['batch']
+    d = tempfile.mkdtemp(prefix="cham_cpu_")
+    try:
+        T, est, files, scfg = boundary_setup(cfg, d, n_steps + 1, length_dist, seed, state="host")
+        orc = NAROracle(est.params, seed=seed)
+        st = ClickedItemsState(1.0, cfg['buffer'], cfg['for_norm'], cfg['n_items'])
+        times, t_in = [], 0.0
+        it = iter(datasets.SessionDataset(files, scfg, batch_size=B, truncate_sequence_length=cfg['seq_len']))
+        for i in range(n_steps + 1):
+            t0 = time.perf_counter()
+            f, l = next(it)                        # (decode + batch: the C++ codec's share of the step, reported separately)
+            t1 = time.perf_counter()
+            if i == 1:
+                orc.timers = {}                    # first step = warm-up
+                t_in = 0.0
+            orc.train_step(f, l, st.get_recent_clicks_buffer(), st.get_articles_recent_pop_norm())
+            with orc._stage('state_update'):
+                ids, ts = batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp'])
+                st.update_items_state(ids, ts)
+            times.append(time.perf_counter() - t0)
+            t_in += t1 - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     dt, n = sum(times[1:]), len(times) - 1
-    return dict(value=round(Bs * n / dt, 3), unit="sessions/s", cores=cores, kind="port",
-                sample="%d timed optimizer steps of 64-session batches (same shape, 1 warm-up step), restated CPU oracle "
-                       "(PyTorch-CPU fp32, TF 1.12 unavailable), %d threads" % (n, cores),
-                ms_per_step=round(dt / n * 1e3, 1),
-                stage_ms_per_step={k: round(v / n * 1e3, 1) for k, v in orc.timers.items()})
+    stages = {k: round(v / n * 1e3, 1) for k, v in orc.timers.items()}
+    stages['input_fn'] = round(t_in / n * 1e3, 1)
+    return dict(value=round(B * n / dt, 3), unit="sessions/s", cores=cores, kind="port",
+                sample="%d timed optimizer steps (1 warm-up) of %d-session batches decoded from the through-boundary leg's own GZIP TFRecord "
+                       "files (same generator + seed, %s session lengths) by the same input_fn, restated CPU oracle (PyTorch-CPU fp32, TF 1.12 "
+                       "unavailable), %d threads" % (n, B, length_dist, cores),
+                ms_per_step=round(dt / n * 1e3, 1), stage_ms_per_step=stages)
 
 
 def gemm_symbol(r):
@@ -195,30 +241,8 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
     d = tempfile.mkdtemp(prefix="cham_bench_")
     try:
         t0 = time.time()
-        per_file = 50 * B
-        n_files = -(-(warm_steps + timed_steps) * B // per_file)
-        files, csv, pkl = synthetic.write_dataset(d, n_files, per_file, cfg['n_items'], cfg['ace_dim'], seq_len=cfg['seq_len'],
-                                                  seed=seed, length_dist=length_dist)
+        T, est, files, scfg = boundary_setup(cfg, d, warm_steps + timed_steps, length_dist, seed, state, gemm_dtype)
         gen_s = time.time() - t0
-        argv = ['--batch_size', str(B), '--truncate_session_length', str(cfg['seq_len']), '--learning_rate', '1e-4', '--reg_l2', '1e-5',
-                '--softmax_temperature', '0.1', '--recent_clicks_buffer_max_size', str(cfg['buffer']),
-                '--recent_clicks_for_normalization', str(cfg['for_norm']), '--eval_metrics_top_n', '5',
-                '--CAR_embedding_size', str(cfg['C']), '--rnn_units', str(cfg['H']),
-                '--train_total_negative_samples', str(cfg['neg']), '--train_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
-                '--eval_total_negative_samples', str(cfg['neg']), '--eval_negative_samples_from_buffer', str(cfg['neg_from_buffer']),
-                '--content_embedding_scale_factor', '6.0', '--disable_eval_benchmarks', '--model_dir', os.path.join(d, 'model'),
-                '--clicked_items_state', state, '--gemm_dtype', gemm_dtype]
-        T.FLAGS = T.define_flags().parse_args(argv)
-        meta_df, ace = T.load_acr_module_resources(csv, pkl)
-        ace = T.l2_normalize_rows(ace) * np.float32(6.0)
-        acfg = T.get_articles_features_config(n_items=ace.shape[0])
-        meta = T.process_articles_metadata(meta_df, acfg)
-        scfg = T.get_session_features_config()
-        T.eval_sessions_metrics_log = []
-        T.clicked_items_state = (DeviceClickedItemsState if state == "device" else ClickedItemsState)(1.0, cfg['buffer'], cfg['for_norm'], ace.shape[0])
-        est = T.build_estimator(os.path.join(d, 'model'), ace, meta, acfg, scfg)
-        est.config.log_step_count_steps = 0
-        est.config.save_checkpoints_secs = 0
 
         class Clock(SessionRunHook):
             n, t0, t1, n1 = 0, None, None, 0
@@ -246,6 +270,30 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
                     input_pipeline_alone_sessions_per_s=round(n_in / dt_in, 1), dataset_generation_s=round(gen_s, 1))
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def stress_arm(n_items=1_000_000, batch=1024, neg=200, micro=512, steps=2):
+    """BASELINE.json configs[4] (large-catalog stress: 128-d ACE, 200 negatives, item-embedding width floor(8 n^0.25)) scaled to a catalog
+    and batch that fit the default run's budget, as a child process (scripts/stress_large_catalog.py: micro-batched optimizer step, the
+    HBM rooflines of the gather, TF-dense Adam and embedding-gradient kernels).  The full 5 M x 4096 run is the same script's default."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "stress_large_catalog.py"), "--n-items", str(n_items), "--batch", str(batch),
+           "--neg", str(neg), "--micro", str(micro), "--steps", str(steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-400:])}
+        d = json.loads(lines[-1])
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+    keep = ("workload", "n_items", "ace_dim", "batch", "negatives", "micro_batch_sessions", "params", "item_embedding_dim", "setup_s", "step_s",
+            "sessions_per_s", "hbm_gb_allocated", "item_rows_per_micro_batch")
+    arm = {k: d.get(k) for k in keep}
+    arm["command"] = " ".join(["python"] + [os.path.relpath(c, ROOT) if c.endswith(".py") else c for c in cmd[1:]])
+    for k in ("adam", "gather_lds_tiles", "embedding_gradient"):
+        arm[k] = {q: d[k].get(q) for q in ("bound", "algorithmic_bytes", "ms", "achieved_gbs", "peak_gbs", "frac")}
+    return arm
 
 
 def hitrate_parity(seed):
@@ -636,8 +684,9 @@ def main():
             # other, this process idle meanwhile): configs[2]'s arithmetic on one GPU, configs[3]'s shape
             out["bf16_arm"] = child_arm(args, ["--dtype", "bf16"])
             out["adressa_arm"] = child_arm(args, ["--config", "adressa", "--no-ragged-leg"])
+            out["stress_arm"] = stress_arm()          # configs[4] scaled to 1 M articles x 1024 sessions (HBM rooflines of gather / Adam / embedding gradient)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, cfg, args.length_dist, args.seed)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)
         if world > 1:
             dist.barrier()

@@ -604,12 +604,23 @@ void* cham_sessions_open(const char* const* files, int n_files, const char* cons
     if (e != TFR_OK) return nullptr;
     r->batch_size = batch_size; r->truncate = truncate_session_length; r->check_crc = check_crc;
     r->prefetch = prefetch > 0 ? prefetch : 1;
-    // decode threads: CHAM_TFRECORD_THREADS, default min(hardware threads, 16) (datasets.py:118-120 uses cpu_count() map calls; on
-    // the GPU box 8 ranks share 256 host cores; 16 decode + 4 inflate threads: 369 k full-length / 981 k G1-like sessions/s,
-    // profiles/r02_decode_throughput.json)
+    // decode threads: CHAM_TFRECORD_THREADS, default min(this process's share of the hardware threads, 16) (datasets.py:118-120 uses
+    // cpu_count() map calls).  Under data parallelism every rank of the node decodes the GLOBAL batch stream (the integer
+    // tensors are replicated by reading the same files): the share is hardware threads / LOCAL_WORLD_SIZE (torchrun's count of ranks on
+    // this node; WORLD_SIZE when that is absent), less the inflate threads, so 8 ranks do not start 8 x 20 threads on one host.
+    // 16 decode + 4 inflate threads: 369 k full-length / 981 k G1-like sessions/s, profiles/r02_decode_throughput.json
     int nw = 0;
     if (const char* e = getenv("CHAM_TFRECORD_THREADS")) nw = atoi(e);
-    if (nw <= 0) { nw = (int)std::thread::hardware_concurrency(); if (nw > 16) nw = 16; if (nw < 1) nw = 1; }
+    if (nw <= 0) {
+        int ranks = 1;
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = atoi(e);
+        else if (const char* e2 = getenv("WORLD_SIZE")) ranks = atoi(e2);
+        if (ranks < 1) ranks = 1;
+        int share = (int)std::thread::hardware_concurrency() / ranks;
+        nw = share > 20 ? 16 : (share * 4) / 5;          // (a fifth of the share is left to the inflate threads below)
+        if (nw > 16) nw = 16;
+        if (nw < 1) nw = 1;
+    }
     r->n_workers = nw;
     int ni = 0;
     if (const char* e = getenv("CHAM_TFRECORD_INFLATE_THREADS")) ni = atoi(e);

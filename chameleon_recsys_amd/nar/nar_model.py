@@ -264,6 +264,10 @@ class NARRuntime:
         # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
         # per-CU matrix kernels that only time-slice the chip when they overlap
         self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
+        # ... and is the side lane's LAST work: the small weight / bias gradients queued behind it used to wait for the dgrad too
+        self.w2_last = os.environ.get("CHAM_W2_LAST", "1") == "1"
+        if self.h2:
+            self.lib.cham_gemm_h2_set_variant(int(os.environ.get("CHAM_H2_VARIANT", "0")))      # 1 = direct dword NT epilogue (A/B arm)
         self.side_critical_first = os.environ.get("CHAM_SIDE_CRITICAL_FIRST", "1") == "1"
         # three more schedule arms suggested by the kernel trace of the plane-product build, each measured neutral or slower (A/B in one
         # gpurun call, ms/step: all off 12.95 | scorer layer-1 wgrad only after its dgrad dM 13.16 -> +0.06 | the small PreCAR-backward
@@ -1380,6 +1384,7 @@ class NARModuleModel:
             e_w2main = mark()
         # session FCs + recurrent layers (latency-bound: one workgroup per 32 sessions) ...
         last = L.L - 1
+        deferred_w2 = None
         with side(e_dZ2c):
             ss = _stream()
             rnn_y = (lambda l: pl.rnn_drop[l]) if drop else (lambda l: pl.rnn_out[l])     # what the next layer / FC1 consumed
@@ -1443,15 +1448,23 @@ class NARModuleModel:
                     elif use_p3:
                         # ... and the CAR layer-2 weight gradient: the candidate rows from their planes (TN, split-K), the clicked-input
                         # rows (fp32) added by the on-the-fly kernel; b2 from the per-position partial sums of k_mulpred_bwd_p3
-                        if w2_main:       # (the candidate rows' share was written by the main lane: behind e_cdgrad it is complete)
-                            rt.side_stream.wait_event(e_w2main)
-                        else:
-                            if on and rt.w2_after_dgrad:
-                                rt.side_stream.wait_event(e_cdgrad)
-                            w2_wgrad_planes(rt.p3_w2_splits)
-                        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
+                        def w2_grads():
+                            if w2_main:       # (the candidate rows' share was written by the main lane: behind e_cdgrad it is complete)
+                                rt.side_stream.wait_event(e_w2main)
+                            else:
+                                if on and rt.w2_after_dgrad:
+                                    rt.side_stream.wait_event(e_cdgrad)
+                                w2_wgrad_planes(rt.p3_w2_splits)
+                            rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
+                        if on and rt.w2_last and not w2_main:
+                            # the plane weight gradient waits for the main lane's CAR dgrad (two one-workgroup-per-CU matrix kernels only
+                            # time-slice the chip): everything this lane still has to do that does NOT wait - bias sums, the recurrent and
+                            # input-projection weight gradients - goes first and runs under that dgrad; the big GEMM is the lane's last work
+                            deferred_w2 = w2_grads
+                        else:
+                            w2_grads()
                     elif not swap:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
                         if rt.b2_early:          # (needs dZ2 only: runs while this lane waits for the CAR dgrad)
@@ -1472,6 +1485,8 @@ class NARModuleModel:
                 if cell == 1:   # candidate kernel: (r * h_prev)^T dz_c
                     rt.gemm(pl.RH[l], pl.dxproj[:, 2 * Hp:], g('rnn%d/Wch' % l), Hp, Hp, BTf, Hp, NGH, Hp, transA=1, splits=0, force_f32=True)
                 rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn%d/b' % l))
+            if deferred_w2 is not None:
+                deferred_w2()
         def precar_backward(ws):
             """PreCAR combine scatter, W1 weight gradients, feature / embedding backward (on whatever lane is current)."""
             st = _stream()

@@ -197,6 +197,8 @@ int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* 
                  const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr,
                  int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 void cham_gemm_h2_launch_counts(long long* out8, int reset);
+/* A/B aid (tests/bench_gemm_h2.py): 0 = NT epilogue through LDS with 16-byte stores (default), 1 = the direct dword epilogue */
+void cham_gemm_h2_set_variant(int variant);
 /* producers of two-plane matrices (csrc/scorer.hip, csrc/dm_fused.hip): cham_combine_fwd_p3 / cham_mulpred_bwd_p3 / cham_dm_mulpred_p3
  * with the output written as (h, l) fp16 planes x the scale of `scale_rec` (filled BEFORE the call: max|U| + max|V| for the PreCAR output,
  * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */
