@@ -139,14 +139,11 @@ def gemm_symbol(r):
     if r.get('b1'):       # bf16-resident operands on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel)
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
-        return "k_dm_mulpred_fused(DmfParams)"
+        return "void k_dm_mulpred_fused<%s>(DmfParams)" % tf(bool(r.get('h2out')))
     if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
         return "void gemm_h2_kernel<%s, %d>(H2Params)" % (tf(bool(r['transA'])), epi)
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
-        var = int(os.environ.get("CHAM_P3_VARIANT", "0"))
-        if var == 2 and not r['transA'] and epi != 6:
-            return "void gemm_p3h_kernel<%d>(P3Params)" % epi
-        return "void gemm_p3_kernel<%s, %d, %d>(P3Params)" % (tf(bool(r['transA'])), epi, 1 if var == 1 else 0)
+        return "void gemm_p3_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
         rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
@@ -155,7 +152,7 @@ def gemm_symbol(r):
     rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
     if r['bf16']:
         return "void gemm_bf16_kernel<%d, %d, %d, %d, 32, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
-    return "void gemm_f32_kernel<%d, %d, %d, %d, 16, %s, %s, %d, true, 0, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
+    return "void gemm_f32_kernel<%d, %d, %d, %d, 16, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
 
 
 def child_arm(args, extra):

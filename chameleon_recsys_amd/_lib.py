@@ -42,7 +42,6 @@ _SIGNATURES = {
                              P, c_size_t, c_int, P]),
     "cham_gemm_b16_dma": (c_int, [P, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_p3_launch_counts": (None, [P, c_int]),
-    "cham_gemm_p3_set_variant": (None, [c_int]),
     "cham_split3": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P]),
     "cham_combine_fwd_p3": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
     "cham_mulpred_bwd_p3": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P]),
@@ -53,7 +52,6 @@ _SIGNATURES = {
     "cham_gemm_h2": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                              P, c_size_t, c_int, P]),
     "cham_gemm_h2_launch_counts": (None, [P, c_int]),
-    "cham_gemm_h2_set_variant": (None, [c_int]),
     "cham_combine_fwd_h2": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, P]),
     "cham_mulpred_bwd_h2": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P, P]),
     "cham_dm_mulpred_h2": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
@@ -79,7 +77,6 @@ _SIGNATURES = {
     "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_ugrnn_point_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_ugrnn_point_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "cham_rnn_set_exclusive_lds": (None, [c_size_t]),
     "cham_transpose_f32": (c_int, [P, c_int, c_int, P, P]),
     "cham_rows_gather": (c_int, [P, P, c_long, c_int, P, P]),
     "cham_rows_scatter": (c_int, [P, P, c_long, c_int, P, P]),

@@ -114,13 +114,9 @@ struct TileLoader {
             if (NF4 % NTH != 0 && idx >= NF4) continue;
             if (XK) {
                 const int fr = idx / (BK / 4), kq = idx % (BK / 4);
-#ifdef CHAM_PROBE_B128STORE     // probe only (wrong layout, same bytes): what would one ds_write_b128 instead of 4 x ds_write_b32 buy?
-                *reinterpret_cast<float4*>(S + ((kq * (BF / 4) + fr / 4) * 4) * 4 + (fr & 3) * LD * 0) = as_f4(r[i]);
-#else
                 float* d = S + (kq * 4) * LD + fr;
                 d[0] = __uint_as_float(r[i].x); d[LD] = __uint_as_float(r[i].y);
                 d[2 * LD] = __uint_as_float(r[i].z); d[3 * LD] = __uint_as_float(r[i].w);
-#endif
             } else {
                 const int kk = idx / (BF / 4), f4 = idx % (BF / 4);
                 *reinterpret_cast<float4*>(S + kk * LD + f4 * 4) = as_f4(r[i]);
@@ -133,12 +129,8 @@ struct TileLoader {
 template <int BM, int BN, int WM, int WN>
 __host__ __device__ constexpr bool g_sched_hint_static() { return WM * WN <= 4 && BM * BN >= 256 * 256; }
 
-static int g_pipe = 1;          // (the non-pipelined K loop was an A/B arm: neutral, removed; profiles/r01_notes.md item 9)
-
-// EPI: see gemm_epilogue
-// ABL (ablation bits, probe builds only - tests/probe_gemm.hip): 1 = no global loads / LDS writes inside the K loop,
-// 2 = no barrier inside the K loop, 4 = no LDS fragment reads, 8 = minimal epilogue.  0 in the product library.
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE, int ABL = 0, bool RS = false>
+// EPI: see gemm_epilogue.  (The ablation bits and the non-pipelined K loop of the round-1 probes are gone: profiles/r01_notes.md items 3, 9.)
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool RS = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
     using LA = TileLoader<BM, BK, AK, NTH>;
@@ -216,7 +208,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
     __syncthreads();
     const int kl = lane >> 5, fl = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = (ABL & 1) ? 0 : (kt & 1);
+        const int cur = kt & 1;
         // one base register per fragment (kept opaque so that the compiler addresses every k-step with the 16-bit immediate of
         // ds_read_b32 instead of re-basing a ds_read2_b32 pair with a v_add per k-step: VALU slots are MFMA slots)
         int ai[TM], bj[TN];          // indices into smem[] (the array keeps its LDS address space -> ds_read_b32 base + immediate)
@@ -230,29 +222,20 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
         for (int i = 0; i < TM; ++i) a[0][i] = smem[ai[i]];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[0][j] = smem[bj[j]];
-        if (PIPE && kt + 1 < nk && !(ABL & 1)) {        // tile kt+1: registers -> the LDS buffer every wave finished reading at the last barrier
+        if (kt + 1 < nk) {        // tile kt+1: registers -> the LDS buffer every wave finished reading at the last barrier
             if (has_rs) la.apply_scale();
-            if (!(ABL & 16)) {            // probe bit 16: global loads stay, LDS writes (and their vmcnt wait) go
-                la.store(As + (cur ^ 1) * ASZ);
-                lb.store(Bs + (cur ^ 1) * BSZ);
-            }
-            if (kt + 2 < nk && !(ABL & 32)) load_tile(kt + 2);      // probe bit 32: LDS writes stay, global loads go
+            la.store(As + (cur ^ 1) * ASZ);
+            lb.store(Bs + (cur ^ 1) * BSZ);
+            if (kt + 2 < nk) load_tile(kt + 2);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int c = (kk >> 1) & 1;
             if (kk + 2 < BK) {
-                if (ABL & 4) {         // probe: no LDS traffic, operands stay live in registers
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[c ^ 1][i] = a[c][i] + 1e-30f;
+                for (int i = 0; i < TM; ++i) a[c ^ 1][i] = smem[ai[i] + (kk + 2) * LDA];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[c ^ 1][j] = b[c][j] + 1e-30f;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[c ^ 1][i] = smem[ai[i] + (kk + 2) * LDA];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[c ^ 1][j] = smem[bj[j] + (kk + 2) * LDB];
-                }
+                for (int j = 0; j < TN; ++j) b[c ^ 1][j] = smem[bj[j] + (kk + 2) * LDB];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -267,32 +250,15 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p) {
                 }
             }
         }
-        if (!PIPE && kt + 1 < nk) {
-            if (has_rs) la.apply_scale();
-            la.store(As + (cur ^ 1) * ASZ);
-            lb.store(Bs + (cur ^ 1) * BSZ);
-            if (kt + 2 < nk) load_tile(kt + 2);
-        }
-        if (!(ABL & 2)) __syncthreads();
-    }
-    if (ABL & 8) {      // probe: one store per thread keeps the accumulators (and the last loaded tile) live
-        float v = __uint_as_float(la.r[0].x) * 1e-30f + __uint_as_float(lb.r[0].x) * 1e-30f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v += acc[i][j][e];
-        p.C[(size_t)(m0 + wm0 + fl) * p.ldc + n0 + wn0 + kl] = v;
-        return;
+        __syncthreads();
     }
 
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool PIPE, int ABL = 0, bool RS = false>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, bool RS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmParams p) {
-    gemm_f32_body<BM, BN, WM, WN, BK, AK, BKC, EPI, PIPE, ABL, RS>(p);
+    gemm_f32_body<BM, BN, WM, WN, BK, AK, BKC, EPI, RS>(p);
 }
 
 // =====================================================================================================================
@@ -443,7 +409,7 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         constexpr bool RSI = (EPI == 1 && AK && !BKC) || ((EPI == 6 || EPI == 0) && !AK && !BKC);
         if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
         if (RSI && p.rs != nullptr) {
-            auto k = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true, 0, RSI>;
+            auto k = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, RSI>;
             static bool done_rs = false;
             if (!done_rs) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -454,16 +420,16 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
             CHAM_CHECK_LAUNCH();
             return CHAM_OK;
         }
-        kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>);
+        kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>);
     }
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[g_pipe]) {      // (g_pipe is always 1)
+    static bool attr_done = false;
+    if (!attr_done) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -CHAM_ERR_LAUNCH;
-        attr_done[g_pipe] = true;
+        attr_done = true;
     }
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
     if (BF16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, true>), grid, dim3(WM * WN * 64), smem, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
@@ -472,27 +438,39 @@ template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, bool BF16 =
 static int launch_cfg(GemmParams& p, hipStream_t st) {
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
-    int rc;
+    // Epilogues are instantiated for the layouts that use them (a third of the library's code size otherwise):
+    //   NN (forward)  plain | bias | bias + leaky | bias + tanh        NT (dgrad)  plain / accumulate | x leaky'(dref) | x tanh'(dref)
+    //   TN (wgrad)    plain / accumulate | split-K partial
+    // gemm_plan never plans K-splits for NN / NT; the other combinations return -EINVAL.
+    constexpr bool NN = AK && !BKC, NT = AK && BKC, TN = !AK && !BKC;
     if (p.splits > 1) {
-        static const bool tile_major = getenv("CHAM_GEMM_SPLIT_TILE_MAJOR") != nullptr;      // A/B switch: the placement of builds a-i
-        p.xcd_split = (p.splits % 8 == 0 && !tile_major) ? 1 : 0;
-        rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6, BF16>(p, st);
-        if (rc != CHAM_OK) return rc;
-        launch_splitk_reduce(p, st);
-        CHAM_CHECK_LAUNCH();
-        return CHAM_OK;
+        if constexpr (TN) {
+            p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
+            const int rc = launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6, BF16>(p, st);
+            if (rc != CHAM_OK) return rc;
+            launch_splitk_reduce(p, st);
+            CHAM_CHECK_LAUNCH();
+            return CHAM_OK;
+        } else {
+            return -CHAM_ERR_ARG;
+        }
     }
     if (p.dref) {
         if (p.bias || p.act != ACT_NONE) return -CHAM_ERR_ARG;
-        if (p.dact == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3, BF16>(p, st);
-        if (p.dact == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4, BF16>(p, st);
+        if constexpr (NT) {
+            if (p.dact == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3, BF16>(p, st);
+            if (p.dact == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4, BF16>(p, st);
+        }
         return -CHAM_ERR_ARG;
     }
     if (p.bias || p.act != ACT_NONE) {
         if (!p.bias || p.accumulate) return -CHAM_ERR_ARG;       // every activated layer of the model has a bias
-        if (p.act == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1, BF16>(p, st);
-        if (p.act == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2, BF16>(p, st);
-        return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5, BF16>(p, st);
+        if constexpr (NN) {
+            if (p.act == ACT_LEAKY) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1, BF16>(p, st);
+            if (p.act == ACT_TANH) return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2, BF16>(p, st);
+            return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5, BF16>(p, st);
+        }
+        return -CHAM_ERR_ARG;
     }
     return launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0, BF16>(p, st);
 }
@@ -509,13 +487,10 @@ static int launch_by_shape(GemmParams& p, hipStream_t st) {
         // the largest tile whose grid still gives every one of the 256 CUs a workgroup (a 4 864-row GEMM on 256x256 tiles is 76
         // workgroups: 70 % of the chip idle)
         auto grid = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.splits; };
-        static const bool by_area = getenv("CHAM_GEMM_TILE_BY_AREA") != nullptr;      // A/B switch: the rule of builds a-h
         int v = ((long)p.M * p.N >= (1L << 20)) ? 2 : 0;
         if (v == 2 && (!AK || BKC) && p.K >= 512 && p.M >= 1024 && p.N >= 512) v = 4;
-        if (!by_area) {       // ... demoted while the grid does not cover the chip
-            if (v == 4 && grid(256, 256) < 256) v = 2;
-            if (v == 2 && grid(256, 128) < 256) v = 0;
-        }
+        if (v == 4 && grid(256, 256) < 256) v = 2;       // ... demoted while the grid does not cover the chip
+        if (v == 2 && grid(256, 128) < 256) v = 0;
         if (g_variant >= 0) v = g_variant;
         switch (v) {      // (other tile shapes were measured and dropped: profiles/r01_notes.md items 3 and 9)
             case 2: ++g_tile_launches[1]; return launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
@@ -593,38 +568,3 @@ static int gemm_dispatch(int precision, const float* A, int lda, int transA, con
     return -CHAM_ERR_ARG;                                // TT never occurs on this path
 }
 
-#ifdef CHAM_GEMM_PROBE
-// Ablation probe (NOT part of the product library): C[M,N] = A[M,K] * B[K,N], NN, full tiles only, 256x128x16 / 8 waves.
-template <int ABL>
-static int probe_launch(GemmParams& p, hipStream_t st) {
-    using LA = TileLoader<256, 16, true, 512>;
-    using LB = TileLoader<128, 16, false, 512>;
-    const size_t smem = (size_t)2 * 16 * (LA::LD + LB::LD) * sizeof(float);
-    auto kern = gemm_f32_kernel<256, 128, 4, 2, 16, true, false, 0, true, ABL>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    p.nbm = p.M / 256; p.nbn = p.N / 128;
-    hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-extern "C" int cham_gemm_probe(int abl, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
-    GemmParams p = {};
-    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N; p.rs_div = 1;
-    p.kchunk = K; p.splits = 1;
-    hipStream_t st = (hipStream_t)stream;
-    switch (abl) {
-        case 0: return probe_launch<0>(p, st);
-        case 1: return probe_launch<1>(p, st);
-        case 3: return probe_launch<3>(p, st);
-        case 7: return probe_launch<7>(p, st);
-        case 8: return probe_launch<8>(p, st);
-        case 9: return probe_launch<9>(p, st);
-        case 11: return probe_launch<11>(p, st);
-        case 15: return probe_launch<15>(p, st);
-        case 4: return probe_launch<4>(p, st);
-        case 24: return probe_launch<24>(p, st);
-        case 40: return probe_launch<40>(p, st);
-        case 12: return probe_launch<12>(p, st);
-        default: return -22;
-    }
-}
-#endif

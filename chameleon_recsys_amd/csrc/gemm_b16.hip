@@ -356,8 +356,7 @@ static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStrea
     if (!AK) {                                           // TN (wgrad): fp32 out, plain or split-K
         if (p.bias || act != ACT_NONE || p.dref || !out_f32) return -CHAM_ERR_ARG;
         if (p.splits > 1) {
-            static const bool tile_major = getenv("CHAM_GEMM_SPLIT_TILE_MAJOR") != nullptr;
-            p.xcd_split = (p.splits % 8 == 0 && !tile_major) ? 1 : 0;
+            p.xcd_split = (p.splits % 8 == 0 ) ? 1 : 0;
             const int rc = b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 6, true>(p, st);
             if (rc != CHAM_OK) return rc;
             const size_t n4 = (size_t)p.M * p.N / 4;
@@ -376,16 +375,17 @@ static int b16_launch_cfg(B16Params& p, int act, int dact, int out_f32, hipStrea
         return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, true>(p, st);
     }
     if (p.splits > 1 || p.accumulate) return -CHAM_ERR_ARG;
+    // NT epilogues the bf16 configuration uses (bf16 out): plain, + bias -> leaky | tanh, x leaky'(dref); plain also with fp32 out.
+    // (tanh' dgrads and bias-only layers of the model run on fp32-resident operands: cham_gemm_bf16.)
     if (p.dref) {
-        if (p.bias || act != ACT_NONE || out_f32) return -CHAM_ERR_ARG;
-        if (dact == ACT_LEAKY) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 3, false>(p, st);
-        if (dact == ACT_TANH) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 4, false>(p, st);
-        return -CHAM_ERR_ARG;
+        if (p.bias || act != ACT_NONE || out_f32 || dact != ACT_LEAKY) return -CHAM_ERR_ARG;
+        return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 3, false>(p, st);
     }
     if (p.bias) {
-        if (act == ACT_LEAKY) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 1, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 1, false>(p, st);
-        if (act == ACT_TANH) return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 2, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 2, false>(p, st);
-        return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 5, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 5, false>(p, st);
+        if (out_f32) return -CHAM_ERR_ARG;
+        if (act == ACT_LEAKY) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 1, false>(p, st);
+        if (act == ACT_TANH) return b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 2, false>(p, st);
+        return -CHAM_ERR_ARG;
     }
     if (act != ACT_NONE) return -CHAM_ERR_ARG;
     return out_f32 ? b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, true>(p, st) : b16_launch_epi<BM, BN, WM, WN, BK, MINW, AK, BKC, 0, false>(p, st);
@@ -404,12 +404,6 @@ static int b16_by_shape(B16Params& p, int act, int dact, int out_f32, hipStream_
         ++g_b16_launches[v < 3 ? v : 2];
         if (v == 1) return b16_launch_cfg<256, 128, 4, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
         if (v == 2) return b16_launch_cfg<256, 128, 2, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
-#ifdef CHAM_B16_TUNING      // experimental instances (tests/bench_gemm_b16.py; build with -DCHAM_B16_TUNING)
-        if (v == 3) return b16_launch_cfg<256, 128, 2, 2, 32, 2, AK, BKC>(p, act, dact, out_f32, st);       // 128x64 per wave, <= 256 VGPRs
-        if (v == 4) return b16_launch_cfg<256, 128, 4, 2, 64, 1, AK, BKC>(p, act, dact, out_f32, st);       // BK = 64
-        if (v == 5) return b16_launch_cfg<256, 256, 4, 2, 32, 2, AK, BKC>(p, act, dact, out_f32, st);       // 256x256, 128x64 per wave
-        if (v == 6) return b16_launch_cfg<256, 256, 4, 2, 64, 1, AK, BKC>(p, act, dact, out_f32, st);       // 256x256, BK = 64
-#endif
         return b16_launch_cfg<128, 128, 2, 2, 32, 1, AK, BKC>(p, act, dact, out_f32, st);
     }
     if (p.N > 32) { ++g_b16_launches[3]; return b16_launch_cfg<256, 64, 4, 1, 32, 1, AK, BKC>(p, act, dact, out_f32, st); }

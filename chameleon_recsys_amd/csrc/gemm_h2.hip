@@ -154,77 +154,12 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
     }
 }
 
-// NT epilogue through LDS (the ring is free once the K loop is over): the 32x32 MFMA C/D map gives a lane ONE column of 16 rows - a
-// dword store instruction then covers two 128-byte row segments, 128 store (and, for the dgrad, 128 two-byte load) instructions per wave
-// and tile, and the eight waves of the one workgroup a CU holds run them in lock step with the matrix pipe idle (~35 k cycles per tile,
-// a fifth of the kernel: profiles/r04_notes.md).  Here a wave writes 32 rows x 64 columns of accumulators to its own 9 KB of LDS
-// (row pitch 72 floats: the two half-waves of a ds_write_b32 land on disjoint bank halves), reads them back as float4 - lane = (row
-// group of 4, 16-byte column group) - and finishes / stores 16 bytes per lane: 32 dwordx4 stores (+ 32 eight-byte loads of the saved
-// activation) per wave and tile, each covering four whole 256-byte row segments.
-#define H2_EPI_PITCH 72
-template <int EPI, int TM, int TNN>
-__device__ __forceinline__ void h2_epilogue_nt(const H2Params& p, floatx16 (&acc)[TM][TNN], int m0, int n0, int wm0, int wn0, int lane, int wave,
-                                               unsigned char* smem) {
-    static_assert(TNN == 2, "a wave's strip is 64 columns");
-    h2_barrier();                                      // every wave has finished its fragment reads: the ring may be overwritten
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int kl = lane_e >> 5, fl = lane_e & 31, r4 = lane_e >> 4, c16 = lane_e & 15;
-    float* S = reinterpret_cast<float*>(smem) + wave * (32 * H2_EPI_PITCH);
-    const float ia = p.sa[1], ib = p.sb[1];
-    const int limM = p.M - m0, limN = p.N - n0;
-    const int col = wn0 + 4 * c16;
-    const bool cok = col < limN;                       // (N % 4 == 0: a group of four columns is in or out as a whole)
-    const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
-    const __amdgpu_buffer_rsrc_t dw = make_window(EPI == 3 ? (const void*)(p.dref + (size_t)m0 * p.ldr + n0) : (const void*)p.C);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (EPI == 2 || EPI == 5) {
-        const __amdgpu_buffer_rsrc_t bw = make_window(p.bias + n0);
-        bv = as_f4(__builtin_amdgcn_raw_buffer_load_b128(bw, cok ? (unsigned)col * 4u : OOB_OFF, 0, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TNN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[((e & 3) + 8 * (e >> 2) + 4 * kl) * H2_EPI_PITCH + 32 * j + fl] = acc[i][j][e];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-        float4 v[8];
-        u32x2_t y[8];
-        unsigned offs[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int rl = 4 * q + r4, row = wm0 + 32 * i + rl;
-            const bool ok = cok && row < limM;
-            v[q] = *reinterpret_cast<const float4*>(S + rl * H2_EPI_PITCH + 4 * c16);
-            offs[q] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
-            if constexpr (EPI == 3) y[q] = __builtin_amdgcn_raw_buffer_load_b64(dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u : OOB_OFF, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 o = v[q];
-            o.x = (o.x * ia) * ib; o.y = (o.y * ia) * ib; o.z = (o.z * ia) * ib; o.w = (o.w * ia) * ib;      // back to true units (two exact factors)
-            if constexpr (EPI == 2 || EPI == 5) { o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
-            if constexpr (EPI == 2) { o.x = cham_tanhf(o.x); o.y = cham_tanhf(o.y); o.z = cham_tanhf(o.z); o.w = cham_tanhf(o.w); }
-            if constexpr (EPI == 3) {
-                // x leaky'(saved activation): positive and non-zero <=> the h plane's bit pattern > 0 as a signed 16-bit integer
-                o.x *= (short)(y[q].x & 0xFFFFu) > 0 ? 1.f : 0.2f; o.y *= (short)(y[q].x >> 16) > 0 ? 1.f : 0.2f;
-                o.z *= (short)(y[q].y & 0xFFFFu) > 0 ? 1.f : 0.2f; o.w *= (short)(y[q].y >> 16) > 0 ? 1.f : 0.2f;
-            }
-            u32x4 w;
-            w.x = __float_as_uint(o.x); w.y = __float_as_uint(o.y); w.z = __float_as_uint(o.z); w.w = __float_as_uint(o.w);
-            __builtin_amdgcn_raw_buffer_store_b128(w, cw, offs[q], 0, 0);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads above precede the next row block's writes
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
+// (Round 4 also tried the NT epilogue THROUGH LDS - accumulators transposed in the free ring, float4 per lane, 32 dwordx4 stores and 32
+// eight-byte activation loads per wave and tile instead of 128 + 128: bit-identical, 7 % SLOWER stand-alone (1.78 vs 1.65 ms) and neutral
+// in the step.  The dword form already writes whole 128-byte lines; what an NT tile pays beside its K loop - ~16 us of 103 us - is the
+// epilogue's VALU work (tanh: ~2 400 instructions per lane) and the pipeline prologue, not store issue.  profiles/r04_notes.md.)
 // EPI: 0 plain (/ accumulate), 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias, 6 split-K partial
-template <bool TN, int EPI, bool LDSEPI>
+template <bool TN, int EPI>
 __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
     constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TNN = 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char h2_smem[];
@@ -370,8 +305,7 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
     }
 
-    if constexpr (!TN && EPI != 6 && LDSEPI) h2_epilogue_nt<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, lane, wave, h2_smem);
-    else h2_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, split, lane);
+    h2_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, split, lane);
 }
 
 // ================================================================================================================================
@@ -538,15 +472,11 @@ extern "C" void cham_gemm_h2_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_h2_launches[i]; if (reset) g_h2_launches[i] = 0; }
 }
 
-static int g_h2_variant = 0;      // 0 = NT epilogue through LDS (16-byte stores), 1 = the direct dword epilogue (A/B arm)
-extern "C" void cham_gemm_h2_set_variant(int v) { g_h2_variant = v; }
-
-template <bool TN, int EPI, bool LDSEPI>
-static int h2_launch_v(H2Params& p, hipStream_t st) {
+template <bool TN, int EPI>
+static int h2_launch(H2Params& p, hipStream_t st) {
     g_h2_launches[6] = EPI; g_h2_launches[7] = p.splits;
     constexpr int smem = H2_RING * H2_STAGE;
-    static_assert(8 * 32 * H2_EPI_PITCH * 4 <= smem, "the epilogue's transpose buffers live in the ring");
-    auto k = gemm_h2_kernel<TN, EPI, LDSEPI>;
+    auto k = gemm_h2_kernel<TN, EPI>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -557,16 +487,6 @@ static int h2_launch_v(H2Params& p, hipStream_t st) {
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
-template <bool TN, int EPI>
-static int h2_launch(H2Params& p, hipStream_t st) {
-    if constexpr (!TN && EPI != 6) {
-        if (g_h2_variant == 1) return h2_launch_v<TN, EPI, false>(p, st);
-        return h2_launch_v<TN, EPI, true>(p, st);
-    } else {
-        return h2_launch_v<TN, EPI, false>(p, st);
-    }
-}
-
 // C[M,N] = epi((sum of the three plane products) / (s_a s_b)) - see the header.  A, B: plane 0 (fp16 h plane), the l plane
 // `*_plane_stride` elements further; a_scale / b_scale: the operands' H2Scale records (device memory, written by the kernels above).
 //   tn = 0 (NT): A [M, lda], B [N, ldb], k contiguous; K % 16 == 0.  bias (+ act = CHAM_ACT_TANH), or dref_h + dact = CHAM_ACT_LEAKY:
@@ -580,8 +500,7 @@ extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, co
                             void* stream) {
     if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0) return -CHAM_ERR_ARG;
     if ((lda & 7) || (ldb & 7) || (a_plane_stride & 7) || (b_plane_stride & 7) || (N & 3) || (ldc & 3)) return -CHAM_ERR_ARG;
-    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) return -CHAM_ERR_ARG;
-    if (dref_h && ((ldr & 3) || ((uintptr_t)dref_h & 7))) return -CHAM_ERR_ARG;          // (the epilogue reads four saved activations per lane)
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return -CHAM_ERR_ARG;
     if ((size_t)ldc * 4 * 256 >= WINDOW_BYTES || (size_t)ldr * 2 * 256 >= WINDOW_BYTES) return -CHAM_ERR_ARG;
     H2Params p;
     p.A = reinterpret_cast<const _Float16*>(A); p.B = reinterpret_cast<const _Float16*>(B); p.a_ps = a_plane_stride; p.b_ps = b_plane_stride;

@@ -82,37 +82,6 @@ __device__ __forceinline__ void p3_dma_stage(unsigned lds0, unsigned va, unsigne
         : "memory");
 }
 
-// one request (the staggered pipeline issues one per MFMA pass)
-__device__ __forceinline__ void p3_dma_one(unsigned lds, unsigned voff, const u32x4& r) {
-    unsigned keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r) : "memory");
-}
-
-// one MFMA pass: acc[i][j] += X[i] * Y[j] over the wave's 4 x 2 tiles, with `aux` (this pass's DMA request and fragment reads) placed
-// after the first MFMA for wave group 0 and after the fifth for group 1: the two waves of a SIMD are released by the same barrier and
-// would otherwise stop issuing MFMAs for their memory instructions at the same moment, leaving the matrix pipe idle.
-template <int G, typename AuxF>
-__device__ __forceinline__ void p3_pass(floatx16 (&acc)[4][2], const bf16x8 (&X)[4], const bf16x8 (&Y)[2], AuxF&& aux) {
-    constexpr int SPLIT = G == 0 ? 1 : 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (i * 2 + j == SPLIT) {
-                __builtin_amdgcn_sched_barrier(0);
-                aux();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 template <bool TN>
 __device__ __forceinline__ bf16x8 p3_frag(const unsigned char* __restrict__ s) {
     if constexpr (!TN) {
@@ -181,7 +150,10 @@ __device__ __forceinline__ void p3_epilogue(const P3Params& p, floatx16 (&acc)[T
 }
 
 // EPI: 0 plain, 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias, 6 split-K partial
-template <bool TN, int EPI, int VAR>
+// (Round 3's A/B arms of this kernel - a staggered pipeline with one DMA request per MFMA pass, 2-5 % slower; the NT form on 256x128
+// tiles with two workgroups per CU, 15 % slower; the last round of tiles as its own split-K launch, neutral - were measured and removed:
+// profiles/r03_notes.md sections 1 and 5.)
+template <bool TN, int EPI>
 __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TNN = 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
@@ -270,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
     const unsigned wave_off = (unsigned)wave * 1024u;
     bf16x8 AH[TM], AM[TM], AL[TM], BH[TNN], BMf[TNN], BL[TNN];
 
-    if (VAR == 0 && nk > 0) {          // first version: all six requests at the top of a step, both wave groups in lockstep
+    if (nk > 0) {          // all six requests at the top of a step, both wave groups in lockstep
         p3_dma_stage(lds_base + wave_off, va, vb, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
         va += stepa; vb += stepb;
         p3_dma_stage(lds_base + P3_STAGE + wave_off, va, vb, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
@@ -356,210 +328,7 @@ __global__ __launch_bounds__(512) void gemm_p3_kernel(P3Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
     }
 
-    if (VAR == 1 && nk > 0) {
-        // Staggered pipeline.  Stage s: its A slabs are requested in P3..P5 of step s - 3 (into the slot of stage s - 3, whose last
-        // fragment reads precede that step's barrier), its B slabs in P0..P2 of step s - 2; its early fragments are read after the
-        // barrier of step s - 1, before which every wave has waited for them: s_waitcnt vmcnt(6) - the six younger requests (A of
-        // stage s + 1, B of stage s + 1) stay in flight.  One request and a few fragment reads per pass, at different points of the
-        // pass for the two waves of a SIMD (p3_pass).
-        unsigned vaN = va, vbN = vb;
-        p3_dma_stage(lds_base + wave_off, vaN, vbN, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
-        vaN += stepa; vbN += stepb;
-        p3_dma_stage(lds_base + P3_STAGE + wave_off, vaN, vbN, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2]);
-        vaN += stepa; vbN += stepb;
-        p3_dma_one(lds_base + 2 * P3_STAGE + 0 * P3_SLAB + wave_off, vaN, ra[0]);
-        p3_dma_one(lds_base + 2 * P3_STAGE + 1 * P3_SLAB + wave_off, vaN, ra[1]);
-        p3_dma_one(lds_base + 2 * P3_STAGE + 2 * P3_SLAB + wave_off, vaN, ra[2]);
-        vaN += stepa;
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        p3_barrier();
-        {   // early fragments of stage 0
-            const unsigned char* S = p3_smem;
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<TN>(S + 3 * P3_SLAB + fb[j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) AL[i] = p3_frag<TN>(S + 2 * P3_SLAB + fa[i]);
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<TN>(S + 5 * P3_SLAB + fb[j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) AM[i] = p3_frag<TN>(S + 1 * P3_SLAB + fa[i]);
-        }
-        auto run = [&](auto GG) {
-            constexpr int G = decltype(GG)::value;
-            int cur = 0;
-            for (int i = 0; i < nk; ++i) {
-                const int nxt = cur == P3_RING - 1 ? 0 : cur + 1, nx2 = nxt == P3_RING - 1 ? 0 : nxt + 1;
-                const unsigned char* Sc = p3_smem + cur * P3_STAGE;
-                const unsigned char* Sn = p3_smem + nxt * P3_STAGE;
-                const unsigned lb = lds_base + (unsigned)nx2 * P3_STAGE + wave_off;      // B slabs of stage i + 2
-                const unsigned la = lds_base + (unsigned)cur * P3_STAGE + wave_off;      // A slabs of stage i + 3
-                __builtin_amdgcn_sched_barrier(0);
-                p3_pass<G>(acc, AL, BH, [&] {
-                    p3_dma_one(lb + 3 * P3_SLAB, vbN, rb[0]);
-#pragma unroll
-                    for (int ii = 0; ii < TM; ++ii) AH[ii] = p3_frag<TN>(Sc + 0 * P3_SLAB + fa[ii]);
-                });
-                p3_pass<G>(acc, AM, BH, [&] {
-                    p3_dma_one(lb + 4 * P3_SLAB, vbN, rb[1]);
-#pragma unroll
-                    for (int j = 0; j < TNN; ++j) BMf[j] = p3_frag<TN>(Sc + 4 * P3_SLAB + fb[j]);
-                });
-                p3_pass<G>(acc, AH, BH, [&] {
-                    p3_dma_one(lb + 5 * P3_SLAB, vbN, rb[2]);
-                });
-                vbN += stepb;
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                p3_barrier();
-                p3_pass<G>(acc, AH, BL, [&] {
-                    p3_dma_one(la + 0 * P3_SLAB, vaN, ra[0]);
-#pragma unroll
-                    for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<TN>(Sn + 3 * P3_SLAB + fb[j]);
-#pragma unroll
-                    for (int ii = 0; ii < TM; ++ii) AL[ii] = p3_frag<TN>(Sn + 2 * P3_SLAB + fa[ii]);
-                });
-                p3_pass<G>(acc, AM, BMf, [&] {
-                    p3_dma_one(la + 1 * P3_SLAB, vaN, ra[1]);
-#pragma unroll
-                    for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<TN>(Sn + 5 * P3_SLAB + fb[j]);
-                });
-                p3_pass<G>(acc, AH, BMf, [&] {
-                    p3_dma_one(la + 2 * P3_SLAB, vaN, ra[2]);
-#pragma unroll
-                    for (int ii = 0; ii < TM; ++ii) AM[ii] = p3_frag<TN>(Sn + 1 * P3_SLAB + fa[ii]);
-                });
-                vaN += stepa;
-                cur = nxt;
-            }
-        };
-        if (wave < 4) run(std::integral_constant<int, 0>{});
-        else run(std::integral_constant<int, 1>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
-    }
-
     p3_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, split, lane);
-}
-
-// ================================================================================================================================
-// NT with TWO workgroups per CU (variant 2): 256 x 128 tile, 4 waves as 2 x 2 (128 x 64 per wave: the same 4 x 2 MFMA tiles), a stage =
-// three A slabs of 8 KB + three B slabs of 4 KB = 36 KB, ring of TWO stages = 72 KB per workgroup.  The one-workgroup-per-CU kernel
-// above leaves the matrix pipe idle while its eight waves run the epilogue (and the prologue of the next tile) in lock step - the TN
-// form, which has no epilogue, is 11 % busier in cycles; here the second workgroup of a CU is somewhere else in its tile.  Price: the
-// B operand is staged once per 128 instead of 256 output columns (1.5x the L2 -> LDS bytes per flop) and a request has one step, not
-// 1.5, to land:
-//   step i (slot i & 1):  P0 A_l x B_h (+ late fragments A_h, B_m) | P1 A_m x B_h | P2 A_h x B_h | s_waitcnt vmcnt(0): stage i + 1 landed,
-//   s_barrier: everyone has read slot i & 1 | DMA of stage i + 2 into slot i & 1 | P3 A_h x B_l (+ early fragments of stage i + 1) | P4 | P5
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_p3h_kernel(P3Params p) {
-    constexpr int BM = 256, BN = 128, BK = 16, TM = 4, TNN = 2;
-    constexpr unsigned SA = 8192, SB = 4096, STAGE = 3 * SA + 3 * SB;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
-    const int nwg = p.nbm * p.nbn;
-    const int id = blockIdx.x;
-    const int q8 = nwg / 8, rr = nwg % 8, xcd = id % 8;
-    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + id / 8;
-    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = (p.K + BK - 1) / BK;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
-
-    u32x4 ra[3], rb[3];
-    const size_t abytes = (size_t)max(p.M - m0, 0) * p.lda * 2, bbytes = (size_t)max(p.N - n0, 0) * p.ldb * 2;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        ra[q] = p3_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda, (unsigned)min(abytes, (size_t)0xFFFFFFF0u));
-        rb[q] = p3_rsrc(p.B + q * p.b_ps + (size_t)n0 * p.ldb, (unsigned)min(bbytes, (size_t)0xFFFFFFF0u));
-    }
-    // lane l of wave w fills A pieces (row 64 w + l / 2) and (row 64 w + 32 + l / 2), B piece (row 32 w + l / 2); half l & 1 of the LDS row
-    // holds source half (l & 1) ^ bit 3 of the row (the same for a row and the row 32 below it)
-    const unsigned half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1));
-    unsigned va = ((unsigned)(64 * wave + (lane >> 1)) * (unsigned)p.lda + 8u * half) * 2u;
-    unsigned va2 = va + 32u * (unsigned)p.lda * 2u;
-    unsigned vb = ((unsigned)(32 * wave + (lane >> 1)) * (unsigned)p.ldb + 8u * half) * 2u;
-
-    unsigned fa[TM], fb[TNN];
-    {
-        const int l31 = lane & 31;
-        const unsigned fo = (unsigned)l31 * 32u + (unsigned)((lane >> 5) ^ ((l31 >> 3) & 1)) * 16u;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)(wm0 + 32 * i) * 32u + fo;
-#pragma unroll
-        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)(wn0 + 32 * j) * 32u + fo;
-    }
-    floatx16 acc[TM][TNN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TNN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)p3_smem;
-    const unsigned la = (unsigned)wave * 2048u, lb = 3 * SA + (unsigned)wave * 1024u;
-    auto dma = [&](unsigned slot) {
-        const unsigned b = lds_base + slot * STAGE;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            p3_dma_one(b + q * SA + la, va, ra[q]);
-            p3_dma_one(b + q * SA + la + 1024u, va2, ra[q]);
-            p3_dma_one(b + q * SB + lb, vb, rb[q]);
-        }
-        va += BK * 2; va2 += BK * 2; vb += BK * 2;
-    };
-    bf16x8 AH[TM], AM[TM], AL[TM], BH[TNN], BMf[TNN], BL[TNN];
-    constexpr unsigned OAH = 0, OAM = SA, OAL = 2 * SA, OBH = 3 * SA, OBM = 3 * SA + SB, OBL = 3 * SA + 2 * SB;
-    auto mma = [&](const bf16x8 (&X)[TM], const bf16x8 (&Y)[TNN]) {
-#pragma unroll
-        for (int ii = 0; ii < TM; ++ii)
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ii], Y[j], acc[ii][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if (nk > 0) {
-        dma(0u);
-        dma(1u);
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        p3_barrier();
-#pragma unroll
-        for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<false>(p3_smem + OBH + fb[j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) AL[i] = p3_frag<false>(p3_smem + OAL + fa[i]);
-#pragma unroll
-        for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<false>(p3_smem + OBL + fb[j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) AM[i] = p3_frag<false>(p3_smem + OAM + fa[i]);
-        for (int i = 0; i < nk; ++i) {
-            const unsigned cur = (unsigned)(i & 1);
-            const unsigned char* Sc = p3_smem + cur * STAGE;
-            const unsigned char* Sn = p3_smem + (cur ^ 1u) * STAGE;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) AH[ii] = p3_frag<false>(Sc + OAH + fa[ii]);
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) BMf[j] = p3_frag<false>(Sc + OBM + fb[j]);
-            mma(AL, BH);
-            mma(AM, BH);
-            mma(AH, BH);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            p3_barrier();
-            dma(cur);           // stage i + 2 (past the reduction range: requested all the same, never consumed)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) BH[j] = p3_frag<false>(Sn + OBH + fb[j]);
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) AL[ii] = p3_frag<false>(Sn + OAL + fa[ii]);
-            mma(AH, BL);
-#pragma unroll
-            for (int j = 0; j < TNN; ++j) BL[j] = p3_frag<false>(Sn + OBL + fb[j]);
-            mma(AM, BMf);
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) AM[ii] = p3_frag<false>(Sn + OAM + fa[ii]);
-            mma(AH, BMf);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
-    }
-    p3_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, 0, lane);
 }
 
 // ================================================================================================================================
@@ -809,42 +578,17 @@ extern "C" int cham_split3(const float* X, int R, int Cc, int ld, void* dst, lon
     return CHAM_OK;
 }
 
-// ---- NT with split-K: the LAST, partly filled round of 256 x 256 tiles of a tall NT GEMM (3 876 tiles on 256 CUs = 15 rounds + 36
-// tiles: a sixteenth of the kernel's time for 14 % of a round) is issued as its own launch with the reduction range cut into
-// 256 / tiles pieces, so that every CU gets a piece; this kernel adds the pieces in split order and applies the epilogue.
-__global__ __launch_bounds__(256) void k_p3_nt_finish(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
-                                                      const float* __restrict__ bias, int act, const __bf16* __restrict__ dref, int ldr) {
-    const size_t n4 = (size_t)M * N / 4;
-    const unsigned N4 = (unsigned)N / 4u;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4* src = reinterpret_cast<const float4*>(partial) + i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 0; q < splits; ++q) { const float4 x = src[(size_t)q * n4]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
-        const int row = (int)(i / N4), col = (int)(i % N4) * 4;
-        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (act == ACT_TANH) { v.x = cham_tanhf(v.x); v.y = cham_tanhf(v.y); v.z = cham_tanhf(v.z); v.w = cham_tanhf(v.w); }
-        if (dref) {
-            const float4 y = ld4(dref + (size_t)row * ldr + col);
-            v.x *= y.x > 0.f ? 1.f : 0.2f; v.y *= y.y > 0.f ? 1.f : 0.2f; v.z *= y.z > 0.f ? 1.f : 0.2f; v.w *= y.w > 0.f ? 1.f : 0.2f;
-        }
-        *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
-    }
-}
-
-// launch counters: [0] NT launches ([4]: of those, with split-K), [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [5] NT launches on the half-tile kernel, [6] epilogue and [7] K-splits of the last launch
+// launch counters: [0] NT launches, [1] TN launches, [2] / [3] NT / TN launches of the one-plane bf16 form, [6] epilogue and [7] K-splits of the last launch
 static long long g_p3_launches[8];
 extern "C" void cham_gemm_p3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_p3_launches[i]; if (reset) g_p3_launches[i] = 0; }
 }
 
-static int g_p3_variant = 0;      // 0 = all requests of a stage at the top of a step, 1 = staggered (A/B arm: 2-5 % slower), 2 = NT on the half-tile kernel (two workgroups per CU)
-extern "C" void cham_gemm_p3_set_variant(int v) { g_p3_variant = v; }
-
-template <bool TN, int EPI, int VAR>
-static int p3_launch_var(P3Params& p, hipStream_t st) {
+template <bool TN, int EPI>
+static int p3_launch(P3Params& p, hipStream_t st) {
     g_p3_launches[6] = EPI; g_p3_launches[7] = p.splits;
     constexpr int smem = P3_RING * P3_STAGE;
-    auto k = gemm_p3_kernel<TN, EPI, VAR>;
+    auto k = gemm_p3_kernel<TN, EPI>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -855,34 +599,10 @@ static int p3_launch_var(P3Params& p, hipStream_t st) {
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
-template <int EPI>
-static int p3h_launch(P3Params p, hipStream_t st) {       // (by value: the column-tile count is this variant's own)
-    g_p3_launches[6] = EPI; g_p3_launches[7] = 1; ++g_p3_launches[5];
-    constexpr int smem = 2 * (3 * 8192 + 3 * 4096);
-    p.nbn = (p.N + 127) / 128;
-    auto k = gemm_p3h_kernel<EPI>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(256), smem, st, p);
-    CHAM_CHECK_LAUNCH();
-    return CHAM_OK;
-}
-template <bool TN, int EPI>
-static int p3_launch(P3Params& p, hipStream_t st) {
-    if constexpr (!TN && EPI != 6) {
-        if (g_p3_variant == 2) return p3h_launch<EPI>(p, st);
-    }
-    return g_p3_variant == 1 ? p3_launch_var<TN, EPI, 1>(p, st) : p3_launch_var<TN, EPI, 0>(p, st);
-}
 
 // C[M,N] = epi(sum of six plane products) - see the header.  A, B: plane 0 (bf16), planes `*_plane_stride` elements apart.
 //   tn = 0 (NT): A [M, lda], B [N, ldb], k contiguous; K % 16 == 0.  bias + act (CHAM_ACT_NONE / CHAM_ACT_TANH), or dref_h + dact =
-//     CHAM_ACT_LEAKY: x leaky'(saved activation) with dref_h the h plane [M, ldr] of that activation.  splits_hint > 1 + workspace:
-//     the reduction range in that many pieces (partials + k_p3_nt_finish; for a launch that would not fill the CUs otherwise).
+//     CHAM_ACT_LEAKY: x leaky'(saved activation) with dref_h the h plane [M, ldr] of that activation.
 //   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N]; M % 256 == 0, N % 256 == 0, any K; split-K through `workspace`
 //     (splits_hint: 1 none, 0 automatic, n at most n; fixed-order reduction), accumulate adds to C.
 // Returns -CHAM_ERR_ARG for shapes it does not take (the caller keeps cham_gemm_f32x3 for those).
@@ -906,28 +626,6 @@ extern "C" int cham_gemm_p3(const void* A, long long a_plane_stride, int lda, co
         ++g_p3_launches[0];
         if (dref_h && (bias || act != ACT_NONE || dact != ACT_LEAKY)) return -CHAM_ERR_ARG;
         if (act != ACT_NONE && !(bias && act == ACT_TANH)) return -CHAM_ERR_ARG;
-        if (splits_hint > 1 && workspace && K >= 32) {       // explicit split-K (the partly filled last round of a tall GEMM: see k_p3_nt_finish)
-            long want = splits_hint;
-            if (want > K / 16) want = K / 16;
-            const long maxw = (long)(workspace_bytes / ((size_t)M * N * sizeof(float)));
-            if (want > maxw) want = maxw;
-            if (want > 1) {
-                const int ksteps = (int)((K / 16 + want - 1) / want);
-                p.kchunk = ksteps * 16;
-                p.splits = (K + p.kchunk - 1) / p.kchunk;
-            }
-        }
-        if (p.splits > 1) {
-            ++g_p3_launches[4];
-            const int rc = p3_launch<false, 6>(p, st);
-            if (rc != CHAM_OK) return rc;
-            const size_t n4 = (size_t)M * N / 4;
-            int blocks = (int)((n4 + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(k_p3_nt_finish, dim3(blocks), dim3(256), 0, st, workspace, p.splits, M, N, C, ldc, bias, act, p.dref, ldr);
-            CHAM_CHECK_LAUNCH();
-            return CHAM_OK;
-        }
         if (dref_h) return p3_launch<false, 3>(p, st);
         if (bias) {
             if (act == ACT_TANH) return p3_launch<false, 2>(p, st);

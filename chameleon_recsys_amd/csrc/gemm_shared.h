@@ -364,7 +364,8 @@ static inline int gemm_plan(GemmParams& p, const float* A, int lda, int transA, 
     // the split-K reductions (gemm_splitk_reduce / _wide) walk the output in float4 groups of one row and read the bias 16 bytes at a
     // time: an output width that is not a multiple of four (only possible with transB) or a misaligned bias takes the unsplit kernel
     const bool reduce_ok = (N & 3) == 0 && (!bias || (reinterpret_cast<size_t>(bias) & 15) == 0);
-    if (splits_hint != 1 && workspace && reduce_ok) {
+    // K-splits are a weight-gradient device (TN: long reduction, small output); the NN / NT kernels have no split-K instances
+    if (splits_hint != 1 && workspace && reduce_ok && transA && !transB) {
         // long-reduction / small-output shapes (wgrad): fill >= ~1024 workgroups
         const int bm = (N > 64) ? (((long)M * N >= (1L << 20)) ? 256 : 128) : 256, bn = (N > 64) ? 128 : (N > 32 ? 64 : 32);
         const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);

@@ -427,25 +427,36 @@ template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
 static int x3_launch_cfg(GemmParams& p, hipStream_t st) {
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
+    // epilogues per layout as in gemm.hip's launch_cfg: NN plain | bias (+ leaky | tanh); NT plain | x act'(dref); TN plain | split-K partial
+    constexpr bool NN = AK && !BKC, NT = AK && BKC, TN = !AK && !BKC;
     if (p.splits > 1) {
-        p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
-        const int rc = x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
-        if (rc != CHAM_OK) return rc;
-        launch_splitk_reduce(p, st);
-        CHAM_CHECK_LAUNCH();
-        return CHAM_OK;
+        if constexpr (TN) {
+            p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
+            const int rc = x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
+            if (rc != CHAM_OK) return rc;
+            launch_splitk_reduce(p, st);
+            CHAM_CHECK_LAUNCH();
+            return CHAM_OK;
+        } else {
+            return -CHAM_ERR_ARG;
+        }
     }
     if (p.dref) {
         if (p.bias || p.act != ACT_NONE) return -CHAM_ERR_ARG;
-        if (p.dact == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3>(p, st);
-        if (p.dact == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4>(p, st);
+        if constexpr (NT) {
+            if (p.dact == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3>(p, st);
+            if (p.dact == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4>(p, st);
+        }
         return -CHAM_ERR_ARG;
     }
     if (p.bias || p.act != ACT_NONE) {
         if (!p.bias || p.accumulate) return -CHAM_ERR_ARG;
-        if (p.act == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1>(p, st);
-        if (p.act == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2>(p, st);
-        return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5>(p, st);
+        if constexpr (NN) {
+            if (p.act == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1>(p, st);
+            if (p.act == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2>(p, st);
+            return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5>(p, st);
+        }
+        return -CHAM_ERR_ARG;
     }
     return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0>(p, st);
 }

@@ -485,14 +485,11 @@ extern "C" int cham_rows_scatter(const void* src, const int32_t* pos, long n_row
 // When the recurrent kernels run on a side stream next to the big CAR GEMM they must not share a CU with GEMM
 // workgroups (the MFMA pipes would be time-sliced and the latency-bound recurrence would stretch 5x): requesting
 // most of the 160 KB LDS makes every CU that hosts a recurrent workgroup exclusive to it.
-static size_t g_rnn_lds_hog = 0;
-extern "C" void cham_rnn_set_exclusive_lds(size_t bytes) { g_rnn_lds_hog = bytes > 160 * 1024 ? 160 * 1024 : bytes; }
 
 template <int NT>
 static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_len, int B, int T, float* out, float* hprev,
                             float* G, float* Cc, hipStream_t st) {
     size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
-    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_ugrnn_fwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
@@ -504,7 +501,6 @@ template <int NT>
 static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_len, int B, int T, const float* hprev,
                             const float* G, const float* Cc, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
-    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_ugrnn_bwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
@@ -517,7 +513,6 @@ template <int NT>
 static int launch_gru_fwd(const float* xproj, const float* Wh, const int* seq_len, int B, int T, float* out, float* hprev,
                           float* U, float* Cc, float* R, float* RH, hipStream_t st) {
     size_t smem = (size_t)64 * (128 * NT + 1) * sizeof(float);
-    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_gru_fwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
@@ -529,7 +524,6 @@ template <int NT>
 static int launch_gru_bwd(const float* dout, const float* WhT, const int* seq_len, int B, int T, const float* hprev,
                           const float* U, const float* Cc, const float* R, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (384 * NT + 2) * sizeof(float);
-    if (smem < g_rnn_lds_hog) smem = g_rnn_lds_hog;
     auto kern = k_gru_bwd<NT, 1>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }

@@ -221,67 +221,33 @@ class NARRuntime:
         segs, singles = L.item_segments()
         self.item_segs, self.n_item_segs = torch.from_numpy(np.ascontiguousarray(segs)).to(dev), int(segs.shape[0])
         self.item_singles, self.n_item_singles = torch.from_numpy(np.ascontiguousarray(singles)).to(dev), int(singles.shape[0])
-        # item rows through LDS tiles (csrc/features.hip k_item_assemble_lds); CHAM_ITEM_ASSEMBLE_LDS=0: one thread per element
-        self.item_lds = os.environ.get("CHAM_ITEM_ASSEMBLE_LDS", "1") == "1" and L.Fi * 4 * 8 <= 64 * 1024
+        # item rows through LDS tiles (csrc/features.hip k_item_assemble_lds); rows too wide for the tile: one thread per element
+        self.item_lds = L.Fi * 4 * 8 <= 64 * 1024
         self.item_desc = torch.from_numpy(L.item_descriptors()).to(dev)
         self.gemm_ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)        # 256 MB split-K partials (main stream)
         self.colsum_ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
-        # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs
-        self.side_stream = lane_stream(dev, "side", int(os.environ.get("CHAM_SIDE_PRIORITY", "0")))
+        # the recurrent branch (8 CUs busy) runs on a side stream, overlapped with the candidate-row CAR GEMMs (normal priority: a
+        # high-priority side lane was needed by the early builds only, profiles/r01_notes.md items 2 and 25)
+        self.side_stream = lane_stream(dev, "side", 0)
         self._side_raw = self.side_stream.cuda_stream
-        self.aux_stream = lane_stream(dev, "aux", -1)      # second half of k_mulpred_bwd beside the CAR dgrad
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
-        # Side-lane priority, measured on MI355X (profiles/r01_notes.md items 2 and 25): the early builds needed a HIGH-priority
-        # side stream (their 4-wave recurrent workgroups starved behind the 7.7k-workgroup GEMM grid: 22.2 -> 20.7 ms); with the
-        # final schedule (8-wave pipelined recurrent kernels, presampled negatives, PreCAR backward beside the W2 wgrad) normal
-        # priority is 0.2-0.3 ms faster (16.74-16.94 vs 17.06-17.11 ms).  CHAM_OVERLAP=0 turns the lanes off.
-        self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"
-        self.dgrad_nn = os.environ.get("CHAM_DGRAD_NN", "0") == "1"      # experiment switch (profiles/r01_notes.md item 9)
+        self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"           # CHAM_OVERLAP=0: the same program order on one stream
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
         self.compact = os.environ.get("CHAM_COMPACT", "1") == "1"
-        # backward tail schedule (profiles/r01_notes.md item 18): the PreCAR backward on the (high-priority) side lane beside the W2
-        # wgrad on the main lane, the wgrad split finer than the chip needs so that its workgroups retire in rounds
-        # - measured neutral (16.95-17.13 ms both ways; 64 splits 17.6 ms): experiment switch, default off
-        self.tail_on_side = os.environ.get("CHAM_TAIL_ON_SIDE", "0") == "1"
-        self.w2_splits = int(os.environ.get("CHAM_W2_SPLITS", "32"))
-        # K-splits of the plane-resident W2 weight gradient: 0 = automatic (16: one workgroup per CU for the whole 2 ms, nothing else
-        # gets a CU meanwhile); 32 (default): two rounds of shorter workgroups, the main lane's PreCAR backward slips in between
-        # (11.73-11.75 vs 11.80-11.84 ms/step, two alternating runs each in one gpurun call)
-        self.p3_w2_splits = int(os.environ.get("CHAM_P3_W2_SPLITS", "32"))
-        # Short (ragged) batches: the CAR GEMMs shrink with the number of valid positions, the recurrent chain of the side lane does not - the
-        # main lane then waits for the clicked-row gradient behind its CAR dgrad.  With at most this many candidate rows the plane-resident W2
-        # weight gradient runs on the MAIN lane in that wait instead of on the side lane behind the chain (0 = never)
-        self.w2_main_rows = int(os.environ.get("CHAM_W2_MAIN_ROWS", "131072"))     # G1-like lengths: 88.1-88.4 k -> 90.5-90.6 k sessions/s
-        # pipeline variant of the plane-resident GEMMs (csrc/gemm_p3.hip): 0 = all DMA requests of a stage at the top of a step (default),
-        # 1 = staggered per MFMA pass, 2 = NT on 256x128 tiles with two workgroups per CU (A/B arms)
-        if self.p3:
-            self.lib.cham_gemm_p3_set_variant(int(os.environ.get("CHAM_P3_VARIANT", "0")))
-        # the partly filled last round of a tall NT plane GEMM as its own split-K launch (see gemm_p3): shortens the kernel by ~2 % stand-alone,
-        # neutral in the step (11.85 / 11.82 vs 11.83 / 11.75 ms, alternating runs: other lanes' kernels already use those CUs) - off
-        self.p3_tail_split = os.environ.get("CHAM_P3_TAIL_SPLIT", "0") == "1"
-        # the W2 weight gradient (side lane) starts when the candidate-row CAR dgrad (main lane) has finished: both are one-workgroup-
-        # per-CU matrix kernels that only time-slice the chip when they overlap
-        self.w2_after_dgrad = os.environ.get("CHAM_W2_AFTER_DGRAD", "1") == "1"
-        # ... and is the side lane's LAST work: the small weight / bias gradients queued behind it used to wait for the dgrad too
-        self.w2_last = os.environ.get("CHAM_W2_LAST", "1") == "1"
-        if self.h2:
-            self.lib.cham_gemm_h2_set_variant(int(os.environ.get("CHAM_H2_VARIANT", "0")))      # 1 = direct dword NT epilogue (A/B arm)
-        self.side_critical_first = os.environ.get("CHAM_SIDE_CRITICAL_FIRST", "1") == "1"
-        # three more schedule arms suggested by the kernel trace of the plane-product build, each measured neutral or slower (A/B in one
-        # gpurun call, ms/step: all off 12.95 | scorer layer-1 wgrad only after its dgrad dM 13.16 -> +0.06 | the small PreCAR-backward
-        # GEMMs on the native fp32 kernels so that they co-reside with the W2 wgrad: +0.22 | b2 column sum before the W2 wgrad: -0.03):
-        # default off
-        self.ws1_after_dm = os.environ.get("CHAM_WS1_AFTER_DM", "0") == "1"
-        self.precar_bwd_native = os.environ.get("CHAM_PRECAR_BWD_NATIVE", "0") == "1"
-        self.b2_early = os.environ.get("CHAM_B2_EARLY", "0") == "1"
+        # Measured schedule constants (the A/B arms they won against are in profiles/r01-r04_notes.md, not in the code):
+        #   * K-splits of the plane-resident W2 weight gradient: 32 = two rounds of shorter workgroups, the main lane's PreCAR backward
+        #     slips in between (16 = one workgroup per CU for the whole kernel, nothing else gets a CU meanwhile);
+        #   * short (ragged) batches, at most this many candidate rows: the W2 weight gradient runs on the MAIN lane while that lane waits
+        #     for the clicked-row gradient out of the side lane's recurrent chain (the chain does not shrink with the valid positions);
+        #   * otherwise it waits for the main lane's CAR dgrad (two one-workgroup-per-CU matrix kernels only time-slice the chip) and is
+        #     the side lane's LAST work: the small weight / bias gradients go first and run under that dgrad.
+        self.p3_w2_splits = 32
+        self.w2_main_rows = 131072
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
-        self.upload_stream = lane_stream(dev, "upload") if os.environ.get("CHAM_ASYNC_UPLOAD", "1") == "1" else None
-        self.pinned = _PinnedRing() if os.environ.get("CHAM_PINNED_UPLOAD", "1") == "1" else None
-        self.split_mulpred = os.environ.get("CHAM_SPLIT_MULPRED", "0") == "1"      # experiment switch, no gain (profiles/r01_notes.md item 17)
-        if os.environ.get("CHAM_RNN_LDS_HOG"):
-            self.lib.cham_rnn_set_exclusive_lds(int(os.environ["CHAM_RNN_LDS_HOG"]))
+        self.upload_stream = lane_stream(dev, "upload")       # H2D copies of a batch on their own stream, from a page-locked staging ring
+        self.pinned = _PinnedRing()
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)
         # bf16 configuration: bf16 shadows (plain + transposed) of the weights whose GEMMs run over the candidate rows, refreshed
         # whenever the fp32 master copy changed (csrc/gemm_b16.hip wants both operands k-contiguous: W^T forward, W dgrad)
@@ -294,9 +260,9 @@ class NARRuntime:
                 r, c = L.entries[name].shape
                 self.shadow[name] = torch.zeros(r, c, dtype=torch.bfloat16, device=dev)
                 self.shadow[name + 'T'] = torch.zeros(c, r, dtype=torch.bfloat16, device=dev)
-        # bf16 configuration: the three candidate-row CAR GEMMs on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel); CHAM_B16_DMA=0: the
-        # register-staged kernels of csrc/gemm_b16.hip for those too (A/B arm; also what shapes the core does not take fall back to)
-        self.b16_dma = self.gemm_dtype == 'bf16' and os.environ.get("CHAM_B16_DMA", "1") == "1" and L.C % 256 == 0
+        # bf16 configuration: the three candidate-row CAR GEMMs on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel) where it takes the
+        # shape; the register-staged kernels of csrc/gemm_b16.hip otherwise (tests switch rt.b16_dma off to cover those at the G1 shape)
+        self.b16_dma = self.gemm_dtype == 'bf16' and L.C % 256 == 0
         if self.p3:
             C_ = L.C
             npl, pdt = (2, torch.float16) if self.h2 else (3, torch.bfloat16)
@@ -305,8 +271,9 @@ class NARRuntime:
             if self.h2:      # H2Scale records (32 bytes each, zero-initialised): W2's scale; max row norm of Ws1 (factor of the dZ2 bound)
                 self.sc_w2 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_ws1n = torch.zeros(8, dtype=torch.float32, device=dev)
-            # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip); CHAM_DM_FUSED=0: the two separate kernels
-            self.dm_fused = os.environ.get("CHAM_DM_FUSED", "1") == "1" and L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
+            # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip) where the kernel takes the shape; otherwise
+            # (and for 1 + N outside [32, 256]) the two separate kernels
+            self.dm_fused = L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
             self.ws1p = torch.zeros(3, C_, 128, dtype=torch.bfloat16, device=dev)     # planes of Ws1 as stored
         self._plans = {}
         self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
@@ -484,22 +451,8 @@ class NARRuntime:
                              ev=(e0, e1)))
 
     def gemm_p3(self, A, a_ps, lda, B, b_ps, ldb, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
-                accumulate=0, splits=1, whole=False):
-        """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K).
-        A tall NT GEMM whose 256 x 256 tiles end in a round that fills at most half of the 256 CUs (G1 shape: 3 876 tiles = 15 rounds
-        + 36 tiles) goes out as two launches: the full rounds, and the rows of the last round with the reduction range cut into
-        256 // tiles pieces (split-K partials + k_p3_nt_finish), so that round costs a fraction of a tile's time instead of a whole one."""
-        if not tn and splits == 1 and not whole and self.p3_tail_split:
-            nbn = (N + 255) // 256
-            tiles = ((M + 255) // 256) * nbn
-            rem = tiles % 256
-            if tiles > 256 and 0 < rem <= 128 and rem % nbn == 0:
-                m_main = (tiles - rem) // nbn * 256
-                rows = lambda x: None if x is None else (x[0, m_main:] if x.dim() == 3 else x[m_main:])
-                self.gemm_p3(A, a_ps, lda, B, b_ps, ldb, 0, C, ldc, m_main, N, K, bias=bias, act=act, dref_h=dref_h, ldr=ldr, dact=dact, whole=True)
-                self.gemm_p3(rows(A), a_ps, lda, B, b_ps, ldb, 0, rows(C), ldc, M - m_main, N, K, bias=bias, act=act, dref_h=rows(dref_h), ldr=ldr,
-                             dact=dact, splits=256 // rem, whole=True)
-                return
+                accumulate=0, splits=1):
+        """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K)."""
         ws = None
         if splits != 1:
             ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
@@ -680,7 +633,6 @@ class StepPlan:
         self.RH = [f32(BT, Hp) if gru else None for _ in range(L.L)]
         self.drnn = f32(BT, Hp)
         self.WhT = f32(NG * Hp, Hp)
-        self.W2T = f32(C, C)
         if L.rnn_stepwise:
             self.h_state, self.zh, self.carry = f32(B, Hp), f32(B, 2 * Hp), f32(B, Hp)
             self.dzs, self.direct = f32(B, 2 * Hp), f32(B, Hp)
@@ -1216,7 +1168,6 @@ class NARModuleModel:
         drop = self._drop
         dropout = drop['fn'] if drop else None
         use_p3 = getattr(pl, 'used_p3', False)
-        swap = on and rt.tail_on_side and not b16 and not drop and not use_p3
 
         def mark():                      # event on the current stream
             if not on:
@@ -1267,14 +1218,12 @@ class NARModuleModel:
                   "cham_h2_scale_rownorm")
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
-        fused = False      # (round 1's fused scorer-dgrad + mulpred epilogue measured slower than the two passes and was removed in round 2)
         # scorer layer-1 dgrad + cand (.) pred backward in one kernel (csrc/dm_fused.hip): dM never reaches HBM
         dm_fused = use_p3 and rt.dm_fused and 32 <= NC <= 256
         if b16:
             rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
         elif not dm_fused:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
-        e_side0 = mark() if (on and rt.x3 and rt.ws1_after_dm) else e_dS1
         def scorer_small_wgrads():       # layers 2-4: short split-K GEMMs + column sums, nothing but Adam (and the early DP bucket) waits for them
             if b16:
                 rt.gemm_b16(pl.S1, 128, 1, pl.dS2, 64, 0, g('Ws2'), 64, 1, 128, 64, Rc, splits=0)
@@ -1289,14 +1238,14 @@ class NARModuleModel:
                 rt.colsum(pl.dS3, 32, Rc, 32, g('bs3'))
                 rt.colsum(pl.S3, 32, Rc, 32, g('Ws4'), w=pl.ds)
             rt.colsum(pl.ds, 1, Rc, 1, g('bs4'))
-        # Side lane, "critical chain first" (CHAM_SIDE_CRITICAL_FIRST, default on): with short sessions the CAR GEMMs shrink and the
+        # Side lane, "critical chain first": with short sessions the CAR GEMMs shrink and the
         # main lane ends up waiting for the clicked-row gradient that comes out of the side lane's FC -> recurrent -> CAR chain (0.4 ms
         # of a 3.4 ms step in the kernel trace of the G1-like bench leg).  So that chain is enqueued ahead of every weight / bias
         # gradient it does not need; those follow behind it.
         # (bf16 configuration with full-length sessions: 6.26 vs 6.17 ms - the deferred gradients then land beside the W2 wgrad - so there it
         # is used for compacted, i.e. ragged, batches only: 2.23 vs 2.35 ms; fp32: 13.0 = 13.0 ms full-length, 2.95 vs 3.11 ms G1-like lengths)
-        crit_first = on and rt.side_critical_first and (not b16 or pos is not None)
-        with side(e_start, e_side0):
+        crit_first = on and (not b16 or pos is not None)
+        with side(e_start, e_dS1):
             if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
                 rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
@@ -1305,17 +1254,6 @@ class NARModuleModel:
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
             if not crit_first:
                 scorer_small_wgrads()
-        # k_mulpred_bwd is HBM-bound (3 GB, 0.6 ms) and sits between two MFMA-bound GEMMs.  Experiment (CHAM_SPLIT_MULPRED=1): only
-        # the first half of the positions stays in front of the CAR dgrad, the second half runs on the aux lane beside the first
-        # half's dgrad - measured neutral (17.10 / 17.04 vs 16.98 / 17.04 ms), default off
-        half = BT // 2 if (on and rt.split_mulpred and BT >= 256 and not b16 and not use_p3) else BT
-        if fused:
-            half = BT
-
-        def mulpred(g0, g1):
-            check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(
-                ptr(dZ2c[g0 * NC:g1 * NC]), ptr(Z2c[g0 * NC:g1 * NC]), ptr(pl.pred[g0:g1]), C, g1 - g0, N, ptr(pl.dpred[g0:g1]),
-                _stream()), "cham_mulpred_bwd")
         if dm_fused:
             prof = rt.profile
             if prof is not None:
@@ -1337,25 +1275,14 @@ class NARModuleModel:
         elif use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_p3(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part), s),
                   "cham_mulpred_bwd_p3")
-        elif not fused:
-            mulpred(0, half)
-        e_halfB = None
-        if half < BT:
-            e_halfA = mark()
-            rt.aux_stream.wait_event(e_halfA)
-            with torch.cuda.stream(rt.aux_stream):
-                mulpred(half, BT)
-                e_halfB = mark()
-            e_dZ2c = e_halfB
-        else:
-            e_dZ2c = mark()              # dZ2c final + dpred
+        else:             # k_mulpred_bwd: HBM-bound (3 GB), between two MFMA-bound GEMMs
+            check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s),
+                  "cham_mulpred_bwd")
+        e_dZ2c = mark()              # dZ2c final + dpred
         # The candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only): the largest GEMM of the backward, ENQUEUED BEFORE the
         # side lane's long launch sequence below - in the bf16 configuration the GPU keeps up with the host, and the ~25 launches of the
         # side block (0.5-0.8 ms of host time) left this lane idle for that long (kernel-trace timeline, profiles/r02_notes.md);
-        # NT layout on the 256x256 tile.  (CHAM_DGRAD_NN=1: transpose W2 once and run it in the NN layout - faster stand-alone,
-        # slower inside the step; profiles/r01_notes.md item 10)
-        if rt.dgrad_nn:
-            check(lib.cham_transpose_f32(ptr(p('W2')), C, C, ptr(pl.W2T), s), "cham_transpose_f32")
+        # NT layout on the 256x256 tile.
         if b16:
             rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY, dma=rt.b16_dma)
         def w2_wgrad_planes(splits):      # candidate rows' share of the W2 weight gradient from the planes (TN, split-K)
@@ -1367,17 +1294,10 @@ class NARModuleModel:
             rt.gemm_h2(pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         elif use_p3:
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
-        for r0, r1, ev in ((BT, BT + half * NC, None), (BT + half * NC, Rall, e_halfB)):
-            if r1 <= r0 or b16 or use_p3:
-                continue
-            if ev is not None:
-                main_wait(ev)
-            if rt.dgrad_nn:
-                rt.gemm(pl.dZ2[r0:r1], pl.W2T, pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
-            else:
-                rt.gemm(pl.dZ2[r0:r1], p('W2'), pl.dZ1[r0:r1], r1 - r0, C, C, C, C, C, transB=1, dref=pl.Z1[r0:r1], ldr=C, dact=ACT_LEAKY)
+        elif not b16 and Rc > 0:
+            rt.gemm(pl.dZ2[BT:Rall], p('W2'), pl.dZ1[BT:Rall], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
         e_cdgrad = mark()
-        w2_main = bool(on and use_p3 and not swap and 0 < Rc <= rt.w2_main_rows)
+        w2_main = bool(on and use_p3 and 0 < Rc <= rt.w2_main_rows)
         e_w2main = None
         if w2_main:      # candidate rows' share of the W2 weight gradient here, in the main lane's wait for the side lane's recurrent chain
             w2_wgrad_planes(0)
@@ -1452,28 +1372,25 @@ class NARModuleModel:
                             if w2_main:       # (the candidate rows' share was written by the main lane: behind e_cdgrad it is complete)
                                 rt.side_stream.wait_event(e_w2main)
                             else:
-                                if on and rt.w2_after_dgrad:
+                                if on:
                                     rt.side_stream.wait_event(e_cdgrad)
                                 w2_wgrad_planes(rt.p3_w2_splits)
                             rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         rt.colsum(pl.b2part, C, BT, C, g('b2'))
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
-                        if on and rt.w2_last and not w2_main:
+                        if on and not w2_main:
                             # the plane weight gradient waits for the main lane's CAR dgrad (two one-workgroup-per-CU matrix kernels only
                             # time-slice the chip): everything this lane still has to do that does NOT wait - bias sums, the recurrent and
                             # input-projection weight gradients - goes first and runs under that dgrad; the big GEMM is the lane's last work
                             deferred_w2 = w2_grads
                         else:
                             w2_grads()
-                    elif not swap:
+                    else:
                         # ... and the CAR layer-2 weight gradient over ALL rows, the second-largest GEMM of the step, runs beside it
-                        if rt.b2_early:          # (needs dZ2 only: runs while this lane waits for the CAR dgrad)
-                            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
-                        if on and rt.w2_after_dgrad:
+                        if on:
                             rt.side_stream.wait_event(e_cdgrad)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=0)
-                        if not rt.b2_early:
-                            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
+                        rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
                     rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
                 else:
                     rt.gemm(pl.dxproj, p('rnn%d/Wx' % l), pl.drnn, BTf, Hp, NGH, NGH, NGH, Hp, transB=1)
@@ -1512,13 +1429,12 @@ class NARModuleModel:
             else:
                 check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
                       "cham_combine_bwd")
-            nat = rt.precar_bwd_native
             if not drop:
-                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0, force_f32=nat)
+                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
                 rt.colsum(pl.dU, C, BT, C, g('b1'))
-                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0, force_f32=nat)
-                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1, force_f32=nat)
-                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1, force_f32=nat)
+                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
+                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
             # scale/center + embedding tables (fixed summation order: the step is bit-reproducible)
             check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), st), "cham_feature_bwd")
             check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(g('gamma_item')), ptr(g('beta_item')), st), "cham_feature_bwd")
@@ -1535,20 +1451,9 @@ class NARModuleModel:
                                                  rt.meta_cat.data_ptr() + 8 * feat * rt.n_items, ptr(pl.ids_all), card,
                                                  rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
 
-        if swap:
-            # the lanes trade places for the last phase: the W2 wgrad (4 ms of matrix work, nothing but Adam waits for it) on this
-            # normal-priority lane, split so finely that its workgroups retire in rounds; the PreCAR backward on the high-priority
-            # side lane, whose kernels are dispatched first whenever a round of wgrad workgroups frees the CUs' register files
-            e_dgrad = mark()
-            with side(e_dgrad):
-                precar_backward(rt.gemm_ws_side)
-            main_wait(e_dZ1in)       # (= clicked-row dZ2 ready)
-            rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, Rall, C, C, C, transA=1, splits=rt.w2_splits)
-            rt.colsum(pl.dZ2, C, Rall, C, g('b2'))
-        else:
-            if on:
-                main_wait(e_dZ1in)
-            precar_backward(rt.gemm_ws)      # beside the W2 wgrad of the side lane
+        if on:
+            main_wait(e_dZ1in)
+        precar_backward(rt.gemm_ws)      # beside the W2 wgrad of the side lane
         rt.join()
 
     def apply_gradients(self):

@@ -167,8 +167,6 @@ int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb, int tn, vo
                       int act, const void* dref, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes,
                       int splits_hint, void* stream);
 void cham_gemm_p3_launch_counts(long long* out8, int reset);
-/* A/B aid (tests/bench_gemm_p3.py): 1 = staggered pipeline (default), 0 = the first version (all requests of a stage at the top of a step) */
-void cham_gemm_p3_set_variant(int variant);
 /* split3 of an fp32 matrix X [R, Cc] (row stride ld) into bf16 planes: dst[q][r][c] (planes plane_stride elements apart, row stride
  * ldd) and / or dstT[q][c][r] (the transposed matrix); either may be NULL.  a = h + m + l exactly (tests/test_split3_cpu.py). */
 int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
@@ -197,8 +195,6 @@ int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* 
                  const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr,
                  int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 void cham_gemm_h2_launch_counts(long long* out8, int reset);
-/* A/B aid (tests/bench_gemm_h2.py): 0 = NT epilogue through LDS with 16-byte stores (default), 1 = the direct dword epilogue */
-void cham_gemm_h2_set_variant(int variant);
 /* producers of two-plane matrices (csrc/scorer.hip, csrc/dm_fused.hip): cham_combine_fwd_p3 / cham_mulpred_bwd_p3 / cham_dm_mulpred_p3
  * with the output written as (h, l) fp16 planes x the scale of `scale_rec` (filled BEFORE the call: max|U| + max|V| for the PreCAR output,
  * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */
@@ -302,8 +298,6 @@ int cham_ugrnn_point_fwd(const float* xproj, const float* zh, const int32_t* seq
 int cham_ugrnn_point_bwd(const float* dout, const float* carry, const int32_t* seq_len, int B, int T, int t, int Hp,
                          const float* hprev, const float* G, const float* Cc, float* dxproj, float* dzs, float* direct,
                          void* stream);
-/* scheduling hook: recurrent workgroups request this much LDS so that no other workgroup shares their CU */
-void cham_rnn_set_exclusive_lds(size_t bytes);
 int cham_transpose_f32(const float* in, int rows, int cols, float* out, void* stream);
 /* valid-position compaction (the mask of nar_model.py:231 applied as a row selection instead of a multiply): rows are
  * `words` 32-bit words wide; gather: dst[i] = src[pos[i]], scatter: dst[pos[i]] = src[i] (other rows of dst untouched) */

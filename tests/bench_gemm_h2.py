@@ -70,14 +70,11 @@ def main():
          native(A, 1, D, 0, Wg, C, C, R, splits=0),
          lambda: Wg, lambda: A.double().t() @ D.double()),
     ]
-    lib.cham_gemm_p3_set_variant(0)
     for name, f_h2, f_p3, f_nat, out, ref in cases:
         Rf = ref(); scale = float(Rf.abs().max())
-        for tag, fn, peak in (("two fp16 planes (h2)", f_h2, 2500.0 / 3), ("h2, dword epilogue arm", f_h2, 2500.0 / 3), ("three bf16 planes (p3)", f_p3, 2500.0 / 6),
-                              ("native fp32 MFMA", f_nat, 157.3)):
-            if fn is None or (only and tag != "two fp16 planes (h2)") or (tag == "h2, dword epilogue arm" and "wgrad" in name):
+        for tag, fn, peak in (("two fp16 planes (h2)", f_h2, 2500.0 / 3), ("three bf16 planes (p3)", f_p3, 2500.0 / 6), ("native fp32 MFMA", f_nat, 157.3)):
+            if fn is None or (only and tag != "two fp16 planes (h2)"):
                 continue
-            lib.cham_gemm_h2_set_variant(1 if tag == "h2, dword epilogue arm" else 0)
             out().zero_()
             fn(); torch.cuda.synchronize()
             err = float((out().double() - Rf).abs().max()) / scale

@@ -56,10 +56,9 @@ def main():
     only = os.environ.get("P3_ONLY")          # PMC passes (scripts/p3_pmc.sh): only the default plane kernel, few launches
     for name, p3, x3, out, ref in cases:
         Rf = ref(); scale = float(Rf.abs().max())
-        for tag, fn in (("planes in HBM (p3)", p3), ("p3, half tile x 2 per CU", p3), ("p3, staggered arm", p3), ("split on the fly (x3)", x3)):
+        for tag, fn in (("planes in HBM (p3)", p3), ("split on the fly (x3)", x3)):
             if only and tag != "planes in HBM (p3)":
                 continue
-            lib.cham_gemm_p3_set_variant({"p3, staggered arm": 1, "p3, half tile x 2 per CU": 2}.get(tag, 0))
             out().zero_()
             fn(); torch.cuda.synchronize()
             err = float((out().double() - Rf).abs().max()) / scale

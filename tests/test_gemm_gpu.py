@@ -281,4 +281,5 @@ def test_nt_narrow_output_with_split_hint(gpu, N, x3, bf16):
     split-K reductions walk float4 groups of a row, so such a shape must take the unsplit kernel - through every public entry point."""
     tol = 2e-2 if bf16 else 1e-4
     assert _run(gpu, 96, N, 4096, transB=1, splits=0, x3=x3, bf16=bf16) < tol
-    assert _run(gpu, 96, N, 4096, transB=1, bias=True, splits=5, x3=x3, bf16=bf16) < tol
+    assert _run(gpu, 96, N, 4096, transB=1, splits=5, x3=x3, bf16=bf16) < tol
+    assert _run(gpu, 96, N, 4096, transB=1, dref=True, dact=1, splits=0, x3=x3, bf16=bf16) < tol

@@ -110,14 +110,6 @@ def _tn(gpu, M, N, K, splits=1, accumulate=0, seed=0, reps=1):
     return float((outs[0].double() - R).abs().max()) / float(R.abs().max())
 
 
-@pytest.fixture(params=[1, 0], ids=["dword_epilogue", "lds_epilogue"])
-def variant(request):
-    lib = _lib_()
-    lib.cham_gemm_h2_set_variant(request.param)
-    yield request.param
-    lib.cham_gemm_h2_set_variant(0)
-
-
 def test_scale_records_and_split_kernel(gpu):
     """cham_h2_scale_absmax (one and two arrays), cham_h2_scale_rownorm (K = 128 and generic, with a factor), cham_split2h (planes + transposed
     planes bit-exact against the host formula, sign kept on underflow), and that a record can be re-used (the kernels clear their scratch)."""
@@ -158,7 +150,7 @@ def test_scale_records_and_split_kernel(gpu):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 32), (256, 256, 48), (256, 256, 64), (256, 256, 80), (512, 512, 64), (300, 260, 96),
                                    (1000, 1024, 1024), (77, 520, 416), (1, 4, 16), (513, 256, 1024)])
-def test_h2_nt(gpu, variant, M, N, K):
+def test_h2_nt(gpu, M, N, K):
     assert _nt(gpu, M, N, K) < 5e-5
     assert _nt(gpu, M, N, K, bias=True, act=2) < 5e-5
     assert _nt(gpu, M, N, K, bias=True) < 5e-5
@@ -211,23 +203,10 @@ def test_h2_rows_of_very_different_magnitude(gpu, spread):
     assert _nt(gpu, 1000, 512, 256, row_spread=spread, seed=3) < 5e-5
 
 
-def test_h2_is_repeatable_under_load(gpu, variant):
+def test_h2_is_repeatable_under_load(gpu):
     """Race screen: the same launch five times, bit-identical (a fragment read that overtakes its DMA shows up as run-to-run noise)."""
     _nt(gpu, 4096, 1024, 1024, bias=True, act=2, check_ref=False, reps=5)
     assert _tn(gpu, 1024, 1024, 40000, splits=0, reps=5) < 1e-4
-
-
-@pytest.mark.parametrize("M,N,K", [(1000, 1024, 1024), (300, 260, 96), (77, 520, 416)])
-def test_h2_nt_epilogue_forms_are_bit_identical(gpu, M, N, K):
-    """The NT epilogue through LDS (16-byte stores, the default) and the direct dword form apply the same operations in the same order to
-    the same accumulators: bit-identical outputs for every epilogue, ragged edges included."""
-    lib = _lib_()
-    for kw in (dict(), dict(bias=True, act=2), dict(bias=True), dict(dref=True)):
-        lib.cham_gemm_h2_set_variant(1)
-        a = _nt(gpu, M, N, K, check_ref=False, **kw)
-        lib.cham_gemm_h2_set_variant(0)
-        b = _nt(gpu, M, N, K, check_ref=False, **kw)
-        assert torch.equal(a, b), kw
 
 
 def test_h2_argument_errors(gpu):

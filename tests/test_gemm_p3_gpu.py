@@ -87,15 +87,6 @@ def _tn(gpu, M, N, K, splits=1, accumulate=0, seed=0, reps=1):
     return float((outs[0].double() - R).abs().max()) / float(R.abs().max())
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["half_tile_2wg", "staggered", "v1"])
-def variant(request):
-    from chameleon_recsys_amd import _lib
-    lib = _lib.load()
-    lib.cham_gemm_p3_set_variant(request.param)
-    yield request.param
-    lib.cham_gemm_p3_set_variant(0)
-
-
 def test_split3_kernel_is_bit_exact_and_sums_back(gpu):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
@@ -114,7 +105,7 @@ def test_split3_kernel_is_bit_exact_and_sums_back(gpu):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 32), (256, 256, 48), (512, 512, 64), (300, 260, 96), (1000, 1024, 1024), (77, 520, 416),
                                    (1, 4, 16), (513, 256, 1024)])
-def test_p3_nt(gpu, variant, M, N, K):
+def test_p3_nt(gpu, M, N, K):
     assert _nt(gpu, M, N, K) < 5e-5
     assert _nt(gpu, M, N, K, bias=True, act=2) < 5e-5
     assert _nt(gpu, M, N, K, bias=True) < 5e-5
@@ -122,7 +113,7 @@ def test_p3_nt(gpu, variant, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 40), (256, 512, 777), (512, 256, 3001), (1024, 1024, 5000), (256, 256, 1)])
-def test_p3_tn_wgrad_splitk(gpu, variant, M, N, K):
+def test_p3_tn_wgrad_splitk(gpu, M, N, K):
     assert _tn(gpu, M, N, K) < 1e-4
     assert _tn(gpu, M, N, K, splits=0) < 1e-4
     assert _tn(gpu, M, N, K, splits=7) < 1e-4
@@ -130,7 +121,7 @@ def test_p3_tn_wgrad_splitk(gpu, variant, M, N, K):
     assert _tn(gpu, M, N, K, splits=0, accumulate=1) < 1e-4
 
 
-def test_p3_exact_on_bf16_operands_and_layout(gpu, variant):
+def test_p3_exact_on_bf16_operands_and_layout(gpu):
     """Operands that ARE bf16 numbers have empty middle / low planes and integer-valued products are exact; A = I against an asymmetric
     B catches row / column swaps of the fragment maps, the swizzles and the C/D map, in both layouts."""
     from chameleon_recsys_amd import _lib
@@ -160,7 +151,7 @@ def test_p3_dynamic_range(gpu, scale):
     assert _nt(gpu, 300, 260, 96, scale=scale) < 5e-5
 
 
-def test_p3_is_repeatable_under_load(gpu, variant):
+def test_p3_is_repeatable_under_load(gpu):
     """Race screen: the same launch five times, bit-identical (a fragment read that overtakes its DMA shows up as run-to-run noise)."""
     _nt(gpu, 4096, 1024, 1024, bias=True, act=2, check_ref=False, reps=5)
     assert _tn(gpu, 1024, 1024, 40000, splits=0, reps=5) < 1e-4
@@ -286,38 +277,3 @@ def test_infinite_operand_nan_in_plane_arithmetic_inf_in_native(gpu):
     assert (outs[("native", 2)][7] == 1.0).all()                 # tanh(+inf) = 1: finite
     for name in ("x3", "p3"):
         assert torch.isnan(outs[(name, 0)][7]).all() and torch.isnan(outs[(name, 2)][7]).all(), name
-
-
-@pytest.mark.parametrize("epi", ["plain", "tanh", "bias", "dgrad"])
-@pytest.mark.parametrize("splits", [2, 3, 7, 64])
-def test_nt_split_k_matches_the_single_pass(gpu, epi, splits):
-    """NT with the reduction range in pieces (the partly filled last round of a tall GEMM goes out this way: nar_model.gemm_p3): every
-    epilogue through k_p3_nt_finish, against the one-pass kernel on the same planes (fp32 re-association of the K sum only)."""
-    from chameleon_recsys_amd import _lib
-    from chameleon_recsys_amd._lib import check, ptr
-    lib = _lib.load()
-    M, N, K = 2304 + 77, 1024, 1024
-    g = torch.Generator(device=gpu).manual_seed(splits)
-    A = torch.randn(M, K, device=gpu, generator=g)
-    B = torch.randn(N, K, device=gpu, generator=g) * (K ** -0.5)
-    bias = torch.randn(N, device=gpu, generator=g) if epi in ("tanh", "bias") else None
-    Yh = torch.randn(M, N, device=gpu, generator=g).to(torch.bfloat16).contiguous() if epi == "dgrad" else None
-    Ap, Bp = split3(A), split3(B)
-    ws = torch.empty(64 * M * N, device=gpu)
-    st = torch.cuda.current_stream().cuda_stream
-    outs = []
-    for sp in (1, splits, splits):
-        C = torch.full((M, N), float('nan'), device=gpu)
-        c0 = _counts(lib)
-        check(lib.cham_gemm_p3(ptr(Ap), M * K, K, ptr(Bp), N * K, K, 0, ptr(C), N, M, N, K, ptr(bias), 2 if epi == "tanh" else 0, ptr(Yh), N,
-                               1 if epi == "dgrad" else 0, 0, ptr(ws), ws.numel() * 4, sp, st), "cham_gemm_p3")
-        torch.cuda.synchronize()
-        c1 = _counts(lib)
-        assert c1[4] - c0[4] == (1 if sp > 1 else 0)
-        if sp > 1:
-            assert 1 < c1[7] <= min(sp, K // 16)
-        outs.append(C)
-    assert torch.isfinite(outs[1]).all()
-    assert torch.equal(outs[1], outs[2])
-    err = float((outs[1] - outs[0]).abs().max())
-    assert err < 2e-5 * max(1.0, float(outs[0].abs().max())), err

@@ -61,5 +61,5 @@ def test_documented_switch_defaults_match_the_code():
         assert name in doc, "%s is not documented in DESIGN.md section 9" % name
         row = [l for l in doc.splitlines() if l.startswith("| `") and name in l]
         assert row, name
-        if name in ("CHAM_COMPACT", "CHAM_OVERLAP", "CHAM_PRESAMPLE", "CHAM_ASYNC_UPLOAD", "CHAM_SIDE_PRIORITY"):
+        if name in ("CHAM_COMPACT", "CHAM_OVERLAP", "CHAM_PRESAMPLE", "CHAM_GEMM_H2", "CHAM_GEMM_P3"):
             assert "| %s |" % default in row[0], (name, default, row[0])
