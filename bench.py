@@ -640,6 +640,7 @@ def main():
                                 "f32_native": "every GEMM on v_mfma_f32_32x32x2_f32",
                                 "bf16": "bf16-resident candidate-row matrices, fp32 accumulate"}[args.dtype],
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+                       "rnn_coop_spin_timeouts": int(rt.rnn_coop_timed_out()),       # bounded spins of the cooperative recurrent kernels (ragged leg): must be 0
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",
                          "achieved": round(achieved, 2), "peak": round(dom_peak, 1), "unit": "TFLOP/s",

@@ -75,6 +75,10 @@ _SIGNATURES = {
     "cham_upcast_b16": (c_int, [P, c_size_t, P, P]),
     "cham_rnn_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_rnn_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "cham_rnn_coop_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cham_ugrnn_fwd_coop": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
+    "cham_ugrnn_bwd_coop": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
+    "cham_rnn_coop_timeouts": (c_int, [P, c_int, c_int, P]),
     "cham_ugrnn_point_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_ugrnn_point_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "cham_transpose_f32": (c_int, [P, c_int, c_int, P, P]),

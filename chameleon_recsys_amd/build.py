@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libchameleon_nar.so")
-SOURCES = ["gemm.hip", "gemm_x3.hip", "gemm_p3.hip", "gemm_h2.hip", "dm_fused.hip", "gemm_b16.hip", "sampler.hip", "features.hip", "scorer.hip", "rnn.hip", "optim.hip", "state.hip"]
+SOURCES = ["gemm.hip", "gemm_x3.hip", "gemm_p3.hip", "gemm_h2.hip", "dm_fused.hip", "gemm_b16.hip", "sampler.hip", "features.hip", "scorer.hip", "rnn.hip", "rnn_coop.hip", "optim.hip", "state.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("CHAM_BUILD_DEFINES", "").split()          # extra hipcc flags (development aid)
 

@@ -245,6 +245,12 @@ class NARRuntime:
         #     the side lane's LAST work: the small weight / bias gradients go first and run under that dgrad.
         self.p3_w2_splits = 32
         self.w2_main_rows = 131072
+        #   * the same threshold selects the recurrent kernels: steps with at most this many candidate rows (ragged batches, the shard of
+        #     a strong-scaling rank) run the UGRNN time steps on eight cooperating workgroups per 32 sessions with W_h resident in LDS
+        #     (csrc/rnn_coop.hip: ~8 us per time step instead of ~33, but 120-155 KB of LDS per workgroup - no CU shared with a plane-GEMM
+        #     workgroup); a full batch hides the single-workgroup kernels (csrc/rnn.hip, 33 KB of LDS) behind its big GEMMs
+        self.rnn_coop_rows = 131072 if (L.cell == 'ugrnn' and L.Hp == 256 and not L.rnn_stepwise) else -1
+        self._rnn_coop_ws = {}
         self.presample = os.environ.get("CHAM_PRESAMPLE", "1") == "1"       # NARModuleModel.presample (A/B switch)
         self.upload_stream = lane_stream(dev, "upload")       # H2D copies of a batch on their own stream, from a page-locked staging ring
         self.pinned = _PinnedRing()
@@ -357,6 +363,19 @@ class NARRuntime:
         self.flat.copy_(sd['flat']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.global_step = int(sd['global_step'])
         self.weights_version += 1
+
+    def rnn_coop_ws(self, B):
+        """Exchange buffers + flags of the cooperative recurrent kernels for batches of B sessions (zero-initialised once; the forward and
+        the backward of a step run on the same lane and share it)."""
+        ws = self._rnn_coop_ws.get(B)
+        if ws is None:
+            nb = int(self.lib.cham_rnn_coop_workspace_bytes(B, self.layout.Hp))
+            ws = self._rnn_coop_ws[B] = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def rnn_coop_timed_out(self):
+        """True if a cooperating recurrent workgroup ever gave up a bounded spin (synchronises; tests / bench / end of Estimator.train)."""
+        return any(int(self.lib.cham_rnn_coop_timeouts(ptr(ws), B, self.layout.Hp, _stream())) != 0 for B, ws in self._rnn_coop_ws.items())
 
     def plan(self, B, T, N, n_buf, Bg=None):
         """Buffers for one batch shape, cached: ragged hourly files produce a handful of padded lengths T.  Least-recently-used
@@ -1076,6 +1095,10 @@ class NARModuleModel:
                         check(lib.cham_ugrnn_point_fwd(ptr(pl.xproj[l]), ptr(pl.zh), ptr(pl.seq_len), B, T, t, Hp, ptr(pl.h_state),
                                                        ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), _stream()),
                               "cham_ugrnn_point_fwd")
+                elif 0 < Rc <= rt.rnn_coop_rows and B <= 1024:
+                    ws = rt.rnn_coop_ws(B)
+                    check(lib.cham_ugrnn_fwd_coop(ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp, ptr(pl.rnn_out[l]),
+                                                  ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(ws), ws.numel(), _stream()), "cham_ugrnn_fwd_coop")
                 else:
                     check(lib.cham_rnn_fwd(cell, ptr(pl.xproj[l]), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp,
                                            ptr(pl.rnn_out[l]), ptr(pl.hprev[l]), ptr(pl.G[l]), ptr(pl.Cc[l]), ptr(pl.R[l]),
@@ -1341,6 +1364,10 @@ class NARModuleModel:
                         # carry = direct + dzs W_h^T  (rows beyond their length: dzs = 0, direct = carry -> unchanged)
                         pl.carry.copy_(pl.direct)
                         rt.gemm(pl.dzs, p('rnn%d/Wh' % l), pl.carry, B, Hp, 2 * Hp, 2 * Hp, 2 * Hp, Hp, transB=1, accumulate=1, force_f32=True)
+                elif 0 < Rc <= rt.rnn_coop_rows and B <= 1024:
+                    ws = rt.rnn_coop_ws(B)
+                    check(lib.cham_ugrnn_bwd_coop(ptr(pl.drnn), ptr(p('rnn%d/Wh' % l)), ptr(pl.seq_len), B, T, Hp, ptr(pl.hprev[l]), ptr(pl.G[l]),
+                                                  ptr(pl.Cc[l]), ptr(pl.dxproj), ptr(ws), ws.numel(), ss), "cham_ugrnn_bwd_coop")
                 else:
                     check(lib.cham_transpose_f32(ptr(p('rnn%d/Wh' % l)), Hp, 2 * Hp, ptr(pl.WhT), ss), "cham_transpose_f32")
                     if cell == 1:

@@ -290,6 +290,20 @@ int cham_rnn_fwd(int cell_kind, const float* xproj, const float* Wh, const int32
                  float* hprev, float* G, float* Cc, float* R, float* RH, void* stream);
 int cham_rnn_bwd(int cell_kind, const float* dout, const float* WhT, const int32_t* seq_len, int B, int T, int Hp,
                  const float* hprev, const float* G, const float* Cc, const float* R, float* dxproj, void* stream);
+/* UGRNN time steps for Hp == 256 with the recurrent weights resident in LDS: eight cooperating workgroups per 32 sessions, each owning 32
+ * hidden units (its columns of W_h in LDS for the whole sequence), exchanging their slice of h_t (forward) / of the gate and candidate
+ * gradients (backward) through L2 with agent-scope release / acquire every step (csrc/rnn_coop.hip).  Same contract and outputs as
+ * cham_rnn_fwd / cham_rnn_bwd with cell_kind 0 up to the fp32 summation order of the recurrent product; the backward takes W_h AS STORED
+ * [Hp, 2Hp].  For steps whose critical path is the recurrent chain (ragged batches, the 32-session shard of a strong-scaling rank): ~8 us
+ * per time step instead of ~33.  workspace: cham_rnn_coop_workspace_bytes(B, Hp) bytes, 256-byte aligned, zero-initialised once, one per
+ * stream.  -EINVAL for Hp != 256 or B > 1024 (the caller keeps cham_rnn_fwd / _bwd).  cham_rnn_coop_timeouts: 1 if a workgroup ever gave
+ * up a (bounded) spin on this workspace - synchronises the stream; tests and bench.py assert 0. */
+size_t cham_rnn_coop_workspace_bytes(int B, int Hp);
+int cham_ugrnn_fwd_coop(const float* xproj, const float* Wh, const int32_t* seq_len, int B, int T, int Hp, float* out, float* hprev, float* G,
+                        float* Cc, void* workspace, size_t workspace_bytes, void* stream);
+int cham_ugrnn_bwd_coop(const float* dout, const float* Wh, const int32_t* seq_len, int B, int T, int Hp, const float* hprev, const float* G,
+                        const float* Cc, float* dxproj, void* workspace, size_t workspace_bytes, void* stream);
+int cham_rnn_coop_timeouts(const void* workspace, int B, int Hp, void* stream);
 /* step-wise fallback for rnn_units beyond the fused kernels' LDS budget (UGRNN Hp > 512; hypertuning goes to 1024,
  * nar_mlengine_hypertuning.yaml:28-33): the caller computes zh = h_{t-1} W_h (forward) / carry_next = direct + dzs W_h^T
  * (backward) with cham_gemm_f32 per time step; these do the UGRNN gate arithmetic, length masking and state carry */
