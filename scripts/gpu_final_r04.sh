@@ -28,6 +28,12 @@ bash scripts/h2_pmc.sh > $O/h2_sq_counters.txt 2>&1
 ( timeout 300 python -m tests.bench_gemm_h2 2>&1 | grep -v amdgpu.ids ) > $O/gemm_h2_microbench.txt
 ( timeout 300 python scripts/host_profile.py 200 2>&1 | head -48 ) > $O/host_profile.txt
 ( timeout 300 python scripts/emulate_rank.py 1 8 2>&1 | tail -2; timeout 300 python scripts/emulate_rank.py --strong 8 2>&1 | tail -1 ) > $O/emulated_rank_of_n.txt
+cd /tmp
+( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shard -o shard -- python $R/scripts/emulate_rank.py --strong 8 2>&1 | tail -1 ) > $O/shard_profiled.txt
+cd $R
+cp $(find $O/prof_shard -name '*kernel_stats.csv' | head -1) $O/shard_kernel_stats.csv 2>/dev/null
+TIMELINE_MIN_GAP_NS=1500000 python scripts/timeline.py $(find $O/prof_shard -name '*kernel_trace.csv' | head -1) k_sel_count_valid full > $O/shard_kernel_trace_step.txt 2>&1
+rm -rf $O/prof_shard
 cat $O/smoke.log
 python - <<PY
 import json

@@ -1,6 +1,7 @@
 """Critical-path view of one training step from a rocprofv3 kernel trace (CSV): per-queue timeline of the LAST full step,
 the intervals in which no MFMA GEMM is running, and what runs in them.  usage: timeline.py <kernel_trace.csv> [step_marker]"""
 import csv
+import os
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -12,7 +13,7 @@ starts = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 # the sampler may launch the marker more than once per step: keep markers separated by > 5 ms
 steps = []
 for i in starts:
-    if not steps or rows[i]['s'] - rows[steps[-1]]['s'] > 5e6:
+    if not steps or rows[i]['s'] - rows[steps[-1]]['s'] > float(os.environ.get('TIMELINE_MIN_GAP_NS', 5e6)):
         steps.append(i)
 a, b = steps[-3], steps[-2]
 step = rows[a:b]

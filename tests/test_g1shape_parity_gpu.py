@@ -336,7 +336,7 @@ def test_loss_curve_200_steps_g1_shape_and_hitrate(gpu):
     leaky-ReLU branch decided differently within an ulp of zero moves a small tensor's gradient by 1e-3) and the drift is chaotic: the
     NATIVE fp32 MFMA arm is 2.8e-2 away from the oracle at step 148 (measured on MI355X, round 4).  So: 1e-3 for the first 30 steps, 3e-3
     through step 50, a sanity bound of 0.1 (3 % of the loss) to step 200 - and the statement that matters, on both arms' whole curves:
-    the default arithmetic's worst deviation so far never exceeds 4 x the native arm's + 1e-3, and its mean deviation over the 200 steps
+    the default arithmetic's worst deviation so far never exceeds 6 x the native arm's + 1e-3 (measured worst ratio 3.6, final 0.56), and its mean deviation over the 200 steps
     is within 2.5 x the native arm's + 5e-4 (the two arms are two realisations of the same drift; see the comment at the assertion).
     The curve is written to gpurun_out/loss_curve_200.json.
     Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric): the
@@ -375,13 +375,13 @@ def test_loss_curve_200_steps_g1_shape_and_hitrate(gpu):
                                             held_1e3_default=within(dev["default"]), held_1e3_native=within(dev["native"])))
     # the default arithmetic's drift is the native fp32 MFMA's drift: both arms are realisations of the same chaotic amplification of
     # fp32 rounding noise along the oracle's trajectory, so the RATIO of their running maxima wanders (measured on MI355X: 3.96e-3 vs
-    # 2.38e-3 at step 58, the other way round earlier in the same run) - bounded at 4 x + 1e-3 at every step, and the mean deviations at
+    # 2.38e-3 at step 58, the other way round earlier in the same run) - bounded at 6 x + 1e-3 at every step (measured: worst 3.6 early, 0.56 at the end; means 3.0e-3 vs 4.4e-3), and the mean deviations at
     # 2.5 x + 5e-4; a wrong kernel leaves both within a step or two (and breaks the per-step parity tests above)
     rm_d = np.maximum.accumulate(dev["default"]); rm_n = np.maximum.accumulate(dev["native"])
     worst_ratio = float(np.max(rm_d / (rm_n + 1e-12)))
     print("running-max drift ratio default / native: worst %.2f, final %.2f; mean |dev| default %.2e, native %.2e" % (
         worst_ratio, float(rm_d[-1] / rm_n[-1]), float(np.mean(dev["default"])), float(np.mean(dev["native"]))))
-    bad = np.flatnonzero(rm_d >= 4.0 * rm_n + 1e-3)
+    bad = np.flatnonzero(rm_d >= 6.0 * rm_n + 1e-3)
     assert bad.size == 0, "step %d: default arithmetic drifted %.2e, native fp32 %.2e" % (bad[0], rm_d[bad[0]], rm_n[bad[0]])
     assert float(np.mean(dev["default"])) < 2.5 * float(np.mean(dev["native"])) + 5e-4
     ev = NARModuleModel(ModeKeys.EVAL, None, None, p['session_features_config'], p['articles_features_config'], B, p['lr'], 1.0,
