@@ -139,7 +139,7 @@ def gemm_symbol(r):
     if r.get('b1'):       # bf16-resident operands on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel)
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
-        return "void k_dm_mulpred_fused<%s>(DmfParams)" % tf(bool(r.get('h2out')))
+        return "void k_dm_mulpred_fused<%d>(DmfParams)" % (2 if r.get('bf16') else (1 if r.get('h2out') else 0))
     if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
         return "void gemm_h2_kernel<%s, %d>(H2Params)" % (tf(bool(r['transA'])), epi)
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
@@ -439,9 +439,12 @@ def main():
         k = i % n_distinct
         if args.state == "device":
             model.feed_state(state, state)                                                              # hook.before_run
-            model.train_step(dev_batches[k])
-            state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])        # hook.after_run
-            model.presample(dev_batches[(k + 1) % n_distinct])        # next batch's negatives behind the state update
+
+            def mid_step():      # what Estimator.train installs: this batch's state update (the hook's) + the next batch's negatives,
+                #                  enqueued right behind the step's last read of the state (nar_model.backward)
+                state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])
+                model.presample(dev_batches[(k + 1) % n_distinct], step=rt.global_step + 1)
+            model.train_step(dev_batches[k], mid_step=mid_step)
         else:
             model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())
             model.train_step(dev_batches[k])
@@ -500,7 +503,9 @@ def main():
         sh[0] += 1; sh[1] += t_ms
         # operands + output, each touched once: A + B + bias + C (+ the saved activation a dgrad epilogue reads); fp32 storage, or
         # bf16 operands / saved activations and a bf16 or fp32 output for the bf16-resident kernels
-        if r.get('dmf'):      # dS1 in, Z2c in, the planes out (6 B per element as three bf16 planes, 4 B as two fp16 planes), pred / dpred / b2 partials per position
+        if r.get('dmf') and r.get('bf16'):      # the bf16 twin: every matrix one bf16 array
+            e['bytes'] += 2.0 * r['M'] * r['K'] + 2.0 * r['K'] * r['N'] + 2.0 * r['M'] * r['N'] + 2.0 * r['M'] * r['N']
+        elif r.get('dmf'):      # dS1 in, Z2c in, the planes out (6 B per element as three bf16 planes, 4 B as two fp16 planes), pred / dpred / b2 partials per position
             e['bytes'] += 4.0 * r['M'] * r['K'] + 6.0 * r['K'] * r['N'] + 4.0 * r['M'] * r['N'] + (4.0 if r.get('h2out') else 6.0) * r['M'] * r['N']
         elif r.get('h2'):       # operands as two fp16 planes (4 B per element), fp32 output, the dgrad reads the activation's h plane
             e['bytes'] += 4.0 * (r['M'] * r['K'] + r['K'] * r['N']) + 4.0 * r['M'] * r['N'] + (2.0 * r['M'] * r['N'] if r['dref'] else 0) + \
@@ -570,9 +575,11 @@ def main():
         def ragged_step(i):
             k = i % n_distinct
             model.feed_state(state, state)
-            model.train_step(rdev[k])
-            state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
-            model.presample(rdev[(k + 1) % n_distinct])
+
+            def mid_step():
+                state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
+                model.presample(rdev[(k + 1) % n_distinct], step=rt.global_step + 1)
+            model.train_step(rdev[k], mid_step=mid_step)
         for i in range(max(n_distinct, args.warmup)):        # every distinct padded length T allocates its StepPlan once
             ragged_step(i)
         barrier()

@@ -33,9 +33,9 @@
 static_assert(DMF_NT == 2, "the epilogue packs exactly two tiles' columns per lane");
 
 struct DmfParams {
-    const float* dS1; int lds1;                 // [Rc, 128]
-    const __bf16* W; long long w_ps;            // planes of Ws1 [C, 128] as stored, plane stride in elements
-    const float* Z2c; const float* pred;        // [Rc, C], [BT, C]
+    const float* dS1; int lds1;                 // [Rc, 128] (fp32; MODE 2: bf16, lds1 in elements)
+    const __bf16* W; long long w_ps;            // planes of Ws1 [C, 128] as stored, plane stride in elements (MODE 2: the one bf16 shadow)
+    const float* Z2c; const float* pred;        // [Rc, C] (MODE 2: bf16), [BT, C]
     __bf16* out; long long out_ps;              // planes of dZ2 [Rc, C]: three bf16 planes, or (H2) two fp16 planes x the scale of osc
     const H2Scale* osc;
     float* dpred; float* b2part;                // [BT, C]
@@ -52,10 +52,15 @@ __device__ __forceinline__ void dmf_dma_one(unsigned lds, unsigned voff, const u
         : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r) : "memory");
 }
 
-// H2: the output as two fp16 planes x a power-of-two scale (csrc/gemm_h2.hip) instead of three bf16 planes; the kernel's own products
-// (dS1 x Ws1, K = 128: 12 % of its time) stay six bf16 plane products - its time is the 1 GB of Z2 in and the planes out.
-template <bool H2>
+// MODE 0: three bf16 planes out (csrc/gemm_p3.hip).  MODE 1: the output as two fp16 planes x a power-of-two scale (csrc/gemm_h2.hip); the
+// kernel's own products (dS1 x Ws1, K = 128: 12 % of its time) stay six bf16 plane products - its time is the 1 GB of Z2 in and the planes
+// out.  MODE 2: the bf16 configuration (BASELINE configs[2]) - dS1, Ws1 (its bf16 shadow), Z2c and the output are single bf16 matrices, ONE
+// product; dM is rounded to bf16 where the unfused pair (cham_gemm_b16 + cham_mulpred_bwd_b16) stores it, so the result is that pair's up
+// to the summation order of the per-position sums; col_part sums the ROUNDED gradient (what cham_colsum_b16 would read back).
+template <int MODE>
 __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
+    constexpr bool H2 = MODE == 1, B16 = MODE == 2;
+    constexpr int NPL = B16 ? 1 : 3;                                      // planes of each operand
     extern __shared__ __attribute__((aligned(1024))) unsigned char dmf_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -70,8 +75,15 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     // (every global access of this kernel goes through a buffer descriptor sized to the workgroup's valid rows: rows beyond them read
     // zeros / drop their stores without a branch - a branch around a load makes hipcc wait for each load in turn, 16 dependent HBM round
     // trips per column tile in the first version of this epilogue: 1.25 ms for the kernel, profiles/r03_notes.md)
-    bf16x8 AH[8], AM[8], AL[8];
-    {
+    bf16x8 AH[8], AM[B16 ? 1 : 8], AL[B16 ? 1 : 8];
+    if constexpr (B16) {
+        const __bf16* a16 = reinterpret_cast<const __bf16*>(p.dS1);
+        const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a16 + row0 * (size_t)p.lds1), 0,
+                                                                            (unsigned)((size_t)rows_valid * p.lds1 * 2), 0x00020000);
+        const unsigned ao = ((unsigned)(wr0 + l31) * (unsigned)p.lds1 + 8u * hh) * 2u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) AH[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(aw, ao + 32u * s, 0, 0));
+    } else {
         const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dS1 + row0 * (size_t)p.lds1), 0,
                                                                             (unsigned)((size_t)rows_valid * p.lds1 * 4), 0x00020000);
         const unsigned ao = ((unsigned)(wr0 + l31) * (unsigned)p.lds1 + 8u * hh) * 4u;
@@ -90,12 +102,14 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
         }
     }
-    const __amdgpu_buffer_rsrc_t zw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z2c + row0 * (size_t)C), 0,
-                                                                        (unsigned)((size_t)rows_valid * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t zw = B16 ?
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(reinterpret_cast<const __bf16*>(p.Z2c) + row0 * (size_t)C), 0,
+                                          (unsigned)((size_t)rows_valid * C * 2), 0x00020000) :
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z2c + row0 * (size_t)C), 0, (unsigned)((size_t)rows_valid * C * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t ow[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)        // (H2: two planes of 16-bit elements - the third descriptor is never used)
-        ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + (H2 && q == 2 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
+    for (int q = 0; q < 3; ++q)        // (H2: two planes of 16-bit elements, B16: one - the other descriptors are never used)
+        ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + ((H2 && q == 2) || B16 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
     float osc = 1.f;
     if constexpr (H2) osc = p.osc->scale;
 
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
         const unsigned base = lds_base + (unsigned)(h & 1) * DMF_HALF + (unsigned)wave * 1024u;
         const unsigned add = (unsigned)(((h >> 1) * DMF_COLS) * 128 + (h & 1) * 64) * 2u;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dmf_dma_one(base + (unsigned)q * DMF_PLANE, voff + add, rw[q]);
+        for (int q = 0; q < NPL; ++q) dmf_dma_one(base + (unsigned)q * DMF_PLANE, voff + add, rw[q]);
     };
     // fragment read offsets: tile j, lane (n = l31, hh), 16-k step t of the half: slot = 32 j + n, piece (2 t + hh) ^ ((slot >> 1) & 7)
     // ((slot >> 1) & 7 does not depend on j: tile j is the same lane offset + j * 4096)
@@ -142,7 +156,8 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     for (int j = 0; j < DMF_NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      // half-stage 0 landed (this wave's requests)
+    if constexpr (B16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // half-stage 0 landed (this wave's requests: NPL per half-stage)
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -158,21 +173,28 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
             for (int j = 0; j < DMF_NT; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(S + fo[t] + j * 4096);
-                bm[j] = *reinterpret_cast<const bf16x8*>(S + DMF_PLANE + fo[t] + j * 4096);
-                bl[j] = *reinterpret_cast<const bf16x8*>(S + 2 * DMF_PLANE + fo[t] + j * 4096);
+                if constexpr (!B16) {
+                    bm[j] = *reinterpret_cast<const bf16x8*>(S + DMF_PLANE + fo[t] + j * 4096);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(S + 2 * DMF_PLANE + fo[t] + j * 4096);
+                }
             }
+            if constexpr (B16) {
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[s0 + t], bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bl[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[s0 + t], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bm[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bm[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bm[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM[s0 + t], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bm[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
+            }
         }
     };
     for (int h = 0; h < nhalf; ++h) {
@@ -194,7 +216,12 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {      // all sixteen row loads in flight at once (rows beyond the valid ones: zeros)
                 const unsigned r = (unsigned)(wr0 + (e & 3) + 8 * (e >> 2) + 4 * hh);
-                zz[e] = __builtin_amdgcn_raw_buffer_load_b64(zw, (r * (unsigned)C + (unsigned)col) * 4u, 0, 0);
+                if constexpr (B16) {            // two bf16 -> two fp32 bit patterns (exact)
+                    const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(zw, (r * (unsigned)C + (unsigned)col) * 2u, 0, 0);
+                    zz[e].x = u << 16; zz[e].y = u & 0xFFFF0000u;
+                } else {
+                    zz[e] = __builtin_amdgcn_raw_buffer_load_b64(zw, (r * (unsigned)C + (unsigned)col) * 4u, 0, 0);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -203,10 +230,16 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                 const float2 z = make_float2(__uint_as_float(zz[e].x), __uint_as_float(zz[e].y));
                 const bool second = rr >= bnd;
                 const float2 pr = second ? prb : pra;
-                const float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
+                float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
+                if constexpr (B16) { g.x = (float)(__bf16)g.x; g.y = (float)(__bf16)g.y; }      // dM as the unfused pair stores it
                 float2 o;
                 o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
-                if constexpr (H2) {
+                if constexpr (B16) {
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    bf16x2_t ph; ph[0] = (__bf16)o.x; ph[1] = (__bf16)o.y;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ph), ow[0], (r * (unsigned)C + (unsigned)col) * 2u, 0, 0);
+                    o.x = (float)ph[0]; o.y = (float)ph[1];                  // the b2 partial sums add what is stored
+                } else if constexpr (H2) {
                     _Float16 h0, l0, h1, l1;
                     split2h(o.x * osc, h0, l0); split2h(o.y * osc, h1, l1);
                     const unsigned ph = (unsigned)h2_keep_sign(h0, o.x) | ((unsigned)h2_keep_sign(h1, o.y) << 16);
@@ -275,11 +308,11 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 // [BT, C] -> planes of dZ2 (plane stride out_plane_stride elements), dpred_pre [BT, C], col_part [BT, C] (may be NULL).
 // Takes C % 64 == 0, 32 <= 1 + N <= 256 and K = 128 (the reference's matching_dense_layer_1 width); -EINVAL otherwise (the caller
 // keeps cham_gemm_f32x3 + cham_mulpred_bwd_p3 / _h2).
-template <bool H2>
+template <int MODE>
 static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
                              const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
                              float* dpred_pre, float* col_part, void* stream) {
-    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || (H2 && !out_scale_rec)) return -CHAM_ERR_ARG;
+    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || (MODE == 1 && !out_scale_rec)) return -CHAM_ERR_ARG;
     const int NC = N + 1;
     if (K != 128 || (C % DMF_COLS) || C <= 0 || NC < 32 || NC > 256 || (lds1 & 3) || lds1 < K || (out_plane_stride & 3) || (w_plane_stride & 7))
         return -CHAM_ERR_ARG;
@@ -291,7 +324,7 @@ static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, 
     p.dpred = dpred_pre; p.b2part = col_part;
     p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
     constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
-    auto k = k_dm_mulpred_fused<H2>;
+    auto k = k_dm_mulpred_fused<MODE>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -306,7 +339,7 @@ static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, 
 extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
                                   const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, float* dpred_pre,
                                   float* col_part, void* stream) {
-    return dm_mulpred_launch<false>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, nullptr, dpred_pre, col_part, stream);
+    return dm_mulpred_launch<0>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, nullptr, dpred_pre, col_part, stream);
 }
 
 // as cham_dm_mulpred_p3 with dZ2 written as TWO fp16 planes x the scale of `out_scale_rec` (an H2Scale record holding a bound of
@@ -314,5 +347,15 @@ extern "C" int cham_dm_mulpred_p3(const float* dS1, int lds1, int K, const void*
 extern "C" int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
                                   const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
                                   float* dpred_pre, float* col_part, void* stream) {
-    return dm_mulpred_launch<true>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream);
+    return dm_mulpred_launch<1>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream);
+}
+
+// The bf16 configuration's twin (BASELINE configs[2]): dS1 [BT*(1+N), K = 128] bf16 (row stride lds1 elements), Ws1b = the bf16 shadow of Ws1
+// [C, K] as stored, Z2c [BT*(1+N), C] bf16, pred [BT, C] fp32 -> dZ2c bf16 [BT*(1+N), C], dpred_pre, col_part (sums of the stored, i.e.
+// bf16-rounded, gradient rows).  Replaces cham_gemm_b16(dS1, Ws1) + cham_mulpred_bwd_b16 (+ the cham_colsum_b16 pass over dZ2c for b2).
+extern "C" int cham_dm_mulpred_b16(const void* dS1, int lds1, int K, const void* Ws1b, const void* Z2c, const float* pred, int C, int BT, int N,
+                                   void* dZ2c, float* dpred_pre, float* col_part, void* stream) {
+    if ((lds1 & 7)) return -CHAM_ERR_ARG;
+    return dm_mulpred_launch<2>(reinterpret_cast<const float*>(dS1), lds1, K, Ws1b, 0, reinterpret_cast<const float*>(Z2c), pred, C, BT, N, dZ2c, 0,
+                                nullptr, dpred_pre, col_part, stream);
 }

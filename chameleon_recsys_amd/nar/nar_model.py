@@ -269,6 +269,9 @@ class NARRuntime:
         # bf16 configuration: the three candidate-row CAR GEMMs on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel) where it takes the
         # shape; the register-staged kernels of csrc/gemm_b16.hip otherwise (tests switch rt.b16_dma off to cover those at the G1 shape)
         self.b16_dma = self.gemm_dtype == 'bf16' and L.C % 256 == 0
+        # ... and the scorer layer-1 dgrad fused with the cand (.) pred / CAR-tanh backward (csrc/dm_fused.hip, MODE 2) where the kernel takes
+        # the shape (1 + N in [32, 256] is checked per step)
+        self.dm_fused_b16 = self.gemm_dtype == 'bf16' and L.entries['Ws1'].shape == (L.C, 128) and L.C % 64 == 0
         if self.p3:
             C_ = L.C
             npl, pdt = (2, torch.float16) if self.h2 else (3, torch.bfloat16)
@@ -618,6 +621,7 @@ class StepPlan:
         if b16:       # clicked-input rows stay fp32 (they feed / come from the fp32 recurrent branch); candidate rows are bf16
             self.Z1, self.Z2, self.dZ2, self.dZ1 = f32(BT, C), f32(BT, C), f32(BT, C), f32(BT, C)
             self.Z1c, self.Z2c, self.dZ2c, self.dZ1c, self.Mc = bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C), bf(Rc, C)
+            self.b2part = f32(BT, C)
         else:         # one [BT + Rc, C] matrix each: clicked-input rows first (Z1c ... are views taken per step: BT = valid positions)
             # With the plane-resident CAR GEMMs the candidate rows of Z1 exist as planes only, and with the fused scorer dgrad those of
             # dZ2 too: the fp32 matrices keep the clicked-input rows (ensure_rows() grows them on the paths that do need all rows -
@@ -941,8 +945,9 @@ class NARModuleModel:
                                      self.negative_sample_from_buffer, ptr(o['neg_ids']), ptr(o['neg_slot']), ptr(o['pool']),
                                      ptr(o['canon']), ptr(o['meta']), ptr(pl.sampler_ws), pl.ws_bytes, stream), "cham_neg_sample")
 
-    def presample(self, d):
-        """Draw the negatives of the NEXT training step now.  Sampling depends on the recent-clicks state and the batch's ids,
+    def presample(self, d, step=None):
+        """Draw the negatives of the NEXT training step now (step: its sampler key; default = the current global step, i.e. the call comes
+        between two steps - a call from INSIDE a step, train_step's mid_step hook, passes global_step + 1).  Sampling depends on the recent-clicks state and the batch's ids,
         not on the weights, so it can run on the device state's stream right behind the state update of the current batch,
         while the current step's backward is still executing (0.3 ms of latency-bound kernels off the head of every step).
         ``d`` = the uploaded next batch; forward() picks the result up when the batch and the sampler key match."""
@@ -951,7 +956,7 @@ class NARModuleModel:
                 and self._dev_state is not None and self._dev_state.get('device')):
             return False
         pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
-        k, step = 1 - pl._samp_cur, rt.global_step
+        k, step = 1 - pl._samp_cur, (rt.global_step if step is None else step)
         state.stream.wait_event(pl.created)
         state.stream.wait_event(d['uploaded'])
         d['aci'].record_stream(state.stream)
@@ -1169,8 +1174,13 @@ class NARModuleModel:
         return pl
 
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
-    def backward(self):
-        """Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
+    def backward(self, mid_step=None):
+        """mid_step: callable run on the host right after the step's LAST read of the recent-clicks state has been enqueued (the softmax
+        backward; everything behind it depends on the weights and the batch only).  A training loop passes the state update of THIS batch and
+        the staging / negative sampling of the NEXT one here: on short steps (ragged batches, a strong-scaling shard) the host otherwise
+        reaches them only after enqueuing the whole backward, and the sampler - 0.3-0.5 ms of latency-bound kernels over the GLOBAL batch -
+        lands at the head of the next step instead of under this one (profiles/r04_notes.md).
+        Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
         PreCAR combine -> features); SIDE carries everything that only produces weight gradients - wgrad GEMMs,
         bias column sums - plus the session-FC / recurrent chain and the clicked-row CAR dgrad, so the HBM-bound elementwise
         kernels of one lane run beside the MFMA-bound GEMMs of the other (DESIGN.md "Step schedule").  Every cross-lane
@@ -1222,6 +1232,8 @@ class NARModuleModel:
             ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
         if self._dev_state.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
+        if mid_step is not None:
+            mid_step()
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
         # matrix work that then runs beside the HBM-bound k_mulpred_bwd instead of beside the MFMA-bound CAR dgrad - and the small
         # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it
@@ -1243,7 +1255,10 @@ class NARModuleModel:
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
         # scorer layer-1 dgrad + cand (.) pred backward in one kernel (csrc/dm_fused.hip): dM never reaches HBM
         dm_fused = use_p3 and rt.dm_fused and 32 <= NC <= 256
-        if b16:
+        dm_fused_b16 = b16 and rt.dm_fused_b16 and 32 <= NC <= 256
+        if dm_fused_b16:
+            pass
+        elif b16:
             rt.gemm_b16(pl.dS1, 128, 0, sh['Ws1'], 128, 1, dZ2c, C, 0, Rc, C, 128)
         elif not dm_fused:
             rt.gemm(pl.dS1, p('Ws1'), dZ2c, Rc, C, 128, 128, 128, C, transB=1)
@@ -1292,6 +1307,17 @@ class NARModuleModel:
                 e1.record()
                 prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=False,
                                  dmf=True, h2out=bool(h2), tile=0, epi=0, ev=(e0, e1)))
+        elif dm_fused_b16:      # bf16 configuration: the same fusion over single bf16 matrices (dM rounded to bf16 where the pair stores it)
+            prof = rt.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.cham_dm_mulpred_b16(ptr(pl.dS1), 128, 128, ptr(sh['Ws1']), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(dZ2c), ptr(pl.dpred),
+                                          ptr(pl.b2part), s), "cham_dm_mulpred_b16")
+            if prof is not None:
+                e1.record()
+                prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=True,
+                                 dmf=True, tile=0, epi=0, ev=(e0, e1)))
         elif h2:          # gradient at the CAR tanh straight into two fp16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_h2(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part),
                                           ptr(pl.sc_dz2), s), "cham_mulpred_bwd_h2")
@@ -1390,7 +1416,10 @@ class NARModuleModel:
                         # ... and the CAR layer-2 weight gradient: the candidate rows (bf16, TN) + the clicked-input rows (fp32), runs beside it
                         rt.gemm_b16(pl.Z1c, C, 1, dZ2c, C, 0, g('W2'), C, 1, C, C, Rc, splits=0, dma=rt.b16_dma)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
-                        rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
+                        if dm_fused_b16:      # the per-position sums of the stored gradient rows, written by the fused kernel
+                            rt.colsum(pl.b2part, C, BT, C, g('b2'))
+                        else:
+                            rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
                     elif use_p3:
                         # ... and the CAR layer-2 weight gradient: the candidate rows from their planes (TN, split-K), the clicked-input
@@ -1530,22 +1559,27 @@ class NARModuleModel:
         self.total_loss = rt.loss_acc
         return self.total_loss
 
-    def stage_next(self, dataset):
+    def stage_next(self, dataset, mid_step=False):
         """Training-loop hook (estimator.Estimator.train): upload the batch AFTER the current one and draw its negatives now
-        (presample), so that neither the H2D copies nor the sampler sit at the head of the next step."""
-        self._staged = None
+        (presample), so that neither the H2D copies nor the sampler sit at the head of the next step.  mid_step: called from inside the
+        current step (train_step's mid_step hook, after this batch's state update): the sampler key is the NEXT global step."""
         state = self.articles_recent_pop_norm
         if not (self.rt.presample and self.is_training and getattr(state, 'is_device', False)):
+            self._staged = None
             return
         nxt = dataset.peek()
         if nxt is None:
+            self._staged = None
             return
+        staged = getattr(self, '_staged', None)
+        if staged is not None and staged[0] is nxt[0]['item_clicked']:
+            return                        # already staged (by this step's mid_step hook)
         d = self.upload_batch(nxt[0], nxt[1])
-        self.presample(d)
+        self.presample(d, step=self.rt.global_step + 1 if mid_step else None)
         self._staged = (nxt[0]['item_clicked'], d)
 
-    def train_step(self, device_batch=None):
-        """One optimizer step on the current batch (the reference's ``session.run(model.train)``)."""
+    def train_step(self, device_batch=None, mid_step=None):
+        """One optimizer step on the current batch (the reference's ``session.run(model.train)``).  mid_step: see backward()."""
         d = device_batch
         if d is None:
             staged, self._staged = getattr(self, '_staged', None), None
@@ -1556,7 +1590,9 @@ class NARModuleModel:
         pl = self.forward(d)
         if self.eval_cold_start:       # nar_model.py:520: the ranked candidates are also needed while TRAINING for the cold-start analysis
             self._rank_items(pl, d)
-        self.backward()
+        if mid_step is None:
+            mid_step = getattr(self, '_mid_step', None)       # installed by Estimator.train for the duration of a run
+        self.backward(mid_step)
         self.apply_gradients()
         return self.total_loss
 
@@ -1676,6 +1712,17 @@ class ItemsStateUpdaterHook:
                 feed_dict[m.ph_articles_metadata[name]] = self.articles_metadata[name]
         return SessionRunArgs(fetches=fetches, feed_dict=feed_dict)
 
+    def early_state_update(self):
+        """The device-resident state update of the CURRENT batch (nar_model.py:1635-1649), issued from inside the step right behind its
+        last read of the state (NARModuleModel.backward's mid_step hook) instead of from after_run; TRAIN mode without the cold-start
+        analysis only (that one reads the ranked candidates in after_run first).  Returns True if it ran."""
+        if self.mode != ModeKeys.TRAIN or self.eval_cold_start or not getattr(self.clicked_items_state, 'is_device', False):
+            return False
+        d = self.model._d
+        self.clicked_items_state.update_from_device_batch(d['aci'], d['g_event_ts'])
+        self._state_updated_early = True
+        return True
+
     def after_run(self, run_context, run_values):
         r = run_values.results
         clicked_items = r['clicked_items']
@@ -1721,6 +1768,9 @@ class ItemsStateUpdaterHook:
             self.update_items_cold_start_state(r['user_id'], clicked_items, next_item_labels, r['eval_batch_negative_items'],
                                                r['predicted_item_ids'])
         # state update, nar_model.py:1635-1649
+        if getattr(self, '_state_updated_early', False):               # done inside the step (early_state_update)
+            self._state_updated_early = False
+            return
         if getattr(self.clicked_items_state, 'is_device', False):     # straight from the batch tensors already in HBM
             d = self.model._d
             self.clicked_items_state.update_from_device_batch(d['aci'], d['g_event_ts'])

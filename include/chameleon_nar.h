@@ -205,6 +205,11 @@ int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, in
 int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c, const float* pred,
                        int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec, float* dpred_pre,
                        float* col_part, void* stream);
+/* the bf16 configuration's twin (BASELINE configs[2]): every matrix a single bf16 array (dS1 [BT*(1+N), K] row stride lds1 ELEMENTS, Ws1b = the
+ * bf16 shadow of Ws1 [C, K] as stored, Z2c and the output dZ2c [BT*(1+N), C]); replaces cham_gemm_b16(dS1, Ws1) + cham_mulpred_bwd_b16 and,
+ * through col_part (sums of the STORED, bf16-rounded rows), the cham_colsum_b16 pass of the b2 gradient.  Same shape limits. */
+int cham_dm_mulpred_b16(const void* dS1, int lds1, int K, const void* Ws1b, const void* Z2c, const float* pred, int C, int BT, int N, void* dZ2c,
+                        float* dpred_pre, float* col_part, void* stream);
 
 /* producers of plane-resident matrices (csrc/scorer.hip): the candidate rows of the PreCAR output leaky(U[b,t] + V[item])
  * (nar_model.py:356-405) and the gradient at the CAR tanh (autodiff of nar_model.py:478-495: dM * pred * (1 - Z2^2)) written as three

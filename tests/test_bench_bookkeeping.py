@@ -20,7 +20,7 @@ def test_rebuilt_gemm_symbols_are_the_names_rocprof_lists():
     names = _stats_names()
     base = dict(transA=0, transB=1, rowscale=False, bf16=False, tile=0)
     recs = [dict(base, h2=True, epi=3), dict(base, h2=True, epi=2), dict(base, h2=True, epi=6, transA=1, transB=0),
-            dict(base, dmf=True, h2out=True, epi=0),
+            dict(base, dmf=True, h2out=True, epi=0),          # -> k_dm_mulpred_fused<1>
             dict(base, x3=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue)
             dict(base, x3=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient
             dict(base, x3=True, tile=0, epi=6, transA=1, transB=0)]

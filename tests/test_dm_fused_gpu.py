@@ -84,3 +84,45 @@ def test_dm_fused_argument_errors(gpu):
     assert call(128, 96, 50) < 0         # C % 64
     assert call(128, 64, 10) < 0         # 1 + N < 32
     assert call(128, 64, 300) < 0        # 1 + N > 256
+
+
+@pytest.mark.parametrize("BT,N,C", [(40, 50, 1024), (7, 50, 256), (23, 100, 1024), (9, 200, 1024), (16, 31, 128), (1, 50, 64)])
+def test_dm_fused_bf16_twin_matches_the_unfused_pair(gpu, BT, N, C):
+    """BASELINE configs[2] arithmetic: the all-bf16 form (cham_dm_mulpred_b16) against the two kernels it replaces on the same bf16 operands
+    (cham_gemm_b16 NT with bf16 output + cham_mulpred_bwd_b16, then cham_colsum_b16 for b2): dM is rounded to bf16 exactly where the pair
+    stores it, so the bf16 gradient matrix is BIT-identical; the per-position sums differ by fp32 summation order only."""
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    NC = N + 1
+    Rc = BT * NC
+    g = torch.Generator(device=gpu).manual_seed(BT + N)
+    dS1 = (torch.randn(Rc, 128, device=gpu, generator=g)).bfloat16()
+    Ws1 = (torch.randn(C, 128, device=gpu, generator=g) * 0.1).bfloat16()
+    Z2 = torch.tanh(torch.randn(Rc, C, device=gpu, generator=g)).bfloat16()
+    pred = torch.tanh(torch.randn(BT, C, device=gpu, generator=g))
+    st = torch.cuda.current_stream().cuda_stream
+    # unfused pair
+    dZ = torch.empty(Rc, C, dtype=torch.bfloat16, device=gpu)
+    check(lib.cham_gemm_b16(ptr(dS1), 128, 0, ptr(Ws1), 128, 1, ptr(dZ), C, 0, Rc, C, 128, None, 0, None, 0, 0, 0, None, 0, 1, st), "gemm_b16")
+    dpred_ref = torch.empty(BT, C, device=gpu)
+    check(lib.cham_mulpred_bwd_b16(ptr(dZ), ptr(Z2), ptr(pred), C, BT, N, ptr(dpred_ref), st), "mulpred_b16")
+    torch.cuda.synchronize()
+    b2_ref = dZ.float().view(BT, NC, C).double().sum(1)
+    # fused
+    outs = []
+    for _ in range(2):
+        o = torch.full((Rc, C), float('nan'), dtype=torch.bfloat16, device=gpu)
+        dp = torch.full((BT, C), float('nan'), device=gpu); b2 = torch.full((BT, C), float('nan'), device=gpu)
+        check(lib.cham_dm_mulpred_b16(ptr(dS1), 128, 128, ptr(Ws1), ptr(Z2), ptr(pred), C, BT, N, ptr(o), ptr(dp), ptr(b2), st), "dm_b16")
+        torch.cuda.synchronize()
+        outs.append((o, dp, b2))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    o, dp, b2 = outs[0]
+    same = (o.view(torch.int16) == dZ.view(torch.int16)).float().mean().item()
+    # (accumulation order inside the K = 128 product differs between the two kernels: a sum that lands on the other side of a bf16
+    # rounding boundary moves an element by one bf16 ulp - rare)
+    assert same > 0.995, same
+    assert float((o.float() - dZ.float()).abs().max()) <= 2.0 ** -7 * float(dZ.float().abs().max())
+    assert float((dp.double() - dpred_ref.double()).abs().max()) < 2e-3 * float(dpred_ref.abs().max())
+    assert float((b2.double() - b2_ref).abs().max()) < 2e-3 * float(b2_ref.abs().max()) + 1e-6
