@@ -439,12 +439,9 @@ def main():
         k = i % n_distinct
         if args.state == "device":
             model.feed_state(state, state)                                                              # hook.before_run
-
-            def mid_step():      # what Estimator.train installs: this batch's state update (the hook's) + the next batch's negatives,
-                #                  enqueued right behind the step's last read of the state (nar_model.backward)
-                state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])
-                model.presample(dev_batches[(k + 1) % n_distinct], step=rt.global_step + 1)
-            model.train_step(dev_batches[k], mid_step=mid_step)
+            model.train_step(dev_batches[k])
+            state.update_from_device_batch(dev_batches[k]['aci'], dev_batches[k]['g_event_ts'])        # hook.after_run
+            model.presample(dev_batches[(k + 1) % n_distinct])        # next batch's negatives behind the state update
         else:
             model.feed_state(state.get_articles_recent_pop_norm(), state.get_recent_clicks_buffer())
             model.train_step(dev_batches[k])
@@ -575,11 +572,9 @@ def main():
         def ragged_step(i):
             k = i % n_distinct
             model.feed_state(state, state)
-
-            def mid_step():
-                state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
-                model.presample(rdev[(k + 1) % n_distinct], step=rt.global_step + 1)
-            model.train_step(rdev[k], mid_step=mid_step)
+            model.train_step(rdev[k])
+            state.update_from_device_batch(rdev[k]['aci'], rdev[k]['g_event_ts'])
+            model.presample(rdev[(k + 1) % n_distinct])
         for i in range(max(n_distinct, args.warmup)):        # every distinct padded length T allocates its StepPlan once
             ragged_step(i)
         barrier()

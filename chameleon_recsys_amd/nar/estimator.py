@@ -218,15 +218,6 @@ class Estimator:
             h.begin()
         n, t0 = 0, time.time()
         last_log, log_every = 0, self.config.log_step_count_steps
-        # inside every step, right behind its last read of the recent-clicks state: this batch's state update (the hooks that can do it
-        # early) and the staging + negative sampling of the next batch - so that they run under the step's backward also when the step is
-        # short (nar_model.NARModuleModel.backward, mid_step)
-        early = [h for h in all_hooks if hasattr(h, 'early_state_update')]
-        if hasattr(model, 'stage_next') and early:
-            def mid_step():
-                if all([h.early_state_update() for h in early]):
-                    model.stage_next(ds, mid_step=True)
-            model._mid_step = mid_step
         while (steps is None or n < steps) and (max_steps is None or self.global_step < max_steps) and not ctx.stop_requested:
             if not ds.advance():
                 break
@@ -243,8 +234,6 @@ class Estimator:
             if self.config.save_checkpoints_secs and self._checkpoint_due():
                 self.save_checkpoint()
         torch.cuda.synchronize()
-        if hasattr(model, '_mid_step'):
-            model._mid_step = None
         if n:
             self.steps_per_sec = n / max(1e-9, time.time() - t0)
         for h in all_hooks:

@@ -945,9 +945,8 @@ class NARModuleModel:
                                      self.negative_sample_from_buffer, ptr(o['neg_ids']), ptr(o['neg_slot']), ptr(o['pool']),
                                      ptr(o['canon']), ptr(o['meta']), ptr(pl.sampler_ws), pl.ws_bytes, stream), "cham_neg_sample")
 
-    def presample(self, d, step=None):
-        """Draw the negatives of the NEXT training step now (step: its sampler key; default = the current global step, i.e. the call comes
-        between two steps - a call from INSIDE a step, train_step's mid_step hook, passes global_step + 1).  Sampling depends on the recent-clicks state and the batch's ids,
+    def presample(self, d):
+        """Draw the negatives of the NEXT training step now.  Sampling depends on the recent-clicks state and the batch's ids,
         not on the weights, so it can run on the device state's stream right behind the state update of the current batch,
         while the current step's backward is still executing (0.3 ms of latency-bound kernels off the head of every step).
         ``d`` = the uploaded next batch; forward() picks the result up when the batch and the sampler key match."""
@@ -956,7 +955,7 @@ class NARModuleModel:
                 and self._dev_state is not None and self._dev_state.get('device')):
             return False
         pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
-        k, step = 1 - pl._samp_cur, (rt.global_step if step is None else step)
+        k, step = 1 - pl._samp_cur, rt.global_step
         state.stream.wait_event(pl.created)
         state.stream.wait_event(d['uploaded'])
         d['aci'].record_stream(state.stream)
@@ -1174,13 +1173,8 @@ class NARModuleModel:
         return pl
 
     # ------------------------------------------------------------------ backward (hand-derived; nar_model.py:718)
-    def backward(self, mid_step=None):
-        """mid_step: callable run on the host right after the step's LAST read of the recent-clicks state has been enqueued (the softmax
-        backward; everything behind it depends on the weights and the batch only).  A training loop passes the state update of THIS batch and
-        the staging / negative sampling of the NEXT one here: on short steps (ragged batches, a strong-scaling shard) the host otherwise
-        reaches them only after enqueuing the whole backward, and the sampler - 0.3-0.5 ms of latency-bound kernels over the GLOBAL batch -
-        lands at the head of the next step instead of under this one (profiles/r04_notes.md).
-        Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
+    def backward(self):
+        """Hand-derived backward in two stream lanes.  MAIN carries the critical dgrad chain (softmax -> scorer -> CAR layer 2 ->
         PreCAR combine -> features); SIDE carries everything that only produces weight gradients - wgrad GEMMs,
         bias column sums - plus the session-FC / recurrent chain and the clicked-row CAR dgrad, so the HBM-bound elementwise
         kernels of one lane run beside the MFMA-bound GEMMs of the other (DESIGN.md "Step schedule").  Every cross-lane
@@ -1232,8 +1226,6 @@ class NARModuleModel:
             ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
         if self._dev_state.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
-        if mid_step is not None:
-            mid_step()
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
         # matrix work that then runs beside the HBM-bound k_mulpred_bwd instead of beside the MFMA-bound CAR dgrad - and the small
         # (HBM-bound, split-K) weight / bias gradients of layers 2-4 after it
@@ -1559,27 +1551,22 @@ class NARModuleModel:
         self.total_loss = rt.loss_acc
         return self.total_loss
 
-    def stage_next(self, dataset, mid_step=False):
+    def stage_next(self, dataset):
         """Training-loop hook (estimator.Estimator.train): upload the batch AFTER the current one and draw its negatives now
-        (presample), so that neither the H2D copies nor the sampler sit at the head of the next step.  mid_step: called from inside the
-        current step (train_step's mid_step hook, after this batch's state update): the sampler key is the NEXT global step."""
+        (presample), so that neither the H2D copies nor the sampler sit at the head of the next step."""
+        self._staged = None
         state = self.articles_recent_pop_norm
         if not (self.rt.presample and self.is_training and getattr(state, 'is_device', False)):
-            self._staged = None
             return
         nxt = dataset.peek()
         if nxt is None:
-            self._staged = None
             return
-        staged = getattr(self, '_staged', None)
-        if staged is not None and staged[0] is nxt[0]['item_clicked']:
-            return                        # already staged (by this step's mid_step hook)
         d = self.upload_batch(nxt[0], nxt[1])
-        self.presample(d, step=self.rt.global_step + 1 if mid_step else None)
+        self.presample(d)
         self._staged = (nxt[0]['item_clicked'], d)
 
-    def train_step(self, device_batch=None, mid_step=None):
-        """One optimizer step on the current batch (the reference's ``session.run(model.train)``).  mid_step: see backward()."""
+    def train_step(self, device_batch=None):
+        """One optimizer step on the current batch (the reference's ``session.run(model.train)``)."""
         d = device_batch
         if d is None:
             staged, self._staged = getattr(self, '_staged', None), None
@@ -1590,9 +1577,7 @@ class NARModuleModel:
         pl = self.forward(d)
         if self.eval_cold_start:       # nar_model.py:520: the ranked candidates are also needed while TRAINING for the cold-start analysis
             self._rank_items(pl, d)
-        if mid_step is None:
-            mid_step = getattr(self, '_mid_step', None)       # installed by Estimator.train for the duration of a run
-        self.backward(mid_step)
+        self.backward()
         self.apply_gradients()
         return self.total_loss
 
@@ -1712,17 +1697,6 @@ class ItemsStateUpdaterHook:
                 feed_dict[m.ph_articles_metadata[name]] = self.articles_metadata[name]
         return SessionRunArgs(fetches=fetches, feed_dict=feed_dict)
 
-    def early_state_update(self):
-        """The device-resident state update of the CURRENT batch (nar_model.py:1635-1649), issued from inside the step right behind its
-        last read of the state (NARModuleModel.backward's mid_step hook) instead of from after_run; TRAIN mode without the cold-start
-        analysis only (that one reads the ranked candidates in after_run first).  Returns True if it ran."""
-        if self.mode != ModeKeys.TRAIN or self.eval_cold_start or not getattr(self.clicked_items_state, 'is_device', False):
-            return False
-        d = self.model._d
-        self.clicked_items_state.update_from_device_batch(d['aci'], d['g_event_ts'])
-        self._state_updated_early = True
-        return True
-
     def after_run(self, run_context, run_values):
         r = run_values.results
         clicked_items = r['clicked_items']
@@ -1768,9 +1742,6 @@ class ItemsStateUpdaterHook:
             self.update_items_cold_start_state(r['user_id'], clicked_items, next_item_labels, r['eval_batch_negative_items'],
                                                r['predicted_item_ids'])
         # state update, nar_model.py:1635-1649
-        if getattr(self, '_state_updated_early', False):               # done inside the step (early_state_update)
-            self._state_updated_early = False
-            return
         if getattr(self.clicked_items_state, 'is_device', False):     # straight from the batch tensors already in HBM
             d = self.model._d
             self.clicked_items_state.update_from_device_batch(d['aci'], d['g_event_ts'])

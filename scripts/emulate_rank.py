@@ -42,11 +42,9 @@ def run(world, steps=20, warmup=6, seed=42, strong=False):
     def step(i):
         k = i % 8
         model.feed_state(state, state)
-
-        def mid_step():      # as Estimator.train: state update + next batch's negatives right behind the step's last read of the state
-            state.update_from_device_batch(dev[k]['aci'], dev[k]['g_event_ts'])
-            model.presample(dev[(k + 1) % 8], step=rt.global_step + 1)
-        model.train_step(dev[k], mid_step=mid_step)
+        model.train_step(dev[k])
+        state.update_from_device_batch(dev[k]['aci'], dev[k]['g_event_ts'])
+        model.presample(dev[(k + 1) % 8])
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
