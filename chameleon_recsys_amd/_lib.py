@@ -26,7 +26,7 @@ _SIGNATURES = {
     "cham_emb_grad_scan": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "cham_group_rows_workspace_bytes": (c_size_t, [c_int]),
     "cham_group_rows_segments_len": (c_size_t, [c_int]),
-    "cham_group_rows": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+    "cham_group_rows": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
     "cham_emb_grad_grouped": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "cham_dropout": (c_int, [P, P, c_long, c_int, c_int, c_float, c_uint32, c_uint32, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "cham_dense_rows": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),

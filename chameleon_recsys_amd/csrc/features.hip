@@ -283,33 +283,90 @@ __global__ __launch_bounds__(1024) void k_emb_grad_scan(const float* __restrict_
     }
 }
 
-// (b) the trainable item-embedding table (46 k ... 5 M rows, <= a few 10 k of them touched per step): the item rows are ranked by
-//     (id, row) - rank = number of smaller keys, counted against LDS tiles of the key list: O(R^2 / chip) integer compares, a few
-//     microseconds for R ~ 10^4 and independent of the gradients, so it runs in the forward pass - which makes equal ids
-//     contiguous in `perm`; one workgroup per segment adds its rows (4 waves take every 4th member, ascending; wave sums in
-//     wave order) and STORES the table row: distinct segments = distinct table rows.
-#define RANK_KEY(id, r) (((unsigned long long)(id) << 20) | (unsigned long long)(r))
-__global__ __launch_bounds__(256) void k_rank_keys(const int64_t* __restrict__ ids, int R, int span, int* __restrict__ rank) {
-    __shared__ unsigned long long tile[1024];
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long key = r < R ? RANK_KEY(ids[r], r) : ~0ull;
-    const int j0 = blockIdx.y * span, j1 = min(R, j0 + span);
-    int cnt = 0;
-    for (int t0 = j0; t0 < j1; t0 += 1024) {
+// (b) the trainable item-embedding table (46 k ... 5 M rows, <= a few 10 k of them touched per step): the item rows are SORTED by
+//     (id, row) - a stable least-significant-digit radix sort of the 32-bit ids, 8 bits per pass, ceil(key_bits / 8) passes; integer
+//     work that depends on the ids only, so it runs in the forward pass - which makes equal ids contiguous in `perm`, their rows in
+//     ascending order; one wave / workgroup per segment then adds its rows in that order and STORES the table row (distinct segments =
+//     distinct table rows): deterministic, no float atomics.  (Rounds 1-3 ranked every key against every other key - O(R^2) compares
+//     and a 2^20-row limit; the sort is O(R) per pass and has no limit but memory.)
+//     One pass = k_rs_hist (per-workgroup digit histogram of its tile of RS_TILE keys) -> k_rs_scan (exclusive scan over [digit][workgroup])
+//     -> k_rs_scatter: a workgroup walks its tile in rounds of 256 consecutive keys; a key's position = scanned base of its digit +
+//     the digit's count in earlier rounds + in earlier waves of this round + among the lower lanes of its wave (equal-digit lane mask
+//     from eight ballots) - ascending input order within a digit, i.e. stable.
+#define RS_TILE 2048
+__global__ __launch_bounds__(256) void k_rs_hist(const unsigned* __restrict__ keys, const int64_t* __restrict__ ids, int R, int shift, int nb,
+                                                 int* __restrict__ hist /*[256][nb]*/) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int t0 = blockIdx.x * RS_TILE;
+    for (int q = 0; q < RS_TILE / 256; ++q) {
+        const int i = t0 + q * 256 + threadIdx.x;
+        if (i < R) atomicAdd(&h[((keys ? keys[i] : (unsigned)ids[i]) >> shift) & 255u], 1);       // integer: order independent
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_rs_scan(int* __restrict__ hist, int n) {       // exclusive scan in place, one workgroup
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? hist[i] : 0;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
         __syncthreads();
-        for (int q = threadIdx.x; q < 1024; q += 256) {
-            const int j = t0 + q;
-            tile[q] = j < j1 ? RANK_KEY(ids[j], j) : ~0ull;
+        int off = carry_s, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < w) off += wsum[q]; tot += wsum[q]; }
+        if (i < n) hist[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_rs_scatter(const unsigned* __restrict__ keys_in, const int64_t* __restrict__ ids, const int* __restrict__ vals_in,
+                                                    int R, int shift, int nb, const int* __restrict__ hist, unsigned* __restrict__ keys_out,
+                                                    int* __restrict__ vals_out) {
+    __shared__ int base[256], run[256], wc[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    base[tid] = hist[(size_t)tid * nb + blockIdx.x];
+    run[tid] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wc[q][tid] = 0;
+    __syncthreads();
+    const int t0 = blockIdx.x * RS_TILE;
+    for (int q = 0; q < RS_TILE / 256; ++q) {
+        const int i = t0 + q * 256 + tid;
+        const bool ok = i < R;
+        const unsigned key = ok ? (keys_in ? keys_in[i] : (unsigned)ids[i]) : 0u;
+        const int val = ok ? (vals_in ? vals_in[i] : i) : 0;
+        const unsigned d = (key >> shift) & 255u;
+        unsigned long long m = __ballot(ok);              // lanes of this wave with the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const int below = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && below == 0) wc[w][d] = __popcll(m);     // the digit's first lane of the wave records the wave's count
+        __syncthreads();
+        if (ok) {
+            int pos = base[d] + run[d] + below;
+            for (int ww = 0; ww < w; ++ww) pos += wc[ww][d];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
         }
         __syncthreads();
-        const int n = min(1024, j1 - t0);
-        for (int q = 0; q < n; ++q) cnt += tile[q] < key;
+        run[tid] += wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];       // thread = digit
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) wc[ww][tid] = 0;
+        __syncthreads();
     }
-    if (r < R && cnt) atomicAdd(rank + r, cnt);           // integer: order independent
-}
-__global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ rank, int R, int* __restrict__ perm) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < R) perm[rank[r]] = r;
 }
 // Segment table of the sorted row list (depends on the ids only: built in the forward pass next to `perm`), int32 words:
 //   seg[0] = number of segments, seg[1] = number of LONG segments (> 32 rows), seg[2] = number of work items of the long segments
@@ -318,14 +375,15 @@ __global__ __launch_bounds__(256) void k_perm_from_rank(const int* __restrict__ 
 // One workgroup, block scans, ascending order everywhere.
 // (Round 2 launched one workgroup per SORTED POSITION, twice, and let the non-heads exit, and a popular article's rows - Zipf ids: the
 // top item holds ~12 % of a micro-batch's 23 k rows at the config-5 size - were summed by ONE workgroup in two stripes of dependent
-// index -> row loads: 1.08 ms for 71 MB.  Now: one wave per short segment; long segments cut into chunks of 128 rows, one workgroup
+// index -> row loads: 1.08 ms for 71 MB.  Now: one wave per short segment; long segments cut into chunks of EMB_CHUNK rows, one workgroup
 // per chunk, the chunk sums added in chunk order.  profiles/r03_notes.md)
-#define EMB_CHUNK 128
+#define EMB_CHUNK 64
 __host__ __device__ inline int seg_nl(int R) { return R / 33 + 2; }                       // capacity of the long-segment list
 __host__ __device__ inline int seg_nw(int R) { return R / 33 + R / EMB_CHUNK + 4; }       // capacity of the work list
 __host__ __device__ inline size_t seg_off_long(int R) { return (size_t)R + 6; }
 __host__ __device__ inline size_t seg_off_work(int R) { return seg_off_long(R) + seg_nl(R); }
-__host__ __device__ inline size_t seg_off_partial(int R) { return (seg_off_work(R) + seg_nl(R) + 1 + 3) & ~(size_t)3; }
+__host__ __device__ inline size_t seg_off_ticket(int R) { return seg_off_work(R) + seg_nl(R) + 1; }     // one arrival counter per long segment
+__host__ __device__ inline size_t seg_off_partial(int R) { return (seg_off_ticket(R) + seg_nl(R) + 3) & ~(size_t)3; }
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* wsum /*[16]*/, int* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int incl = v;
@@ -366,38 +424,56 @@ __global__ __launch_bounds__(1024) void k_seg_table(const int64_t* __restrict__ 
     int ow = block_excl_scan_1024(cw, wsum, &n_work);
     for (int q = k0; q < k1; ++q) {
         const int len = seg_start[q + 1] - seg_start[q];
-        if (len > 32) { long_list[o] = q; work_first[o] = ow; ++o; ow += (len + EMB_CHUNK - 1) / EMB_CHUNK; }
+        if (len > 32) { long_list[o] = q; work_first[o] = ow; seg[seg_off_ticket(R) + o] = 0; ++o; ow += (len + EMB_CHUNK - 1) / EMB_CHUNK; }
     }
     if (tid == 0) { seg[1] = n_long; seg[2] = n_work; work_first[n_long] = n_work; }
 }
-// short segments (<= 32 rows: almost all): one WAVE per segment, lanes over the columns, rows in order, 4 loads in flight
-__global__ __launch_bounds__(256) void k_emb_grad_short(const float* __restrict__ dxs, int R, int F, int c0, int dim,
-                                                        const float* __restrict__ gamma, const int64_t* __restrict__ ids,
-                                                        const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= seg[0]) return;
-    const int start = seg[4 + k], len = seg[4 + k + 1] - start;
-    if (len > 32) return;
-    const int* rows = perm + start;
-    const int64_t id = ids[rows[0]];
-    for (int sub = lane; sub < dim; sub += 64) {
-        float a = 0.f;
-        int m = 0;
-        for (; m + 4 <= len; m += 4) {
-            float x[4];
+// ONE launch (rounds 2-3: three - short segments, chunk sums, chunk-sum totals).  At a few 10 k rows this is not a bandwidth problem
+// but a chain of dependent HBM latencies (the Zipf-hot id of a config-5 micro-batch has ~ 6 000 rows), so every stage keeps 32-64 loads
+// per lane in flight and the long segments come FIRST in the grid:
+//  - workgroups [0, n_long_wg): work item = EMB_CHUNK (64) consecutive sorted rows of one LONG segment (> 32 rows); wave w adds rows
+//    16 w .. 16 w + 15 in order, lanes over the columns (NG groups of 64 columns), all of them in flight; the four wave sums are added in
+//    wave order -> the chunk sum.  A one-chunk segment stores its table row directly; otherwise the chunk sum goes to `partial`, the
+//    workgroup takes a ticket of its segment, and the one that arrives LAST adds the segment's chunk sums (each wave a contiguous
+//    quarter of the chunks in chunk order, then the quarters in wave order - a fixed tree whoever is last: bit-reproducible) and stores
+//    the table row.  Release / acquire at agent scope around the ticket (the chunk sums cross XCDs); the last workgroup re-arms it;
+//  - the rest: short segments (<= 32 rows: almost all), one WAVE per segment, rows in order, 32 / NG rows x NG column groups in flight.
+template <int NG>
+__global__ __launch_bounds__(256) void k_emb_grad_all(const float* __restrict__ dxs, int R, int F, int c0, int dim,
+                                                      const float* __restrict__ gamma, const int64_t* __restrict__ ids,
+                                                      const int* __restrict__ perm, int* seg, float* __restrict__ table_grad, int n_long_wg) {
+    __shared__ float comb[4][64 * NG];
+    __shared__ int last_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= n_long_wg) {
+        const int k = ((int)blockIdx.x - n_long_wg) * 4 + w;
+        if (k >= seg[0]) return;
+        const int start = seg[4 + k], len = seg[4 + k + 1] - start;
+        if (len > 32) return;
+        const int my_row = perm[start + min(lane, len - 1)];       // the segment's rows, one per lane
+        const int64_t id = ids[__shfl(my_row, 0, 64)];
+        constexpr int RF = 32 / NG;
+        float a[NG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = dxs[(size_t)rows[m + u] * F + c0 + sub];
+        for (int j = 0; j < NG; ++j) a[j] = 0.f;
+        for (int m = 0; m < len; m += RF) {
+            float x[RF][NG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a += x[u];
+            for (int u = 0; u < RF; ++u) {
+                const float* src = dxs + (size_t)__shfl(my_row, min(m + u, len - 1), 64) * F + c0;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) x[u][j] = (m + u < len && lane + 64 * j < dim) ? src[lane + 64 * j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RF; ++u)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) a[j] += x[u][j];        // rows in ascending order per column (adding 0.f for the tail is exact)
         }
-        for (; m < len; ++m) a += dxs[(size_t)rows[m] * F + c0 + sub];
-        table_grad[(size_t)id * dim + sub] = a * gamma[c0 + sub];
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (lane + 64 * j < dim) table_grad[(size_t)id * dim + lane + 64 * j] = a[j] * gamma[c0 + lane + 64 * j];
+        return;
     }
-}
-// long segments, pass 1: work item = EMB_CHUNK consecutive sorted rows of one long segment; thread = column, rows in order, 8 in flight
-__global__ __launch_bounds__(256) void k_emb_grad_long_part(const float* __restrict__ dxs, int R, int F, int c0, int dim,
-                                                            const int* __restrict__ perm, int* __restrict__ seg) {
-    __shared__ int rws[EMB_CHUNK];
     const int wid = blockIdx.x;
     if (wid >= seg[2]) return;
     const int* work_first = seg + seg_off_work(R);
@@ -405,39 +481,75 @@ __global__ __launch_bounds__(256) void k_emb_grad_long_part(const float* __restr
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (work_first[mid] <= wid) lo = mid; else hi = mid; }
     const int k = seg[seg_off_long(R) + lo];
     const int start = seg[4 + k], len = seg[4 + k + 1] - start;
-    const int r0 = (wid - work_first[lo]) * EMB_CHUNK, n = min(EMB_CHUNK, len - r0);
-    for (int i = threadIdx.x; i < n; i += 256) rws[i] = perm[start + r0 + i];
-    __syncthreads();
-    float* partial = reinterpret_cast<float*>(seg + seg_off_partial(R)) + (size_t)wid * dim;
-    for (int sub = threadIdx.x; sub < dim; sub += 256) {
-        float a = 0.f;
-        int m = 0;
-        for (; m + 8 <= n; m += 8) {
-            float x[8];
+    const int w0 = work_first[lo], w1 = work_first[lo + 1];
+    const int r0 = (wid - w0) * EMB_CHUNK, n = min(EMB_CHUNK, len - r0);
+    float a[NG];
+    {
+        const int nw = max(0, min(EMB_CHUNK / 4, n - w * (EMB_CHUNK / 4)));         // this wave's rows of the chunk
+        const int my_row = lane < nw ? perm[start + r0 + w * (EMB_CHUNK / 4) + lane] : 0;
+        constexpr int RB = 64 / NG;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = dxs[(size_t)rws[m + u] * F + c0 + sub];
+        for (int j = 0; j < NG; ++j) a[j] = 0.f;
+        for (int m = 0; m < nw; m += RB) {
+            float x[RB][NG];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += x[u];
+            for (int u = 0; u < RB; ++u) {
+                const float* src = dxs + (size_t)__shfl(my_row, min(m + u, nw - 1), 64) * F + c0;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) x[u][j] = (m + u < nw && lane + 64 * j < dim) ? src[lane + 64 * j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) a[j] += x[u][j];
         }
-        for (; m < n; ++m) a += dxs[(size_t)rws[m] * F + c0 + sub];
-        partial[sub] = a;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) comb[w][lane + 64 * j] = a[j];
     }
-}
-// pass 2: the chunk sums of a long segment, in chunk order
-__global__ __launch_bounds__(256) void k_emb_grad_long_final(int R, int dim, int c0, const float* __restrict__ gamma, const int64_t* __restrict__ ids,
-                                                             const int* __restrict__ perm, const int* __restrict__ seg, float* __restrict__ table_grad) {
-    const int q = blockIdx.x;
-    if (q >= seg[1]) return;
-    const int* work_first = seg + seg_off_work(R);
-    const int k = seg[seg_off_long(R) + q];
-    const int64_t id = ids[perm[seg[4 + k]]];
-    const int w0 = work_first[q], w1 = work_first[q + 1];
-    const float* partial = reinterpret_cast<const float*>(seg + seg_off_partial(R));
+    __syncthreads();
+    const bool single = (w1 - w0 == 1);
+    const int64_t id = ids[perm[start]];
+    float* partial = reinterpret_cast<float*>(seg + seg_off_partial(R));
     for (int sub = threadIdx.x; sub < dim; sub += 256) {
-        float t = 0.f;
-        for (int w = w0; w < w1; ++w) t += partial[(size_t)w * dim + sub];
-        table_grad[(size_t)id * dim + sub] = t * gamma[c0 + sub];
+        const float t = ((comb[0][sub] + comb[1][sub]) + comb[2][sub]) + comb[3][sub];
+        if (single) table_grad[(size_t)id * dim + sub] = t * gamma[c0 + sub];
+        else partial[(size_t)wid * dim + sub] = t;
     }
+    if (single) return;
+    __threadfence();                               // release: this workgroup's chunk sum before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* ticket = seg + seg_off_ticket(R) + lo;
+        const int t = atomicAdd(ticket, 1);
+        last_s = (t == w1 - w0 - 1);
+        if (last_s) atomicExch(ticket, 0);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();                               // acquire: the other workgroups' chunk sums
+    {
+        const int per = (w1 - w0 + 3) / 4, c_lo = min(w1, w0 + w * per), c_hi = min(w1, c_lo + per);
+        constexpr int CB = 32 / NG;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) a[j] = 0.f;
+        for (int c = c_lo; c < c_hi; c += CB) {
+            float x[CB][NG];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int j = 0; j < NG; ++j)
+                    x[u][j] = (c + u < c_hi && lane + 64 * j < dim) ? __builtin_nontemporal_load(partial + (size_t)(c + u) * dim + lane + 64 * j) : 0.f;
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) a[j] += x[u][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) comb[w][lane + 64 * j] = a[j];
+    }
+    __syncthreads();
+    for (int sub = threadIdx.x; sub < dim; sub += 256)
+        table_grad[(size_t)id * dim + sub] = (((comb[0][sub] + comb[1][sub]) + comb[2][sub]) + comb[3][sub]) * gamma[c0 + sub];
 }
 
 // occurrence counts of pool slots over the sampled negatives (only used for the empty-buffer first batch,
@@ -577,21 +689,38 @@ extern "C" int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int di
     return CHAM_OK;
 }
 
-extern "C" size_t cham_group_rows_workspace_bytes(int R) { return R > 0 ? (size_t)R * sizeof(int) : 0; }
+// workspace of cham_group_rows: two key arrays + one value array of R words and the [256][workgroups] digit histogram
+static inline size_t rs_words(int R) { return ((size_t)R + 63) & ~(size_t)63; }
+extern "C" size_t cham_group_rows_workspace_bytes(int R) {
+    if (R <= 0) return 0;
+    const size_t nb = ((size_t)R + RS_TILE - 1) / RS_TILE;
+    return (3 * rs_words(R) + 256 * nb) * sizeof(int);
+}
 extern "C" size_t cham_group_rows_segments_len(int R) {      // int32 words of `seg` (the tail holds the chunk sums of the long segments, <= 512 columns)
     return R > 0 ? seg_off_partial(R) + (size_t)seg_nw(R) * 512 : 0;
 }
-extern "C" int cham_group_rows(const int64_t* ids, int R, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!ids || !perm || !seg || !workspace || R <= 0 || R >= (1 << 20) || workspace_bytes < cham_group_rows_workspace_bytes(R))
+// perm = the rows 0 .. R-1 sorted by (ids[row], row) and the segment table of equal ids (k_seg_table).  key_bits: the ids are < 2^key_bits
+// (0 or > 32: 32) - ceil(key_bits / 8) radix passes.  ids must be non-negative and < 2^32.
+extern "C" int cham_group_rows(const int64_t* ids, int R, int key_bits, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (!ids || !perm || !seg || !workspace || R <= 0 || workspace_bytes < cham_group_rows_workspace_bytes(R) || ((uintptr_t)workspace & 15))
         return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int* rank = reinterpret_cast<int*>(workspace);
-    if (hipMemsetAsync(rank, 0, (size_t)R * sizeof(int), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
-    int span = ((R + 31) / 32 + 1023) / 1024 * 1024;       // <= 32 key ranges, whole LDS tiles
-    if (span < 1024) span = 1024;
-    const int ns = (R + span - 1) / span;
-    hipLaunchKernelGGL(k_rank_keys, dim3((R + 255) / 256, ns), dim3(256), 0, st, ids, R, span, rank);
-    hipLaunchKernelGGL(k_perm_from_rank, dim3((R + 255) / 256), dim3(256), 0, st, rank, R, perm);
+    if (key_bits <= 0 || key_bits > 32) key_bits = 32;
+    const int passes = (key_bits + 7) / 8;
+    const int nb = (R + RS_TILE - 1) / RS_TILE;
+    unsigned* kbuf[2] = {reinterpret_cast<unsigned*>(workspace), reinterpret_cast<unsigned*>(workspace) + rs_words(R)};
+    int* vws = reinterpret_cast<int*>(workspace) + 2 * rs_words(R);
+    int* hist = reinterpret_cast<int*>(workspace) + 3 * rs_words(R);
+    for (int p = 0; p < passes; ++p) {
+        // values ping-pong between the workspace and `perm` so that the LAST pass writes `perm`
+        int* vout = ((passes - 1 - p) & 1) ? vws : perm;
+        const int* vin = p == 0 ? nullptr : (((passes - p) & 1) ? vws : perm);
+        const unsigned* kin = p == 0 ? nullptr : kbuf[(p - 1) & 1];
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, st, kin, ids, R, 8 * p, nb, hist);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, hist, 256 * nb);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, st, kin, ids, vin, R, 8 * p, nb, hist, kbuf[p & 1], vout);
+    }
     hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(1024), 0, st, ids, perm, R, seg);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -601,9 +730,13 @@ extern "C" int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int
                                      const int32_t* perm, const int32_t* seg, float* table_grad, void* stream) {
     if (!dxs || !gamma || !ids || !perm || !seg || !table_grad || R <= 0 || F <= 0 || c0 < 0 || dim <= 0 || dim > 512 || c0 + dim > F)
         return -CHAM_ERR_ARG;
-    hipLaunchKernelGGL(k_emb_grad_short, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm, seg, table_grad);
-    hipLaunchKernelGGL(k_emb_grad_long_part, dim3(seg_nw(R)), dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, perm, const_cast<int32_t*>(seg));
-    hipLaunchKernelGGL(k_emb_grad_long_final, dim3(seg_nl(R)), dim3(256), 0, (hipStream_t)stream, R, dim, c0, gamma, ids, perm, seg, table_grad);
+    const dim3 grid(seg_nw(R) + (R + 3) / 4);
+    if (dim <= 256)
+        hipLaunchKernelGGL(k_emb_grad_all<4>, grid, dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm,
+                           const_cast<int32_t*>(seg), table_grad, seg_nw(R));
+    else
+        hipLaunchKernelGGL(k_emb_grad_all<8>, grid, dim3(256), 0, (hipStream_t)stream, dxs, R, F, c0, dim, gamma, ids, perm,
+                           const_cast<int32_t*>(seg), table_grad, seg_nw(R));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -134,7 +134,7 @@ class Estimator:
             self._store['runtime'].load_state_dict(sd)
 
     def save_checkpoint(self):
-        """Checkpoint of the runtime in model_dir.  Under data parallelism state_dict() is a COLLECTIVE in the sharded / hybrid modes (it
+        """Checkpoint of the runtime in model_dir.  Under data parallelism state_dict() is a COLLECTIVE in the sharded mode (it
         all-gathers the Adam slots their owner ranks hold): every rank calls it at the same step (see _checkpoint_due), rank 0 alone
         writes the file."""
         p = self._ckpt_path()
@@ -149,7 +149,7 @@ class Estimator:
 
     def _checkpoint_due(self):
         """save_checkpoints_secs elapsed?  A per-rank wall-clock decision would let ranks enter save_checkpoint() - a collective under the
-        sharded / hybrid exchange modes - at different steps (hang, or a gather paired with the next step's reduce-scatter): with an active
+        sharded exchange mode - at different steps (hang, or a gather paired with the next step's reduce-scatter): with an active
         data-parallel group rank 0 decides and broadcasts."""
         secs = self.config.save_checkpoints_secs
         due = bool(secs) and time.time() - self._last_ckpt_time > secs

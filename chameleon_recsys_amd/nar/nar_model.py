@@ -165,6 +165,7 @@ class NARRuntime:
         self.n_items = acfg['article_id'].get('cardinality', ace.shape[0]) if 'article_id' in acfg else ace.shape[0]
         if self.n_items != ace.shape[0]:
             raise ValueError("article_id cardinality (%d) != ACE rows (%d)" % (self.n_items, ace.shape[0]))
+        self.item_id_bits = max(1, int(self.n_items - 1).bit_length())      # radix passes of the row grouping (cham_group_rows)
         self.layout = ParamLayout(params['session_features_config'], acfg, self.n_items, ace.shape[1],
                                   params['CAR_embedding_size'], params['rnn_units'],
                                   params.get('rnn_num_layers', 1), params.get('rnn_cell', 'ugrnn'),
@@ -347,7 +348,7 @@ class NARRuntime:
         self._shadow_key = key
 
     def state_dict(self):
-        """Weights + Adam slots + step.  Under the sharded / hybrid data-parallel modes a rank only maintains the slots of the
+        """Weights + Adam slots + step.  Under the sharded data-parallel mode a rank only maintains the slots of the
         parameter slice it owns: they are all-gathered first (a COLLECTIVE - every rank must call state_dict()), so that any
         rank's checkpoint resumes the same optimizer trajectory in any mode (the mode is recorded)."""
         m, v = self.m, self.v
@@ -609,7 +610,7 @@ class StepPlan:
         self.w_rows = f32(RV)
         self.perm = torch.zeros(RV, dtype=torch.int32, device=dev)          # item rows grouped by id (cham_group_rows)
         self.seg = torch.zeros(int(rt.lib.cham_group_rows_segments_len(RV)), dtype=torch.int32, device=dev)      # its segment table
-        self.group_ws = torch.zeros(RV, dtype=torch.int32, device=dev)
+        self.group_ws = torch.zeros(int(rt.lib.cham_group_rows_workspace_bytes(RV)) // 4, dtype=torch.int32, device=dev)
         self.Xc_raw, self.Xc_s, self.dXc = f32(BT, Fc), f32(BT, Fc), f32(BT, Fc)
         self.Xi_raw, self.Xi_s, self.dXi = f32(RV, Fi), f32(RV, Fi), f32(RV, Fi)
         # CAR
@@ -1020,10 +1021,8 @@ class NARModuleModel:
         pl.ref_ts[:BT].copy_(d['ets_rows'])
         pl.ref_ts[BT:RV].fill_(d['max_ts'])
         if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
-            if RV >= (1 << 20):
-                raise ValueError("%d item rows in one step (2 * positions + candidate pool + 1): the row grouping of the embedding gradient takes "
-                                 "fewer than 2^20 - process the batch with train_step_microbatched(features, labels, micro_sessions)" % RV)
-            check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s), "cham_group_rows")
+            check(lib.cham_group_rows(ptr(pl.ids_all), RV, rt.item_id_bits, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s),
+                  "cham_group_rows")
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
         if st['n_last'] > 0 and st.get('device'):

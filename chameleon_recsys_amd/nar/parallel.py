@@ -6,8 +6,8 @@ pool (nar_model.py:1286-1300), max_event_timestamp (:235), the normalisation sta
 sum(mask) (:664) are computed redundantly and identically; each rank runs sampling / features / CAR / RNN / scorer
 for its own rows only (negative sampling is keyed by the GLOBAL row index, so the result does not depend on the
 sharding), and the flat gradient buffer is summed with ONE all-reduce per step (dense grads ~12 MB + the small
-embedding tables; CHAM_DP_MODE=hybrid reduce-scatters the embedding-table region to owner ranks instead, =sharded the
-whole buffer - see DataParallelNAR).  The state update after the step is applied identically on every rank from the
+embedding tables; CHAM_DP_MODE=sharded reduce-scatters the whole buffer to owner ranks instead, =sparse / sparse_rs exchange only
+the touched rows of the item table - see DataParallelNAR).  The state update after the step is applied identically on every rank from the
 replicated ids - no communication.
 """
 import numpy as np
@@ -36,10 +36,9 @@ class DataParallelNAR:
     mode "sharded" (env CHAM_DP_MODE=sharded; the large-catalog layout): reduce-scatter of the flat gradients, each rank runs
     TF-Adam on its contiguous 1/world slice of (weights, m, v) - the embedding tables are >90 % of it - and the updated
     slices are all-gathered.  Same result bit for bit (Adam is elementwise); optimizer HBM traffic per rank / world.
-    mode "hybrid" (SURVEY.md 8e, C1 + C2): all-reduce of the dense (CAR / RNN / FC / scorer) gradients with the full dense
-    Adam on every rank, and for the trainable EMBEDDING TABLES reduce-scatter of their gradient region to the owning rank,
-    owner-side Adam, all-gather of the updated table slices.  (The tables' gradient is dense - the L2 term touches every
-    row, nar_model.py:740/917 - so the exchange is a dense reduce-scatter of the region, not a row-id list.)
+    (Rounds 1-3 also had "hybrid" = all-reduce of the dense gradients + a DENSE reduce-scatter of the embedding-table region to owner
+    ranks: at config 5 that is the whole 7.5 GB table per step where "sparse_rs" moves the touched rows - removed in round 4, SURVEY.md
+    8e's C1 + C2 is "sparse_rs".)
     mode "sparse" (large catalogs, BASELINE config 5): the trainable ITEM table's data gradient only touches the rows of the
     global batch's clicked ids + the candidate pool + the pad item - a list every rank derives identically from the replicated
     integers, so no index exchange is needed: every rank packs those rows (duplicates allowed) into a compact [L, dim] buffer,
@@ -60,8 +59,8 @@ class DataParallelNAR:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.mode = mode or os.environ.get("CHAM_DP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "sharded", "hybrid", "sparse", "sparse_rs"):
-            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'hybrid', 'sparse' or 'sparse_rs'")
+        if self.mode not in ("allreduce", "sharded", "sparse", "sparse_rs"):
+            raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'sparse' or 'sparse_rs'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
         rt.dp_mode = self.mode
@@ -91,12 +90,6 @@ class DataParallelNAR:
                     raise ValueError("flat parameter buffer (%d) does not split over %d ranks" % (rt.flat.numel(), self.world))
                 rt.dp_sharded = self._sharded_step
                 self._grad_slice = torch.empty(rt.flat.numel() // self.world, dtype=rt.flat.dtype, device=rt.flat.device)
-            elif self.mode == "hybrid":
-                # sharded prefix of the embedding region: whole float4 groups per rank; the (< world*64 element) remainder of
-                # the region rides with the dense all-reduce
-                self.emb_sharded = (rt.layout.emb_end // (self.world * 64)) * (self.world * 64)
-                rt.dp_sharded = self._hybrid_step
-                self._grad_slice = torch.empty(max(1, self.emb_sharded // self.world), dtype=rt.flat.dtype, device=rt.flat.device)
             elif self.mode in ("sparse", "sparse_rs") and 'items_embedding' in rt.layout.entries:
                 e = rt.layout.entries['items_embedding']
                 self._item = (e.offset, e.shape[0], e.shape[1])
@@ -191,14 +184,12 @@ class DataParallelNAR:
         # duplicate ids carry identical sums: concurrent writes of the same value
         check(rt.lib.cham_rows_scatter(ptr(rows), ptr(ids), L, dim, ptr(table), st), "cham_rows_scatter")
 
-    # ---- checkpoints: in the sharded / hybrid modes a rank's Adam slots are only valid on its own slice
+    # ---- checkpoints: in the sharded mode a rank's Adam slots are only valid on its own slice
     def _gather_slots(self, m, v):
         """Full (m, v) on every rank, for NARRuntime.state_dict(): the owned slices all-gathered (no-op in the replicated modes)."""
         if not self.active or self.mode in ("allreduce", "sparse", "sparse_rs"):
             return m, v
-        total = m.numel()
-        E = total if self.mode == "sharded" else self.emb_sharded
-        n = E // self.world
+        n = m.numel() // self.world
         a = self.rank * n
         out = []
         for x in (m, v):
@@ -227,29 +218,6 @@ class DataParallelNAR:
                 flat_params[r * n:(r + 1) * n].copy_(t)
         else:
             dist.all_gather_into_tensor(flat_params, flat_params[a:a + n].clone(), group=self.pg)
-
-    def _hybrid_step(self, flat_grads, flat_params, adam):
-        E, total = self.emb_sharded, flat_params.numel()
-        n = E // self.world
-        a = self.rank * n
-        gloo = dist.get_backend(self.pg) == "gloo"
-        dist.all_reduce(flat_grads[E:], op=dist.ReduceOp.SUM, group=self.pg)                     # C1: dense gradients
-        if n > 0:                                                                                 # C2: embedding tables
-            if gloo:
-                dist.all_reduce(flat_grads[:E], op=dist.ReduceOp.SUM, group=self.pg)
-                self._grad_slice.copy_(flat_grads[a:a + n])
-            else:
-                dist.reduce_scatter_tensor(self._grad_slice, flat_grads[:E], op=dist.ReduceOp.SUM, group=self.pg)
-            adam(a, a + n, self._grad_slice, 0)
-        adam(E, total, flat_grads, E)
-        if n > 0:
-            if gloo:
-                parts = [torch.empty_like(self._grad_slice) for _ in range(self.world)]
-                dist.all_gather(parts, flat_params[a:a + n].clone(), group=self.pg)
-                for r, t in enumerate(parts):
-                    flat_params[r * n:(r + 1) * n].copy_(t)
-            else:
-                dist.all_gather_into_tensor(flat_params[:E], flat_params[a:a + n].clone(), group=self.pg)
 
     def upload(self, global_features, global_labels):
         n = np.asarray(global_features['item_clicked']).shape[0]

@@ -86,17 +86,19 @@ int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* d
  * the caller zeroes the embedding-gradient region first).
  *  - cham_emb_grad_scan: small tables (context / metadata embeddings), one workgroup per table row scanning the R source keys;
  *    key(r) = keysrc[r] (ids == NULL) or keysrc[ids[r]] (article metadata of item rows);
- *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows ranks the rows by (id, row) (depends on the
+ *  - cham_group_rows + cham_emb_grad_grouped: the item-embedding table; cham_group_rows sorts the rows by (id, row) - a stable 8-bit
+ *    LSD radix sort, ceil(key_bits / 8) passes, ids < 2^key_bits (0: 32 bits), workspace of cham_group_rows_workspace_bytes(R) - (depends on the
  *    ids only - run it in the forward pass), perm[i] = row with the i-th smallest key, and builds the segment table `seg`
- *    (cham_group_rows_segments_len(R) int32 words: number of segments, of segments longer than 32 rows and of their 128-row chunks,
+ *    (cham_group_rows_segments_len(R) int32 words: number of segments, of segments longer than 32 rows and of their 64-row chunks,
  *    first sorted position of every segment, the indices of the long ones, their first chunk, scratch for the chunk sums - the buffer
  *    is written by cham_emb_grad_grouped too); cham_emb_grad_grouped then runs one wave per short segment, one workgroup per 128-row
- *    chunk of a long one and adds the chunk sums in chunk order; rows in ascending order throughout; ids >= 0, R < 2^20, dim <= 512. */
+ *    chunk of a long one and adds the chunk sums in chunk order; rows in ascending order throughout; 0 <= ids < 2^32, dim <= 512. */
 int cham_emb_grad_scan(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* keysrc,
                        const int64_t* ids, int cardinality, float* table_grad, void* stream);
 size_t cham_group_rows_workspace_bytes(int R);
 size_t cham_group_rows_segments_len(int R);
-int cham_group_rows(const int64_t* ids, int R, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes, void* stream);
+int cham_group_rows(const int64_t* ids, int R, int key_bits, int32_t* perm, int32_t* seg, void* workspace, size_t workspace_bytes,
+                    void* stream);
 int cham_emb_grad_grouped(const float* dxs, int R, int F, int c0, int dim, const float* gamma, const int64_t* ids,
                           const int32_t* perm, const int32_t* seg, float* table_grad, void* stream);
 

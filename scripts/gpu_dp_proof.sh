@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp PYTHONPATH=$R CHAM_DIST_BACKEND=gloo
 : > $O/dp_proof_$T.jsonl
-for cfg in "allreduce weak" "sparse weak" "allreduce strong" "sparse strong" "hybrid weak"; do
+for cfg in "allreduce weak" "sparse weak" "allreduce strong" "sparse strong" "sparse_rs weak"; do
   set -- $cfg
   CHAM_DP_MODE=$1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 8 --steps 4 --warmup 2 --no-cpu-baseline --no-boundary-leg --no-ragged-leg --scaling $2 2>&1 | grep '^{' | python -c "

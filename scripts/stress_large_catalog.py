@@ -98,7 +98,7 @@ def main():
                                                          ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
                                                          ptr(pg), ptr(pb), ptr(pl.Xi_raw), ptr(pl.Xi_s), s_), "elementwise"))
     grp = [g for g in rt.item_emb_groups if g[0] == 5][0]          # (kind, feat, c0, dim, rows, offset) of the item-embedding table
-    ms_group = timed(lambda: check(lib.cham_group_rows(ptr(pl.ids_all), RV, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s_), "group"))
+    ms_group = timed(lambda: check(lib.cham_group_rows(ptr(pl.ids_all), RV, rt.item_id_bits, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s_), "group"))
     ms_scatter = timed(lambda: check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, grp[2], grp[3], ptr(pg), ptr(pl.ids_all), ptr(pl.perm), ptr(pl.seg),
                                                                rt.grads.data_ptr() + 4 * grp[5], s_), "grouped"))
     scatter_bytes = RV * 4.0 * grp[3] * 2                           # read the rows' embedding-gradient columns, write one table row per distinct id (<= RV)
@@ -115,8 +115,8 @@ def main():
                item_rows_per_micro_batch=int(RV),
                gather_lds_tiles=dict(kernel="k_item_assemble_lds (ACE / embedding rows -> LDS tile -> 16-byte row stores, raw + scaled)", **roof(gather_bytes, ms_lds)),
                gather_one_thread_per_element=dict(kernel="k_item_assemble (round-1 form)", **roof(gather_bytes, ms_elem)),
-               embedding_gradient=dict(kernel="k_rank_keys + k_perm_from_rank + k_seg_table (%.3f ms: integer ranking of the rows by id and the segment table, forward pass) + "
-                                              "k_emb_grad_short / k_emb_grad_long (one wave per short segment, one workgroup per long one; deterministic, no float atomics)" % ms_group, **roof(scatter_bytes, ms_scatter)))
+               embedding_gradient=dict(kernel="k_rs_hist / k_rs_scan / k_rs_scatter x passes + k_seg_table (%.3f ms: stable radix sort of the rows by id and the segment table, forward pass) + "
+                                              "k_emb_grad_all (ONE launch: one wave per short segment, one workgroup per 64-row chunk of a long one, the last-arriving chunk adds the chunk sums in chunk order; deterministic, no float atomics)" % ms_group, **roof(scatter_bytes, ms_scatter)))
     print(json.dumps(out), flush=True)
 
 

@@ -27,7 +27,7 @@ def _params(**over):
 def _assert_shadows_fresh(rt):
     """The weight shadows the candidate-row GEMMs read (bf16 copies / fp16 plane pairs of W2) are images of the CURRENT fp32 master
     weights after refresh_shadows() - also when the weights were last written by a collective (broadcast at start-up, all-gather after the
-    sharded / hybrid Adam) rather than by this rank's own Adam kernel."""
+    sharded Adam) rather than by this rank's own Adam kernel."""
     rt.refresh_shadows()
     if rt.b16:
         for name in ('W2', 'Ws1'):
@@ -60,8 +60,8 @@ def _run(dp_world, rank, batches, p, mode=None):
         losses.append(dp.global_loss().cpu().numpy())
         st.update_from_device_batch(d['aci'], d['g_event_ts'])
     torch.cuda.synchronize()
-    sd = model.rt.state_dict()        # checkpoint image: a collective in the sharded / hybrid modes (gathers the Adam slots)
-    return (np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy(), getattr(dp, 'emb_sharded', model.rt.layout.emb_end),
+    sd = model.rt.state_dict()        # checkpoint image: a collective in the sharded modes (gathers the Adam slots)
+    return (np.stack(losses), model.rt.flat.cpu().numpy(), model.rt.m.cpu().numpy(), model.rt.layout.emb_end,
             sd['m'].numpy(), sd['dp_mode'])
 
 
@@ -77,7 +77,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "sharded", "hybrid", "sparse", "sparse_rs"])
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "sparse", "sparse_rs"])
 def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
@@ -88,10 +88,6 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
     if mode == "sharded":       # Adam slots live on the rank that owns the parameter slice
         assert not r0['m'][n:].any() and not r1['m'][:n].any()
         m_dp = np.concatenate([r0['m'][:n], r1['m'][n:]])
-    elif mode == "hybrid":      # embedding-table slots on the owning rank, dense slots replicated
-        E = int(r0['E']); h = E // 2
-        assert E > 0 and not r0['m'][h:E].any() and not r1['m'][:h].any() and np.array_equal(r0['m'][E:], r1['m'][E:])
-        m_dp = np.concatenate([r0['m'][:h], r1['m'][h:E], r0['m'][E:]])
     else:
         assert np.array_equal(r0['m'], r1['m'])
         m_dp = r0['m']
@@ -109,7 +105,7 @@ def test_two_rank_hip_training_equals_single_process(gpu, tmp_path, mode):
 
 # ---- BASELINE configs[2] as written: bf16 AND data parallel (and the fp32 default with its plane shadows of W2) ------------------------
 ARITH = [("f32", 256), ("bf16", 256)]          # C = 256: the plane-resident CAR GEMMs (fp32) / the LDS-DMA bf16 core are active, weight shadows in use
-MODES = ["allreduce", "sharded", "hybrid", "sparse", "sparse_rs"]
+MODES = ["allreduce", "sharded", "sparse", "sparse_rs"]
 
 
 def _worker_arith(rank, world, port, out_dir):
@@ -131,7 +127,7 @@ def _worker_arith(rank, world, port, out_dir):
 
 
 def test_two_rank_training_in_every_arithmetic_and_exchange_mode(gpu, tmp_path):
-    """gemm_dtype x exchange mode: the bf16 configuration (bf16 weight shadows, refreshed per weight version - in the sharded / hybrid
+    """gemm_dtype x exchange mode: the bf16 configuration (bf16 weight shadows, refreshed per weight version - in the sharded
     modes the weights are REWRITTEN by an all-gather after Adam) and the fp32 default at a width where the W2 plane shadows are in use,
     two ranks, three optimizer steps: replicas bit-identical, equal to the single-process run of the same arithmetic."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -13,12 +13,14 @@ def _s():
 
 
 @pytest.mark.parametrize("R,n_items,dim,F,c0", [(10729, 46000, 117, 408, 288), (3000, 500, 44, 112, 8), (70, 1000, 256, 260, 4),
-                                                (23457, 5000000, 16, 96, 0), (4000, 3000, 378, 520, 140)])
+                                                (23457, 5000000, 16, 96, 0), (4000, 3000, 378, 520, 140),
+                                                (1300021, 5000000, 16, 24, 4)])        # more rows than rounds 1-3 could group (2^20)
 def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
     lib = _lib.load()
     rng = np.random.default_rng(R)
+    key_bits = 0 if R == 70 else int(n_items - 1).bit_length()        # 0: all 32 bits of the ids are sorted
     ids = np.minimum(rng.zipf(1.2, size=R) * 7919 % n_items, n_items - 1).astype(np.int64)
     ids[rng.random(R) < 0.05] = 0                                   # the padding item is a real table row too
     dxs = rng.standard_normal((R, F)).astype(np.float32)
@@ -31,11 +33,11 @@ def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     perm = torch.full((R,), -1, dtype=torch.int32, device=gpu)
     ws = torch.zeros(lib.cham_group_rows_workspace_bytes(R) // 4, dtype=torch.int32, device=gpu)
     seg = torch.full((int(lib.cham_group_rows_segments_len(R)),), -7, dtype=torch.int32, device=gpu)
-    check(lib.cham_group_rows(ptr(d_ids), R, ptr(perm), ptr(seg), ptr(ws), ws.numel() * 4, _s()), "cham_group_rows")
+    check(lib.cham_group_rows(ptr(d_ids), R, key_bits, ptr(perm), ptr(seg), ptr(ws), ws.numel() * 4, _s()), "cham_group_rows")
     torch.cuda.synchronize()
     pm = perm.cpu().numpy()
     assert np.array_equal(np.sort(pm), np.arange(R)), "perm is not a permutation"
-    key = ids[pm] * (1 << 20) + pm
+    key = ids[pm] * (1 << 24) + pm
     assert (np.diff(key) > 0).all(), "rows are not sorted by (id, row)"
     # segment table: heads of the runs of equal ids in sorted order, the long ones listed
     sg = seg.cpu().numpy()
@@ -45,7 +47,7 @@ def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     lens = np.diff(np.r_[heads, R])
     longs = np.flatnonzero(lens > 32)
     assert sg[1] == len(longs) and np.array_equal(sg[R + 6:R + 6 + len(longs)], longs)
-    chunks = (lens[longs] + 127) // 128                              # work items: 128-row chunks of the long segments
+    chunks = (lens[longs] + 63) // 64                                # work items: 64-row chunks of the long segments
     wf = R + 6 + R // 33 + 2
     assert sg[2] == chunks.sum() and np.array_equal(sg[wf:wf + len(longs) + 1], np.r_[0, np.cumsum(chunks)])
     outs = []
