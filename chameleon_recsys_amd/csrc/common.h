@@ -20,7 +20,7 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_TANH = 2 };
 
 // ln of the two smoothing-log bases of the item features (nar_model.py:122-123 elapsed_days_smooth_log_base, popularity_smooth_log_base;
 // log_base :28-34), launch scalars of the kernels that use them; set by cham_set_log_bases (csrc/features.hip), defaults 1.3 / 2.0.
-extern float g_cham_ln_elapsed_base, g_cham_ln_pop_base, g_cham_inv_log2_pop_base;      // (the last: 1 / log2(base), exactly 1 for base 2)
+extern thread_local float g_cham_ln_elapsed_base, g_cham_ln_pop_base, g_cham_inv_log2_pop_base;      // per host thread; (the last: 1 / log2(base), exactly 1 for base 2)
 
 // tanh for the GEMM epilogues: branch-free, ~17 VALU (the libdevice tanhf is ~45 with divergent range branches; VALU issue
 // slots are MFMA issue slots, the tanh epilogue cost 8 % of the CAR layer-2 GEMM).  |x| < 0.625: odd minimax polynomial

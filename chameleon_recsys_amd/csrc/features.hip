@@ -21,7 +21,7 @@ enum { COL_ZERO = 0, COL_OHE = 1, COL_EMB = 2, COL_NUM = 3, COL_ACE = 4, COL_ITE
 // descriptor = 5 x int64: kind, feat, sub, dim, param_offset
 #define DESC_W 5
 
-float g_cham_ln_elapsed_base = logf(1.3f), g_cham_ln_pop_base = logf(2.0f), g_cham_inv_log2_pop_base = 1.0f;
+thread_local float g_cham_ln_elapsed_base = logf(1.3f), g_cham_ln_pop_base = logf(2.0f), g_cham_inv_log2_pop_base = 1.0f;
 extern "C" int cham_set_log_bases(float elapsed_days_smooth_log_base, float popularity_smooth_log_base) {
     if (!(elapsed_days_smooth_log_base > 0.f) || elapsed_days_smooth_log_base == 1.f || !(popularity_smooth_log_base > 0.f) ||
         popularity_smooth_log_base == 1.f)

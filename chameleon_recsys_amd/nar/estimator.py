@@ -150,17 +150,25 @@ class Estimator:
     def _checkpoint_due(self):
         """save_checkpoints_secs elapsed?  A per-rank wall-clock decision would let ranks enter save_checkpoint() - a collective under the
         sharded exchange mode - at different steps (hang, or a gather paired with the next step's reduce-scatter): with an active
-        data-parallel group rank 0 decides and broadcasts."""
+        data-parallel group its first rank decides and broadcasts - on the data-parallel process group, and only every
+        CKPT_DECISION_EVERY steps (every rank counts the same steps): the broadcast + read-back is a host-device synchronisation, which
+        every step would undo the enqueue-ahead of the training loop."""
         secs = self.config.save_checkpoints_secs
         due = bool(secs) and time.time() - self._last_ckpt_time > secs
         rt = self._store.get('runtime')
         if rt is not None and getattr(rt, 'dp_active', False):
             import torch.distributed as dist
             if dist.is_initialized():
-                flag = torch.tensor([1 if due else 0], dtype=torch.int32, device=rt.device if dist.get_backend() == "nccl" else "cpu")
-                dist.broadcast(flag, src=0)
+                self._ckpt_poll = getattr(self, '_ckpt_poll', 0) + 1
+                if self._ckpt_poll % self.CKPT_DECISION_EVERY:
+                    return False
+                pg = getattr(rt, 'dp_pg', None)
+                flag = torch.tensor([1 if due else 0], dtype=torch.int32, device=rt.device if dist.get_backend(pg) == "nccl" else "cpu")
+                dist.broadcast(flag, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
                 due = bool(int(flag.item()))
         return due
+
+    CKPT_DECISION_EVERY = 50
 
     def get_variable_value(self, name):
         """tf.estimator.Estimator.get_variable_value: by the reference graph's TF variable name (layout.tf_variable_names(), ':0' and the

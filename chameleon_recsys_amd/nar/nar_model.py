@@ -190,7 +190,9 @@ class NARRuntime:
         self.x3 = self.gemm_dtype == 'f32' and os.environ.get("CHAM_GEMM_X3", "1") == "1"
         # plane-resident CAR GEMMs (csrc/gemm_p3.hip): the candidate rows of Z1 and dZ2 live in HBM as three bf16 planes written by
         # their producers, W2 / W2^T get plane shadows once per step; same six plane products as gemm_x3.hip.  CHAM_GEMM_P3=0: the
-        # on-the-fly split for those three GEMMs too (A/B arm; also what shapes gemm_p3 does not take fall back to)
+        # on-the-fly split for those three GEMMs too (A/B arm).  The only shape gate is C % 256 == 0 below (decided once, here): any other
+        # argument the plane kernels reject is an error of this module and raises from check() mid-step - loudly, there is no silent
+        # fall-back to another arithmetic
         self.p3 = self.x3 and os.environ.get("CHAM_GEMM_P3", "1") == "1" and self.layout.C % 256 == 0
         # two-fp16-plane form of those three GEMMs (csrc/gemm_h2.hip, round 4): planes (h, l) x a power-of-two scale derived on the device
         # from a bound of the matrix, THREE plane products instead of six - the kernels were power-limited, so halving the MFMA count is
@@ -1180,6 +1182,9 @@ class NARModuleModel:
         dependency is an explicit event; with overlap off the same program order runs on one stream."""
         rt, lib, L = self.rt, self.rt.lib, self.rt.layout
         pl, d = self._plan, self._d
+        # the log bases are host-side values of the library read when a kernel is launched: set again here, another model of this process
+        # (different bases) may have run its forward pass since ours (ADVICE r03)
+        check(lib.cham_set_log_bases(self.elapsed_days_smooth_log_base, self.popularity_smooth_log_base), "cham_set_log_bases")
         s = _stream()
         B, T, N = pl.B, pl.T, pl.N
         pos, BT, BTf, NC, pmax = pl.pos, pl.P, pl.BT, pl.NC, pl.pmax          # see forward(): BT = valid positions

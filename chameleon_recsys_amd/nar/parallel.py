@@ -63,6 +63,7 @@ class DataParallelNAR:
             raise ValueError("CHAM_DP_MODE must be 'allreduce', 'sharded', 'sparse' or 'sparse_rs'")
         rt = model.rt
         rt.dp_rank, rt.dp_world = self.rank, self.world
+        rt.dp_pg = process_group
         rt.dp_mode = self.mode
         self._early, self._early_work, self._early_bytes = None, None, 0
         self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
