@@ -554,9 +554,11 @@ def main():
     traffic, traffic_src = None, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if fn.endswith("_pmc_traffic.json"):     # PMC passes cannot be collected inside the timed bench: committed separately
-            rec = json.load(open(os.path.join(ROOT, "profiles", fn))).get(DOM_SYMBOL)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            rec = pmc.get(DOM_SYMBOL)
             if rec and args.config == "g1" and world == 1 and args.scaling == "weak":
-                traffic, traffic_src = rec["traffic_bytes_per_launch"], "profiles/" + fn
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_src = "profiles/%s (%s)" % (fn, pmc.get("_generated_by", "scripts/pmc_traffic.py"))
             break
 
     # ---- secondary leg: the same step on G1-LIKE session lengths (2 + min(Geometric(0.45), seq_len - 2), mean

@@ -13,17 +13,26 @@ if [ "${SKIP_TESTS:-1}" != "1" ]; then
   ( timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -12; echo "pytest rc ${PIPESTATUS[0]}" ) > $O/pytest_gpu.log
 fi
 ( timeout 200 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3 ) > $O/smoke.log
+cd /tmp
+( timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ragged-leg --no-boundary-leg --no-arms --no-native-arm 2>&1 | tail -2 ) > $O/pmc_fetch.log
+( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ragged-leg --no-boundary-leg --no-arms --no-native-arm 2>&1 | tail -2 ) > $O/pmc_write.log
+cd $R
+PMC_GENERATED_BY=scripts/gpu_final_r04.sh python scripts/pmc_traffic.py $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $O/pmc_write -name '*counter_collection.csv' | head -1) > $O/pmc_traffic.json 2>$O/pmc_traffic.err
+rm -rf $O/pmc_fetch $O/pmc_write
+# the bench below reads the dominant kernel's `traffic` from profiles/*_pmc_traffic.json: this pass's file, so that value, bytes and symbol
+# come from one box and one build
+[ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json
 ( timeout 1500 python bench.py 2>$O/bench.err | grep '^{' | tail -1 ) > $O/bench.json
 cd /tmp
 BARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-ragged-leg --no-boundary-leg --no-arms --no-native-arm"
 ( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python $R/bench.py $BARGS 2>&1 | grep '^{' | tail -1 ) > $O/bench_profiled.json
 cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null
 python $R/scripts/timeline.py $(find $O/prof -name '*kernel_trace.csv' | head -1) k_sel_count_valid full > $O/kernel_trace_step.txt 2>&1
-( timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ragged-leg --no-boundary-leg --no-arms --no-native-arm 2>&1 | tail -2 ) > $O/pmc_fetch.log
-( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ragged-leg --no-boundary-leg --no-arms --no-native-arm 2>&1 | tail -2 ) > $O/pmc_write.log
+rm -rf $O/prof
+( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stress -o stress -- python $R/scripts/stress_large_catalog.py --n-items 1000000 --batch 1024 --neg 200 --micro 512 --steps 2 2>&1 | grep '^{' | tail -1 ) > $O/stress_profiled.json
+cp $(find $O/prof_stress -name '*kernel_stats.csv' | head -1) $O/stress_kernel_stats.csv 2>/dev/null
+rm -rf $O/prof_stress
 cd $R
-python scripts/pmc_traffic.py $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $O/pmc_write -name '*counter_collection.csv' | head -1) > $O/pmc_traffic.json 2>$O/pmc_traffic.err
-rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 bash scripts/h2_pmc.sh > $O/h2_sq_counters.txt 2>&1
 ( timeout 300 python -m tests.bench_gemm_h2 2>&1 | grep -v amdgpu.ids ) > $O/gemm_h2_microbench.txt
 ( timeout 300 python scripts/host_profile.py 200 2>&1 | head -48 ) > $O/host_profile.txt

@@ -6,6 +6,7 @@ usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv 
 import collections
 import csv
 import json
+import os
 import sys
 
 
@@ -23,4 +24,5 @@ out = {}
 for k in f:
     out[k] = dict(dispatches=nf[k], fetch_kb_raw=round(f[k], 1), write_kb=round(w.get(k, 0.0), 1),
                   traffic_bytes_per_launch=round((2 * f[k] + w.get(k, 0.0)) * 1024))
+out["_generated_by"] = "%s: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 2 --warmup 1 --no-arms ...` -> scripts/pmc_traffic.py" % os.environ.get("PMC_GENERATED_BY", "scripts/pmc_traffic.py")
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
