@@ -59,7 +59,7 @@ def test_documented_switch_defaults_match_the_code():
     doc = open(nar_model.__file__.rsplit("/chameleon_recsys_amd/", 1)[0] + "/DESIGN.md").read()
     for name, default in re.findall(r'os\.environ\.get\("(CHAM_[A-Z0-9_]+)",\s*"([^"]*)"\)', src):
         assert name in doc, "%s is not documented in DESIGN.md section 9" % name
-        row = [l for l in doc.splitlines() if l.startswith("| `") and name in l]
+        row = [l for l in doc.splitlines() if l.startswith("| `%s`" % name)]            # the row OF the switch in section 9's table
         assert row, name
         if name in ("CHAM_COMPACT", "CHAM_OVERLAP", "CHAM_PRESAMPLE", "CHAM_GEMM_H2", "CHAM_GEMM_P3"):
             assert "| %s |" % default in row[0], (name, default, row[0])
