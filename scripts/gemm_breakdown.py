@@ -1,5 +1,5 @@
 """Manual tool: per-shape GEMM time inside the G1 full-length training step (HIP events around every cham_gemm_* launch, lanes
-overlapped as in production).  usage: gemm_breakdown.py   (env CHAM_GEMM_TILE_BY_AREA=1 selects the old tile rule)"""
+overlapped as in production).  usage: python scripts/gemm_breakdown.py"""
 import collections
 import os
 import sys

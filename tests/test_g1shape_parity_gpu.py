@@ -12,6 +12,7 @@ tight whatever the luck of the flips: relative L2 error < 1e-4, max error < 2e-4
 the worst tensor, 1e-6 on the CAR kernels, the same for the native fp32 MFMA and the bf16x3 GEMMs)."""
 import ctypes
 import os
+import time
 
 import numpy as np
 import pytest
@@ -340,16 +341,18 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     the default arithmetic's worst deviation so far never exceeds 6 x the native arm's + 1e-3 (measured worst ratio 3.6, final 0.56), and its mean deviation over the 200 steps
     is within 2.5 x the native arm's + 5e-4 (the two arms are two realisations of the same drift; see the comment at the assertion).
     The curve is written to gpurun_out/loss_curve_200.json.
-    Horizon: the 200-step run is committed (profiles/r04_loss_curve_200.json, MI355X, these assertions) and reproduced with
-    CHAM_CURVE_STEPS=200 (8 minutes, almost all of it the CPU oracle); the default here is 120 steps so that the whole `-m gpu` suite stays
-    well inside the driver's 1 200 s - every assertion is on running maxima / means, i.e. holds on any prefix of the committed curve.
+    Horizon: 200 steps (CHAM_CURVE_STEPS), 8 minutes on the GPU box, almost all of it the CPU oracle (2.4 s per step on 32 host threads) -
+    the whole `-m gpu` suite then takes ~830 of the driver's 1 200 s.  Safety valve for a slower host: the curve is time-boxed at
+    CHAM_CURVE_SECONDS (560) and stops early - never before step 100 - instead of running the suite out of its budget; every assertion
+    is on running maxima / means, i.e. holds on any prefix (the full 200-step curve of round 4: profiles/r04_loss_curve_200.json).
     Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric): the
     HIP path, the oracle trained separately, and the oracle evaluating the HIP-trained weights (the eval path alone: must agree to the
     last hit)."""
     from chameleon_recsys_amd.nar import metrics
     from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel
     from oracle.nar_oracle import NAROracle
-    B, STEPS = 64, int(os.environ.get("CHAM_CURVE_STEPS", "120"))
+    B, STEPS = 64, int(os.environ.get("CHAM_CURVE_STEPS", "200"))
+    time_box = float(os.environ.get("CHAM_CURVE_SECONDS", "560"))
     p = _g1_params(B)
     batches = synthetic.make_batches(2 + STEPS + 4, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=21)
     st = H.warm_state(p, batches[:2])
@@ -358,7 +361,12 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     assert model.rt.h2 and not native.rt.x3
     dev = {"default": [], "native": []}
     oracle_loss = []
-    for i, (f, l) in enumerate(batches[2:2 + STEPS]):
+    t_start, TOTAL = time.time(), STEPS
+    for i, (f, l) in enumerate(batches[2:2 + TOTAL]):
+        if i >= 100 and time.time() - t_start > time_box:
+            print("loss curve stopped after %d of %d steps: %.0f s of wall time (CHAM_CURVE_SECONDS)" % (i, STEPS, time.time() - t_start))
+            STEPS = i
+            break
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         ref = orc.train_step(f, l, buf, pop)
         oracle_loss.append(float(ref['total_loss']))
@@ -396,7 +404,7 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
                         CAR_embedding_size=p['CAR_embedding_size'], rnn_units=p['rnn_units'], runtime=model.rt)
     orc_hw = NAROracle(p, weights=model.rt.logical_weights())
     m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "oracle", "oracle_on_hip_weights")}
-    for i, (f, l) in enumerate(batches[2 + STEPS:]):
+    for i, (f, l) in enumerate(batches[2 + TOTAL:]):
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         ev.feed_state(pop, buf); ev.evaluate_step(ev.upload_batch(f, l))
         ids = ev.predicted_item_ids.eval()
@@ -409,7 +417,7 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     hr = {k: float(v[0].result()) for k, v in m.items()}
     mrr = {k: float(v[1].result()) for k, v in m.items()}
     print("HitRate@5 %r MRR@5 %r" % (hr, mrr))
-    n_pos = sum(int((l['label_next_item'] != 0).sum()) for _, l in batches[2 + STEPS:])
+    n_pos = sum(int((l['label_next_item'] != 0).sum()) for _, l in batches[2 + TOTAL:])
     assert abs(hr["hip"] - hr["oracle_on_hip_weights"]) <= 1.5 / n_pos, hr          # same weights: at most one tie broken differently
     assert abs(hr["hip"] - hr["oracle"]) < 0.02 and abs(mrr["hip"] - mrr["oracle"]) < 0.02, (hr, mrr)
 
