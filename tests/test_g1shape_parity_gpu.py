@@ -336,8 +336,9 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     bit-exact at every step on both.
     Loss: two correct fp32 trainers drift apart under Adam (an entry whose gradient is roundoff moves by +-lr per step in either run; a
     leaky-ReLU branch decided differently within an ulp of zero moves a small tensor's gradient by 1e-3) and the drift is chaotic: the
-    NATIVE fp32 MFMA arm is 2.8e-2 away from the oracle at step 148 (measured on MI355X, round 4).  So: 1e-3 for the first 30 steps, 3e-3
-    through step 50, a sanity bound of 0.1 (3 % of the loss) after that - and the statement that matters, on both arms' whole curves:
+    NATIVE fp32 MFMA arm is 2.8e-2 away from the oracle at step 148 (measured on MI355X, round 4).  So: 1e-3 asserted for the first 20 steps
+    (measured to hold for 38-43 steps on either arm in the recorded runs, profiles/r04_loss_curve_*.json), 3e-3 through step 30, 6e-3 through
+    step 50, a sanity bound of 0.1 (3 % of the loss) after that - and the statement that matters, on both arms' whole curves:
     the default arithmetic's worst deviation so far never exceeds 6 x the native arm's + 1e-3 (measured worst ratio 3.6, final 0.56), and its mean deviation over the 200 steps
     is within 2.5 x the native arm's + 5e-4 (the two arms are two realisations of the same drift; see the comment at the assertion).
     The curve is written to gpurun_out/loss_curve_200.json.
@@ -376,7 +377,9 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
             assert np.array_equal(m._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy()), "step %d (%s): negative samples differ" % (i, name)
             d = abs(float(loss[0]) - float(ref['total_loss']))
             dev[name].append(d)
-            bound = LOGIT_TOL if i < 30 else (3 * LOGIT_TOL if i < 50 else 0.1)
+            # the deviation grows ~10 x per 10 steps until it saturates near 1e-2 (both arms, two recorded runs: <= 1.3e-4 before step 20,
+            # <= 8.2e-4 before step 30, <= 1.8e-3 before step 50): bounds with >= 3 x room over those, 1e-3 itself for the first 20 steps
+            bound = LOGIT_TOL if i < 20 else (3 * LOGIT_TOL if i < 30 else (6 * LOGIT_TOL if i < 50 else 0.1))
             assert d < bound, "step %d (%s): loss %r vs oracle %g" % (i, name, loss, float(ref['total_loss']))
         H.update_state(st, f, l)
     w_def, w_nat = max(dev["default"]), max(dev["native"])
