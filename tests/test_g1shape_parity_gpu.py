@@ -428,9 +428,10 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
 def test_loss_curve_50_steps_bf16_g1_shape(gpu):
     """BASELINE configs[2] arithmetic over 50 consecutive optimizer steps (32 sessions of G1-like lengths, state evolving): the HIP bf16
     path free-running against the oracle that emulates the bf16 operand / storage rounding (oracle/nar_oracle.py _BF16MatMul, _StoreBF16)
-    on its own trajectory.  Negatives bit-exact every step; loss within 5e-3 for the first 10 steps and 4e-2 through step 50 (a value that
+    on its own trajectory.  Negatives bit-exact every step; loss within 1.2e-2 for the first 10 steps and 6e-2 (2 % of the loss) through step 50 (a value that
     lands on the other side of a bf16 rounding boundary moves by 2^-8 relative - the two runs are two roundings of the same trajectory,
-    not the same sequence of bits; measured on MI355X: 2.5e-3 at step 10, worst 1.8e-2 at step 39, 2.2e-2 against the FP32 oracle's loss).  Curve -> gpurun_out/loss_curve_bf16_50.json."""
+    not the same sequence of bits; measured on MI355X in three runs of round 4: 2.5e-3 / 3.6e-3 / 4.5e-3 within the first 10 steps, worst
+    1.8e-2 / 2.0e-2 / 2.2e-2 overall - the bounds leave 2.7 x room over those; 2.2e-2 against the FP32 oracle's loss).  Curve -> gpurun_out/loss_curve_bf16_50.json."""
     B, STEPS = 32, 50
     p = _g1_params(B, gemm_dtype='bf16')
     batches = synthetic.make_batches(2 + STEPS, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=23)
@@ -446,7 +447,7 @@ def test_loss_curve_50_steps_bf16_g1_shape(gpu):
         assert np.array_equal(model._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy()), "step %d: negative samples differ" % i
         d = abs(float(loss[0]) - float(ref['total_loss']))
         dev.append(d); ol.append(float(ref['total_loss']))
-        assert d < (5e-3 if i < 10 else 4e-2), "step %d: bf16 loss %r vs the rounding-emulating oracle %g" % (i, loss, float(ref['total_loss']))
+        assert d < (1.2e-2 if i < 10 else 6e-2), "step %d: bf16 loss %r vs the rounding-emulating oracle %g" % (i, loss, float(ref['total_loss']))
         H.update_state(st, f, l)
     print("50-step bf16 loss curve: worst |loss - emulating oracle| %.2e, final loss %.5f" % (max(dev), float(loss[0])))
     _dump_curve("loss_curve_bf16_50.json", dict(batch=B, steps=STEPS, oracle_bf16_loss=ol, abs_dev_vs_bf16_oracle=dev))
