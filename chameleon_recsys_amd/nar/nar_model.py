@@ -323,12 +323,15 @@ class NARRuntime:
         self.flat.copy_(torch.from_numpy(self.layout.pack(logical)))
         self.weights_version += 1
 
+    def shadows_stale(self):
+        return (self.b16 or self.p3) and (self.global_step, self.weights_version) != self._shadow_key
+
     def refresh_shadows(self):
         """bf16 shadows (bf16 configuration) / bf16 plane shadows of W2 (plane-resident CAR GEMMs) of the candidate-row GEMM weights,
         once per weight version (one small launch per weight)."""
-        key = (self.global_step, self.weights_version)
-        if not (self.b16 or self.p3) or key == self._shadow_key:
+        if not self.shadows_stale():
             return
+        key = (self.global_step, self.weights_version)
         if self.h2:
             C = self.layout.C
             check(self.lib.cham_split2h(ptr(self.p('W2')), C, C, C, ptr(self.w2p), C * C, C, ptr(self.w2tp), C * C, C, ptr(self.sc_w2), 1, _stream()),
@@ -982,6 +985,16 @@ class NARModuleModel:
         check(lib.cham_set_log_bases(self.elapsed_days_smooth_log_base, self.popularity_smooth_log_base), "cham_set_log_bases")
         torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
+        # weight shadows (planes of W2 / W2^T, the row-norm bound of Ws1, bf16 shadows): four small launches that depend on the weights only -
+        # on the side lane (idle at the head of a step) behind the previous step's Adam, beside this lane's feature kernels (round 4: the
+        # head of a step is ~35 latency-bound launches in a row on one lane)
+        shadows_ev = None
+        if rt.overlap and rt.shadows_stale():
+            rt.side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(rt.side_stream):
+                rt.refresh_shadows()
+                shadows_ev = torch.cuda.Event()
+                shadows_ev.record()
         # BT = rows of the row-wise stages = the P valid positions (all B*T when nothing is padded); BTf = the [B, T] layout
         pos, BT, BTf, NC, pmax = d['pos'], d['P'], pl.BT, pl.NC, pl.pmax
         pl.pos, pl.P = pos, BT
@@ -1022,9 +1035,20 @@ class NARModuleModel:
             pl.ids_all[2 * BT + pmax:2 * BT + pmax + 1].zero_()      # the pad item row moves with P
         pl.ref_ts[:BT].copy_(d['ets_rows'])
         pl.ref_ts[BT:RV].fill_(d['max_ts'])
+        pl.grouped_ev = None
         if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
-            check(lib.cham_group_rows(ptr(pl.ids_all), RV, rt.item_id_bits, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws), pl.group_ws.numel() * 4, s),
-                  "cham_group_rows")
+            if rt.overlap:        # ~10 launches nobody needs before the end of the backward: on the side lane, behind the id copies above
+                e_ids = torch.cuda.Event()
+                e_ids.record()
+                rt.side_stream.wait_event(e_ids)
+                with torch.cuda.stream(rt.side_stream):
+                    check(lib.cham_group_rows(ptr(pl.ids_all), RV, rt.item_id_bits, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws),
+                                              pl.group_ws.numel() * 4, _stream()), "cham_group_rows")
+                    pl.grouped_ev = torch.cuda.Event()
+                    pl.grouped_ev.record()
+            else:
+                check(lib.cham_group_rows(ptr(pl.ids_all), RV, rt.item_id_bits, ptr(pl.perm), ptr(pl.seg), ptr(pl.group_ws),
+                                          pl.group_ws.numel() * 4, s), "cham_group_rows")
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
         if st['n_last'] > 0 and st.get('device'):
@@ -1055,7 +1079,10 @@ class NARModuleModel:
                                          ptr(pl.rec_raw), ptr(pl.nov_raw), ptr(pl.stats), ptr(rt.item_desc), Fi, ptr(rt.flat),
                                          ptr(p('gamma_item')), ptr(p('beta_item')), ptr(pl.Xi_raw), ptr(pl.Xi_s), s),
                   "cham_item_assemble")
-        rt.refresh_shadows()
+        if shadows_ev is not None:
+            torch.cuda.current_stream().wait_event(shadows_ev)
+        else:
+            rt.refresh_shadows()
         drop = self.is_training and self.keep_prob < 1.0
         pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])
         if drop:
@@ -1496,6 +1523,8 @@ class NARModuleModel:
                                              None, card, rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
             for kind, feat, c0, dim, card, off in rt.item_emb_groups:
                 if kind == COL_ITEMEMB:
+                    if getattr(pl, 'grouped_ev', None) is not None:
+                        torch.cuda.current_stream().wait_event(pl.grouped_ev)
                     check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')), ptr(pl.ids_all), ptr(pl.perm),
                                                     ptr(pl.seg), rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_grouped")
                 else:
