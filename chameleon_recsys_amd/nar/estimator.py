@@ -139,6 +139,7 @@ class Estimator:
         writes the file."""
         p = self._ckpt_path()
         rt = self._store.get('runtime')
+        self._check_device_health()           # never persist weights a failed kernel hand-off may have touched
         if p and rt is not None:
             sd = rt.state_dict()
             if getattr(rt, 'dp_rank', 0) == 0:
@@ -146,6 +147,16 @@ class Estimator:
                 torch.save(sd, tmp)
                 os.replace(tmp, p)
             self._last_ckpt_time = time.time()
+
+    def _check_device_health(self):
+        """The cooperative recurrent kernels (csrc/rnn_coop.hip) hand h_t from workgroup to workgroup with BOUNDED spins; a spin that gave
+        up (a cooperating workgroup never became resident - e.g. several processes' cooperative kernels competing for one GPU) leaves a
+        sticky word in their workspace and wrong hidden states behind.  Checked where the loop synchronises anyway (checkpoints, the end of
+        train / evaluate): fail loudly rather than train on."""
+        rt = self._store.get('runtime')
+        if rt is not None and getattr(rt, '_rnn_coop_ws', None) and rt.rnn_coop_timed_out():
+            raise RuntimeError("a cooperative recurrent kernel (csrc/rnn_coop.hip) gave up a bounded spin: the hidden states of at least one "
+                               "step are invalid.  Is another process running cooperative kernels on this GPU?")
 
     def _checkpoint_due(self):
         """save_checkpoints_secs elapsed?  A per-rank wall-clock decision would let ranks enter save_checkpoint() - a collective under the
@@ -270,6 +281,7 @@ class Estimator:
         for h in all_hooks:
             h.end(None)
         ds.close()
+        self._check_device_health()
         out = {k: (v.result() if hasattr(v, 'result') else v) for k, v in spec.eval_metric_ops.items()}
         out['loss'] = loss_sum / max(1, n)
         out['global_step'] = self.global_step

@@ -14,7 +14,8 @@ def _s():
 
 @pytest.mark.parametrize("R,n_items,dim,F,c0", [(10729, 46000, 117, 408, 288), (3000, 500, 44, 112, 8), (70, 1000, 256, 260, 4),
                                                 (23457, 5000000, 16, 96, 0), (4000, 3000, 378, 520, 140),
-                                                (1300021, 5000000, 16, 24, 4)])        # more rows than rounds 1-3 could group (2^20)
+                                                (1300021, 5000000, 16, 24, 4),         # more rows than rounds 1-3 could group (2^20)
+                                                (2048, 70000, 32, 40, 8), (1, 300, 8, 8, 0), (4097, 2, 12, 16, 4)])   # one full sort tile; one row; two ids
 def test_grouped_item_embedding_gradient(gpu, R, n_items, dim, F, c0):
     from chameleon_recsys_amd import _lib
     from chameleon_recsys_amd._lib import check, ptr
