@@ -179,3 +179,37 @@ def test_exchange_modes_match_single_process_step(tmp_path, mode):
     else:
         E = (_N_EMB // (world * 64)) * (world * 64)
         assert (owned[:E] == 1).all() and (owned[E:] == world).all()                # tables sharded, dense replicated
+
+
+# ---- the checkpoint decision under data parallelism (estimator._checkpoint_due): rank 0's wall clock, broadcast on the data-parallel
+# ---- group every CKPT_DECISION_EVERY steps - every rank takes the same decision at the same step whatever its own clock says
+def _ckpt_worker(rank, world, port, out_dir):
+    import time
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chameleon_recsys_amd.nar.estimator import Estimator, RunConfig
+    est = Estimator(model_fn=None, config=RunConfig(save_checkpoints_secs=1000))
+    pg = dist.new_group(list(range(world)))
+    est._store['runtime'] = types.SimpleNamespace(dp_active=True, dp_pg=pg, device="cpu")
+    every = Estimator.CKPT_DECISION_EVERY
+    decisions = []
+    for step in range(1, 3 * every + 1):
+        if step == every + 1:                 # after the first decision point: rank 0's clock says "due", rank 1's never does
+            est._last_ckpt_time = time.time() - (2000 if rank == 0 else 0)
+        if step == 2 * every + 1:             # ... and the other way round
+            est._last_ckpt_time = time.time() - (0 if rank == 0 else 2000)
+        decisions.append(bool(est._checkpoint_due()))
+    np.save(os.path.join(out_dir, "ckpt_rank%d.npy" % rank), np.asarray(decisions))
+    dist.destroy_process_group()
+
+
+def test_checkpoint_decision_is_rank0s_and_taken_every_k_steps(tmp_path):
+    from chameleon_recsys_amd.nar.estimator import Estimator
+    world, every = 2, Estimator.CKPT_DECISION_EVERY
+    mp.spawn(_ckpt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d0, d1 = (np.load(str(tmp_path / ("ckpt_rank%d.npy" % r))) for r in range(world))
+    assert np.array_equal(d0, d1)                                         # same decision on every rank at every step
+    want = np.zeros(3 * every, bool)
+    want[2 * every - 1] = True                                            # step 2K: rank 0 is due (rank 1's own clock is not)
+    assert np.array_equal(d0, want), np.flatnonzero(d0)                   # step 3K: only rank 1 would be due -> nobody saves
