@@ -242,15 +242,19 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
         gen_s = time.time() - t0
 
         class Clock(SessionRunHook):
-            n, t0, t1, n1 = 0, None, None, 0
+            n, t0, t1, n1, p0, p1 = 0, None, None, 0, 0, 0
+
+            @staticmethod
+            def plans():
+                return getattr(est._store.get('runtime'), 'plans_created', 0)
 
             def after_run(self, ctx, values):
                 self.n += 1
                 if self.n == warm_steps:
-                    torch.cuda.synchronize(); self.t0 = time.perf_counter()
+                    torch.cuda.synchronize(); self.t0 = time.perf_counter(); self.p0 = self.plans()
 
             def end(self, session=None):
-                torch.cuda.synchronize(); self.t1, self.n1 = time.perf_counter(), self.n
+                torch.cuda.synchronize(); self.t1, self.n1, self.p1 = time.perf_counter(), self.n, self.plans()
         clock = Clock()
         est.train(lambda: datasets.prepare_dataset_iterator(files, scfg, batch_size=B, truncate_session_length=cfg['seq_len']),
                   hooks=[clock])
@@ -264,6 +268,9 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
                     session_lengths=length_dist, clicked_items_state=state,
                     path="GZIP TFRecord files -> prepare_dataset_iterator (C++ decode) -> Estimator.train -> model_fn + hooks; host "
                          "batches handed over every step (H2D included)",
+                    # buffer sets (StepPlan) built INSIDE the timed steps: a padded length T seen for the first time after the warm-up allocates
+                    # and zero-fills several GB - tens of ms in a 0.5 s window (a training run amortises it over an epoch; this window does not)
+                    step_plans_created_in_timed_steps=clock.p1 - clock.p0,
                     input_pipeline_alone_sessions_per_s=round(n_in / dt_in, 1), dataset_generation_s=round(gen_s, 1))
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -398,6 +398,7 @@ class NARRuntime:
                 self._plans.pop(next(iter(self._plans)))          # oldest entry (dicts keep insertion order)
             pl = StepPlan(self, B, T, N, n_buf, Bg or B)
             pl.nbytes = pl.allocated_bytes()                       # what the eviction above counts for the plans already cached
+            self.plans_created = getattr(self, 'plans_created', 0) + 1      # (bookkeeping: a first-seen padded length costs GBs of allocation)
         self._plans[key] = pl                                      # (re)insert as most recently used
         return pl
 
