@@ -697,11 +697,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)
-        if world > 1:
-            dist.barrier()
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)          # C stdio buffers (RCCL banner) leave through the redirected descriptor
+    # every rank drains its (redirected) stdout - the RCCL banner is C stdio - and meets at a barrier BEFORE rank 0 prints the one JSON line.
+    # (Round 3 had this barrier inside the rank-0 block: the other ranks went straight to destroy_process_group and rank 0's barrier
+    # failed with "connection closed by peer" - caught in round 4 by running the launch contract with 4 and 8 gloo ranks on one GPU,
+    # profiles/r04_dp_proof_gloo_one_gpu.jsonl; tests/test_bench_bookkeeping.py now checks that no collective sits under `if rank == 0`.)
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)

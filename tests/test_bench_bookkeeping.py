@@ -45,3 +45,29 @@ def test_pack_offsets_layout():
     assert offs == dict(a=0, b=256, c=512, d=512) and total == 1024
     for k, a in arrs.items():
         assert offs[k] % 256 == 0 and offs[k] + a.nbytes <= total
+
+
+def test_no_collective_under_a_rank0_branch_of_bench():
+    """bench.py under torchrun: a collective that only rank 0 reaches deadlocks or - once the other ranks have left - fails with
+    'connection closed by peer' (round 3's final barrier sat inside `if rank == 0`; no N > 1 run existed to catch it)."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    collectives = {"barrier", "all_reduce", "broadcast", "all_gather", "reduce_scatter_tensor", "all_gather_into_tensor", "reduce", "gather"}
+    bad = []
+
+    def walk(node, under_rank0):
+        if isinstance(node, ast.If):
+            r0 = ast.unparse(node.test).replace(" ", "") == "rank==0"
+            for n in node.body:
+                walk(n, under_rank0 or r0)
+            for n in node.orelse:
+                walk(n, under_rank0)
+            return
+        if isinstance(node, ast.Call) and under_rank0:
+            f = ast.unparse(node.func)
+            if f.startswith("dist.") and f.split(".")[1] in collectives:
+                bad.append((node.lineno, f))
+        for n in ast.iter_child_nodes(node):
+            walk(n, under_rank0)
+    walk(tree, False)
+    assert not bad, bad
