@@ -82,7 +82,7 @@ def boundary_setup(cfg, d, n_steps, length_dist, seed, state="device", gemm_dtyp
     return T, est, files, scfg
 
 
-def cpu_baseline(cfg, length_dist, seed, n_steps=5):
+def cpu_baseline(cfg, length_dist, seed, n_steps=20):
     """The restated CPU oracle ("port": TF 1.12 cannot run here) on a bounded sample of THE SAME JOB the through-boundary leg runs
     (SURVEY 8d): the first batches of the same GZIP TFRecord session files (same generator, same seed), decoded by the same input_fn
     (datasets.SessionDataset), at the workload's own batch size, with the Estimator params the trainer builds - 1 warm-up + n_steps timed
@@ -93,7 +93,8 @@ def cpu_baseline(cfg, length_dist, seed, n_steps=5):
     from chameleon_recsys_amd.nar import datasets
     from chameleon_recsys_amd.nar.clicked_items_state import ClickedItemsState, batch_clicks_for_state
     from oracle.nar_oracle import NAROracle
-    cores = min(len(os.sched_getaffinity(0)), 32)     # beyond ~32 threads the oracle's many small ops only get slower
+    host_cores = len(os.sched_getaffinity(0))         # what the node gives this process ("core count printed")
+    cores = min(host_cores, 32)                       # threads actually used: beyond ~32 the oracle's many small ops only get slower
     torch.set_num_threads(cores)
     B = cfg['batch']
     d = tempfile.mkdtemp(prefix="cham_cpu_")
@@ -121,10 +122,11 @@ def cpu_baseline(cfg, length_dist, seed, n_steps=5):
     dt, n = sum(times[1:]), len(times) - 1
     stages = {k: round(v / n * 1e3, 1) for k, v in orc.timers.items()}
     stages['input_fn'] = round(t_in / n * 1e3, 1)
-    return dict(value=round(B * n / dt, 3), unit="sessions/s", cores=cores, kind="port",
+    return dict(value=round(B * n / dt, 3), unit="sessions/s", cores=cores, host_cores_visible=host_cores, host_cpu_count=os.cpu_count(),
+                torch_threads=torch.get_num_threads(), kind="port",
                 sample="%d timed optimizer steps (1 warm-up) of %d-session batches decoded from the through-boundary leg's own GZIP TFRecord "
                        "files (same generator + seed, %s session lengths) by the same input_fn, restated CPU oracle (PyTorch-CPU fp32, TF 1.12 "
-                       "unavailable), %d threads" % (n, B, length_dist, cores),
+                       "unavailable), %d threads on a host that shows this process %d cores" % (n, B, length_dist, cores, host_cores),
                 ms_per_step=round(dt / n * 1e3, 1), stage_ms_per_step=stages)
 
 
@@ -250,6 +252,10 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
 
             def after_run(self, ctx, values):
                 self.n += 1
+                if self.n == 1:       # warm-up: the buffer sets of every padded length the files can produce (ragged sessions: T = batch maximum - 1)
+                    rt_ = est._store.get('runtime')
+                    if rt_ is not None and length_dist != "full":
+                        rt_.warm_plans(B, range(1, cfg['seq_len']), cfg['neg'], cfg['neg_from_buffer'])
                 if self.n == warm_steps:
                     torch.cuda.synchronize(); self.t0 = time.perf_counter(); self.p0 = self.plans()
 
@@ -276,10 +282,11 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
         shutil.rmtree(d, ignore_errors=True)
 
 
-def stress_arm(n_items=1_000_000, batch=1024, neg=200, micro=512, steps=2):
-    """BASELINE.json configs[4] (large-catalog stress: 128-d ACE, 200 negatives, item-embedding width floor(8 n^0.25)) scaled to a catalog
-    and batch that fit the default run's budget, as a child process (scripts/stress_large_catalog.py: micro-batched optimizer step, the
-    HBM rooflines of the gather, TF-dense Adam and embedding-gradient kernels).  The full 5 M x 4096 run is the same script's default."""
+def stress_arm(n_items=5_000_000, batch=4096, neg=200, micro=512, steps=2):
+    """BASELINE.json configs[4] AS WRITTEN (large-catalog stress: 5 M articles, 128-d ACE, batch 4096, 200 negatives, item-embedding width
+    floor(8 n^0.25) = 378 -> a 7.56 GB table, 1.89 G parameters under TF-dense Adam) as a child process (scripts/stress_large_catalog.py:
+    micro-batched optimizer step, the HBM rooflines of the gather, TF-dense Adam and embedding-gradient kernels): ~8 s of set-up + 0.7 s per
+    step.  `stress_arm_1m` in the line is the same script at 1 M articles x 1024 sessions (rounds 3-4 reported only that one)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "stress_large_catalog.py"), "--n-items", str(n_items), "--batch", str(batch),
            "--neg", str(neg), "--micro", str(micro), "--steps", str(steps)]
@@ -298,6 +305,48 @@ def stress_arm(n_items=1_000_000, batch=1024, neg=200, micro=512, steps=2):
     for k in ("adam", "gather_lds_tiles", "embedding_gradient"):
         arm[k] = {q: d[k].get(q) for q in ("bound", "algorithmic_bytes", "ms", "achieved_gbs", "peak_gbs", "frac")}
     return arm
+
+
+def pmc_traffic_live(symbol, seed):
+    """HBM bytes per launch of kernel `symbol`, MEASURED IN THIS RUN: two rocprofv3 counter passes (`--kernel-trace --pmc FETCH_SIZE`, then
+    `--pmc WRITE_SIZE`: the two do not fit one pass, MI355X_MICROARCH.md "HBM") over a short child run of this script on the same
+    workload, traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB; the x 2 is the guide's gfx950 correction - FETCH_SIZE tallies 128-byte read
+    requests at 64 bytes), averaged over the symbol's dispatches.  -> (bytes or None, how it was obtained / why it failed)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="cham_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--seed", str(seed), "--no-cpu-baseline",
+             "--no-ragged-leg", "--no-boundary-leg", "--no-arms", "--no-native-arm", "--no-pmc"]
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_d = os.path.join(d, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out_d, "-o", "pmc", "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            files = glob.glob(os.path.join(out_d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or "").strip()[-200:])
+            tot, n = 0.0, 0
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get('Counter_Name') == ctr and row.get('Kernel_Name') == symbol:
+                        tot += float(row['Counter_Value']); n += 1
+            if n == 0:
+                return None, "kernel symbol %r is not in the %s counter output" % (symbol, ctr)
+            vals[ctr] = (tot / n, n)
+    except Exception as ex:          # (time-out, unreadable output: the caller falls back to the committed profile and says so)
+        return None, "%s: %s" % (type(ex).__name__, ex)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    traffic = int(round((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024))
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py %s`, "
+                     "2 x FETCH_SIZE + WRITE_SIZE averaged over %d dispatches of the symbol" % (" ".join(child[2:]), vals["FETCH_SIZE"][1]))
 
 
 def hitrate_parity(seed):
@@ -374,6 +423,8 @@ def main():
     ap.add_argument("--no-arms", action="store_true",
                     help="skip the bf16_arm (BASELINE configs[2] arithmetic) and adressa_arm (configs[3]) legs of the default g1 / f32 run: "
                          "each is this script run as a child process with its own roofline entry")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 counter passes (child runs of this script) that measure roofline.traffic in this run")
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
@@ -558,15 +609,27 @@ def main():
     dom_x3 = bool(dom['r'] and (dom['r'].get('x3') or dom['r'].get('p3')))
     dom_peak = H2_MATRIX_PEAK_TFLOPS if dom_h2 else (X3_MATRIX_PEAK_TFLOPS if dom_x3 else FP32_MATRIX_PEAK_TFLOPS)
     achieved = fl_nn / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
-    traffic, traffic_src = None, None
-    for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        if fn.endswith("_pmc_traffic.json"):     # PMC passes cannot be collected inside the timed bench: committed separately
-            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            rec = pmc.get(DOM_SYMBOL)
-            if rec and args.config == "g1" and world == 1 and args.scaling == "weak":
-                traffic = rec["traffic_bytes_per_launch"]
-                traffic_src = "profiles/%s (%s)" % (fn, pmc.get("_generated_by", "scripts/pmc_traffic.py"))
-            break
+    # roofline.traffic: measured in THIS run by two rocprofv3 counter passes over a short child run (pmc_traffic_live) on the default line;
+    # otherwise (child arms, --no-pmc, no rocprofv3) the newest committed profiles/*_pmc_traffic.json, LABELLED as such - and a symbol that
+    # is missing from it is reported in `traffic_error`, never silently null
+    traffic, traffic_src, traffic_err = None, None, None
+    headline = args.config == "g1" and world == 1 and args.scaling == "weak" and args.dtype == "f32"
+    if rank == 0 and headline and not args.no_pmc and not args.no_arms:
+        traffic, traffic_src = pmc_traffic_live(DOM_SYMBOL, args.seed)
+        if traffic is None:
+            traffic_err, traffic_src = traffic_src, None
+    if traffic is None and headline:
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if fn.endswith("_pmc_traffic.json"):
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                rec = pmc.get(DOM_SYMBOL)
+                if rec:
+                    traffic = rec["traffic_bytes_per_launch"]
+                    traffic_src = "committed profile, NOT measured in this run: profiles/%s (%s)" % (fn, pmc.get("_generated_by", "scripts/pmc_traffic.py"))
+                else:
+                    traffic_err = ((traffic_err + "; ") if traffic_err else "") + "kernel symbol %r is not in profiles/%s" % (DOM_SYMBOL, fn)
+                    print("bench.py: roofline.traffic unavailable - %s" % traffic_err, file=sys.stderr)
+                break
 
     # ---- secondary leg: the same step on G1-LIKE session lengths (2 + min(Geometric(0.45), seq_len - 2), mean
     # ~4 clicks, zero-padded to the batch maximum).  The headline above is the "all sessions full length" stress/roofline
@@ -659,7 +722,7 @@ def main():
                                        "(the native fp32 MFMA peak is %.1f)" % FP32_MATRIX_PEAK_TFLOPS) if dom_h2 else
                                       ("bf16 dense MFMA peak 2500 TFLOP/s / 6 plane products per fp32 product; algorithmic fp32 FLOPs in `achieved` "
                                        "(the native fp32 MFMA peak is %.1f)" % FP32_MATRIX_PEAK_TFLOPS) if dom_x3 else "fp32 dense MFMA peak",
-                         "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_error": traffic_err,
                          "launches_per_step": round(n_nn / nprof, 2), "avg_launch_ms": round(ms_nn / max(1, n_nn), 4),
                          "algorithmic_gflop_per_launch": round(fl_nn / max(1, n_nn) / 1e9, 3),
                          "algorithmic_bytes_per_launch": round(dom['bytes'] / max(1, n_nn)),
@@ -693,7 +756,8 @@ def main():
             # other, this process idle meanwhile): configs[2]'s arithmetic on one GPU, configs[3]'s shape
             out["bf16_arm"] = child_arm(args, ["--dtype", "bf16"])
             out["adressa_arm"] = child_arm(args, ["--config", "adressa", "--no-ragged-leg"])
-            out["stress_arm"] = stress_arm()          # configs[4] scaled to 1 M articles x 1024 sessions (HBM rooflines of gather / Adam / embedding gradient)
+            out["stress_arm"] = stress_arm()          # configs[4] at its full size: 5 M articles x 4096 sessions x 200 negatives
+            out["stress_arm_1m"] = stress_arm(n_items=1_000_000, batch=1024)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

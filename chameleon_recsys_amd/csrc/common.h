@@ -13,6 +13,26 @@
         if (e__ != hipSuccess) return -CHAM_ERR_LAUNCH;      \
     } while (0)
 
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE (the attribute
+// lives with the device's code object): `mask` is a per-kernel-instance bit set of the device ids that have it, atomically updated
+// (two host threads may launch the same kernel; a second device of the same process gets its own call - ADVICE r04).
+#include <atomic>
+static inline int cham_set_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return CHAM_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    mask.fetch_or(bit, std::memory_order_release);
+    return CHAM_OK;
+}
+#define CHAM_SET_DYNAMIC_LDS(kernel, bytes)                                                                  \
+    do {                                                                                                     \
+        static std::atomic<unsigned long long> lds_mask__{0};                                                \
+        if (cham_set_dynamic_lds(reinterpret_cast<const void*>(kernel), (bytes), lds_mask__) != CHAM_OK)     \
+            return -CHAM_ERR_LAUNCH;                                                                         \
+    } while (0)
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

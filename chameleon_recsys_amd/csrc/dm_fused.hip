@@ -325,12 +325,7 @@ static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, 
     p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
     constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
     auto k = k_dm_mulpred_fused<MODE>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, smem);
     hipLaunchKernelGGL(k, dim3((BT + p.PW - 1) / p.PW), dim3(512), smem, (hipStream_t)stream, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

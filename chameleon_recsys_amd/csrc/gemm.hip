@@ -391,12 +391,7 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
         if (RSI && p.rs != nullptr) {
             auto k = gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, RSI>;
-            static bool done_rs = false;
-            if (!done_rs) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                    return -CHAM_ERR_LAUNCH;
-                done_rs = true;
-            }
+            CHAM_SET_DYNAMIC_LDS(k, (int)smem);
             hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(WM * WN * 64), smem, st, p);
             CHAM_CHECK_LAUNCH();
             return CHAM_OK;
@@ -410,23 +405,14 @@ static int launch_epi(GemmParams& p, hipStream_t st) {
         if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
         if (RSI && p.rs != nullptr) {
             auto k = gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, RSI>;
-            static bool done_rs = false;
-            if (!done_rs) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                    return -CHAM_ERR_LAUNCH;
-                done_rs = true;
-            }
+            CHAM_SET_DYNAMIC_LDS(k, (int)smem);
             hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(WM * WN * 64), smem, st, p);
             CHAM_CHECK_LAUNCH();
             return CHAM_OK;
         }
         kern = reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -CHAM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(kern, (int)smem);
     dim3 grid(p.nbm * p.nbn, p.splits, 1);
     if (BF16) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, AK, BKC, EPI, false>), grid, dim3(WM * WN * 64), smem, st, p);

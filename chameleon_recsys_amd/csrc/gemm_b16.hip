@@ -338,12 +338,7 @@ static int b16_launch_epi(B16Params& p, hipStream_t st) {
     const size_t smem = (size_t)2 * (ASZ + BSZ) * 2;
     g_b16_launches[5] = OUTF32; g_b16_launches[6] = EPI; g_b16_launches[7] = p.splits;
     auto k = gemm_b16_kernel<BM, BN, WM, WN, BK, MINW, AK, BKC, EPI, OUTF32>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, (int)smem);
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(WM * WN * 64), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

@@ -479,12 +479,7 @@ static int h2_launch(H2Params& p, hipStream_t st) {
     g_h2_launches[6] = EPI; g_h2_launches[7] = p.splits;
     constexpr int smem = H2_RING * H2_STAGE;
     auto k = gemm_h2_kernel<TN, EPI>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, smem);
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

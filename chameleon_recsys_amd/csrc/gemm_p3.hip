@@ -589,12 +589,7 @@ static int p3_launch(P3Params& p, hipStream_t st) {
     g_p3_launches[6] = EPI; g_p3_launches[7] = p.splits;
     constexpr int smem = P3_RING * P3_STAGE;
     auto k = gemm_p3_kernel<TN, EPI>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, smem);
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -681,12 +676,7 @@ static int b1_launch(P3Params& p, hipStream_t st) {
     g_p3_launches[6] = EPI; g_p3_launches[7] = p.splits;
     constexpr int smem = P3_RING * P3_STAGE;
     auto k = gemm_b1_kernel<TN, EPI>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, smem);
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, p.splits, 1), dim3(512), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

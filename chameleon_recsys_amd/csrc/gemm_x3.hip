@@ -401,23 +401,13 @@ static int x3_launch_epi(GemmParams& p, hipStream_t st) {
     const dim3 grid(p.nbm * p.nbn, p.splits, 1), block(WM * WN * 64);
     if (RSI && p.rs != nullptr) {
         auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, RSI>;
-        static bool done_rs = false;
-        if (!done_rs) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                return -CHAM_ERR_LAUNCH;
-            done_rs = true;
-        }
+        CHAM_SET_DYNAMIC_LDS(k, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
         CHAM_CHECK_LAUNCH();
         return CHAM_OK;
     }
     auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, false>;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k, (int)smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

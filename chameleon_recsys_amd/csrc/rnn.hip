@@ -491,8 +491,7 @@ static int launch_ugrnn_fwd(const float* xproj, const float* Wh, const int* seq_
                             float* G, float* Cc, hipStream_t st) {
     size_t smem = (size_t)32 * (128 * NT + 1) * sizeof(float);
     auto kern = k_ugrnn_fwd<NT, 1>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    CHAM_SET_DYNAMIC_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -502,8 +501,7 @@ static int launch_ugrnn_bwd(const float* dout, const float* WhT, const int* seq_
                             const float* G, const float* Cc, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (256 * NT + 1) * sizeof(float);
     auto kern = k_ugrnn_bwd<NT, 1>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    CHAM_SET_DYNAMIC_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, dout, WhT, seq_len, B, T, hprev, G, Cc, dxproj);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -514,8 +512,7 @@ static int launch_gru_fwd(const float* xproj, const float* Wh, const int* seq_le
                           float* U, float* Cc, float* R, float* RH, hipStream_t st) {
     size_t smem = (size_t)64 * (128 * NT + 1) * sizeof(float);
     auto kern = k_gru_fwd<NT, 1>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    CHAM_SET_DYNAMIC_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, xproj, Wh, seq_len, B, T, out, hprev, U, Cc, R, RH);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -525,8 +522,7 @@ static int launch_gru_bwd(const float* dout, const float* WhT, const int* seq_le
                           const float* U, const float* Cc, const float* R, float* dxproj, hipStream_t st) {
     size_t smem = (size_t)32 * (384 * NT + 2) * sizeof(float);
     auto kern = k_gru_bwd<NT, 1>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    CHAM_SET_DYNAMIC_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((B + 31) / 32), dim3(256 * NT), smem, st, dout, WhT, seq_len, B, T, hprev, U, Cc, R, dxproj);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

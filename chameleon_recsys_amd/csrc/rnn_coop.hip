@@ -257,7 +257,17 @@ extern "C" size_t cham_rnn_coop_workspace_bytes(int B, int Hp) {
 static int rc_prepare(int B, int Hp, void* workspace, size_t workspace_bytes, hipStream_t st, float** payload, unsigned** flags, unsigned** tmo, int* ng) {
     if (Hp != 256 || B <= 0 || !workspace || ((uintptr_t)workspace & 255) || workspace_bytes < cham_rnn_coop_workspace_bytes(B, Hp)) return -CHAM_ERR_ARG;
     *ng = (B + 31) / 32;
-    if (*ng * RC_SLICES > 256) return -CHAM_ERR_ARG;          // every workgroup of a launch must be resident (one per CU)
+    // every workgroup of a launch must be resident at once (one per CU: 114 / 153 KB of LDS each): the CU count of the CURRENT device,
+    // queried once per device - not an assumed 256; -EINVAL keeps the caller on cham_rnn_fwd / _bwd
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -CHAM_ERR_LAUNCH;
+    int n_cu = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n_cu == 0) {
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return -CHAM_ERR_LAUNCH;
+        cus[dev & 63].store(n_cu, std::memory_order_relaxed);
+    }
+    if (*ng * RC_SLICES > n_cu) return -CHAM_ERR_ARG;
     const size_t pay = 2 * (size_t)*ng * 32 * 2 * Hp * sizeof(float);
     *payload = reinterpret_cast<float*>(workspace);
     *flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + pay);
@@ -281,12 +291,7 @@ extern "C" int cham_ugrnn_fwd_coop(const float* xproj, const float* Wh, const in
     const int rc = rc_prepare(B, Hp, workspace, workspace_bytes, st, &pay, &flags, &tmo, &ng);
     if (rc != CHAM_OK) return rc;
     constexpr int smem = (2 * 2 * 32 * RC_PF + 2 * 32 * RC_PF + 4 * 16 * 64 + 32 * 36) * 4;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ugrnn_fwd_coop), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k_ugrnn_fwd_coop, smem);
     hipLaunchKernelGGL(k_ugrnn_fwd_coop, dim3(RC_SLICES, ng), dim3(256), smem, st, xproj, Wh, seq_len, B, T, out, hprev, G, Cc, pay, flags, tmo);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
@@ -300,12 +305,7 @@ extern "C" int cham_ugrnn_bwd_coop(const float* dout, const float* Wh, const int
     const int rc = rc_prepare(B, Hp, workspace, workspace_bytes, st, &pay, &flags, &tmo, &ng);
     if (rc != CHAM_OK) return rc;
     constexpr int smem = (2 * 32 * RC_PB + 2 * 32 * RC_PB + 4 * 16 * 64 + 32 * 68) * 4;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ugrnn_bwd_coop), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return -CHAM_ERR_LAUNCH;
-        done = true;
-    }
+    CHAM_SET_DYNAMIC_LDS(k_ugrnn_bwd_coop, smem);
     hipLaunchKernelGGL(k_ugrnn_bwd_coop, dim3(RC_SLICES, ng), dim3(256), smem, st, dout, Wh, seq_len, B, T, hprev, G, Cc, dxproj, pay, flags, tmo);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;

@@ -148,22 +148,44 @@ class Estimator:
                 os.replace(tmp, p)
             self._last_ckpt_time = time.time()
 
+    def _coop_timed_out_local(self):
+        rt = self._store.get('runtime')
+        return bool(rt is not None and getattr(rt, '_rnn_coop_ws', None) and rt.rnn_coop_timed_out())
+
+    _HEALTH_MSG = ("a cooperative recurrent kernel (csrc/rnn_coop.hip) gave up a bounded spin%s: the hidden states of at least one "
+                   "step are invalid.  Is another process running cooperative kernels on this GPU?")
+
     def _check_device_health(self):
         """The cooperative recurrent kernels (csrc/rnn_coop.hip) hand h_t from workgroup to workgroup with BOUNDED spins; a spin that gave
         up (a cooperating workgroup never became resident - e.g. several processes' cooperative kernels competing for one GPU) leaves a
         sticky word in their workspace and wrong hidden states behind.  Checked where the loop synchronises anyway (checkpoints, the end of
-        train / evaluate): fail loudly rather than train on."""
+        train / evaluate, and the data-parallel checkpoint poll): fail loudly rather than train on.  The word is PER PROCESS: under data
+        parallelism the flags are MAX-reduced over the data-parallel group first, so that every rank raises together - one rank raising
+        alone would leave the others waiting in the next collective (state_dict() all-gathers the Adam slots in the sharded mode).
+        Every rank reaches this at the same steps (save_checkpoint is entered on rank 0's broadcast decision)."""
+        bad = self._coop_timed_out_local()
         rt = self._store.get('runtime')
-        if rt is not None and getattr(rt, '_rnn_coop_ws', None) and rt.rnn_coop_timed_out():
-            raise RuntimeError("a cooperative recurrent kernel (csrc/rnn_coop.hip) gave up a bounded spin: the hidden states of at least one "
-                               "step are invalid.  Is another process running cooperative kernels on this GPU?")
+        where = ""
+        if rt is not None and getattr(rt, 'dp_active', False):
+            import torch.distributed as dist
+            if dist.is_initialized():
+                pg = getattr(rt, 'dp_pg', None)
+                flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=rt.device if dist.get_backend(pg) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=pg)
+                if int(flag.item()) and not bad:
+                    where = " on another data-parallel rank"
+                bad = bool(int(flag.item()))
+        if bad:
+            raise RuntimeError(self._HEALTH_MSG % where)
 
     def _checkpoint_due(self):
         """save_checkpoints_secs elapsed?  A per-rank wall-clock decision would let ranks enter save_checkpoint() - a collective under the
         sharded exchange mode - at different steps (hang, or a gather paired with the next step's reduce-scatter): with an active
-        data-parallel group its first rank decides and broadcasts - on the data-parallel process group, and only every
-        CKPT_DECISION_EVERY steps (every rank counts the same steps): the broadcast + read-back is a host-device synchronisation, which
-        every step would undo the enqueue-ahead of the training loop."""
+        data-parallel group its first rank decides - ONE MAX all-reduce of [rank 0's decision (the others contribute 0), this rank's
+        kernel time-out word] on the data-parallel process group, only every CKPT_DECISION_EVERY steps (every rank counts the same
+        steps): the read-back is a host-device synchronisation, which every step would undo the enqueue-ahead of the training loop
+        (ADVICE r03).  The second word makes a failed cooperative-kernel hand-off on ANY rank stop EVERY rank within
+        CKPT_DECISION_EVERY steps instead of at the next checkpoint."""
         secs = self.config.save_checkpoints_secs
         due = bool(secs) and time.time() - self._last_ckpt_time > secs
         rt = self._store.get('runtime')
@@ -174,9 +196,14 @@ class Estimator:
                 if self._ckpt_poll % self.CKPT_DECISION_EVERY:
                     return False
                 pg = getattr(rt, 'dp_pg', None)
-                flag = torch.tensor([1 if due else 0], dtype=torch.int32, device=rt.device if dist.get_backend(pg) == "nccl" else "cpu")
-                dist.broadcast(flag, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
-                due = bool(int(flag.item()))
+                first = dist.get_rank(pg) == 0
+                bad = self._coop_timed_out_local()
+                flag = torch.tensor([1 if (due and first) else 0, 1 if bad else 0], dtype=torch.int32,
+                                    device=rt.device if dist.get_backend(pg) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=pg)
+                due, any_bad = (bool(int(x)) for x in flag.tolist())
+                if any_bad:
+                    raise RuntimeError(self._HEALTH_MSG % ("" if bad else " on another data-parallel rank"))
         return due
 
     CKPT_DECISION_EVERY = 50

@@ -272,9 +272,12 @@ class ParamLayout:
         "input_features_center_scale/{gamma_scale, beta_center}" (:890-895); "CAR/{PreCAR,CAR}_representation" (:374-387);
         "RNN/rnn/multi_rnn_cell/cell_l/ugrnn_cell" (:1309-1342; tf.nn.rnn_cell.GRUCell: "gru_cell/{gates, candidate}");
         "session_representation/{FC1, FC2}" (:410-425); "recommendations_ranking/matching_dense_layer_{1..4}" (:444-472).
-        tf.layers.Dense OBJECTS (PreCAR / CAR / matching layers) are created in one scope and first CALLED in another; which of the two
-        TF 1.12 puts in the variable name cannot be verified here - tf_variable_aliases() lists the other spelling and
-        from_tf_variables() accepts either."""
+        tf.layers.Dense OBJECTS bind their variable scope at the first __call__, not at construction (TF 1.x base Layer._set_scope):
+        PreCAR_dense is built AND first called inside "CAR" (:372-381) -> "main/CAR/PreCAR_representation"; CAR_dense is built there
+        but first called under "user_personalized_contextual_article_embedding/input" (:388-390); the four matching layers are built
+        under "recommendations_ranking" (:444-471) and first called under its "cos_sim_positive" (:476-486).  The first-call spelling
+        is canonical (what a TF 1.12 checkpoint reader lists); tf_variable_aliases() keeps the construction-scope spelling, which
+        from_tf_variables() also accepts (TF cannot run here to confirm)."""
         m = OrderedDict()
         ucf = 'main/user_items_contextual_features/'
         for name in self.entries:
@@ -288,9 +291,9 @@ class ParamLayout:
                 m[ucf + 'item_features/item_cat_embedding/items_embedding'] = name
         m[ucf + 'input_features_center_scale/gamma_scale'] = 'gamma'
         m[ucf + 'input_features_center_scale/beta_center'] = 'beta'
-        for tf_l, lg in (('PreCAR_representation', 'PreCAR'), ('CAR_representation', 'CAR')):
-            m['main/CAR/%s/kernel' % tf_l] = lg + '/kernel'
-            m['main/CAR/%s/bias' % tf_l] = lg + '/bias'
+        for v in ('kernel', 'bias'):
+            m['main/CAR/PreCAR_representation/' + v] = 'PreCAR/' + v
+            m['main/user_personalized_contextual_article_embedding/input/CAR_representation/' + v] = 'CAR/' + v
         for l in range(self.L):
             cell = 'main/RNN/rnn/multi_rnn_cell/cell_%d/' % l
             if self.cell == 'ugrnn':
@@ -304,22 +307,21 @@ class ParamLayout:
             m['main/session_representation/%s/kernel' % fc] = fc + '/kernel'
             m['main/session_representation/%s/bias' % fc] = fc + '/bias'
         for i in range(1, 5):
-            m['main/recommendations_ranking/matching_dense_layer_%d/kernel' % i] = 'match%d/kernel' % i
-            m['main/recommendations_ranking/matching_dense_layer_%d/bias' % i] = 'match%d/bias' % i
+            m['main/recommendations_ranking/cos_sim_positive/matching_dense_layer_%d/kernel' % i] = 'match%d/kernel' % i
+            m['main/recommendations_ranking/cos_sim_positive/matching_dense_layer_%d/bias' % i] = 'match%d/bias' % i
         assert set(m.values()) == set(self.logical_specs())
         return m
 
     def tf_variable_aliases(self):
-        """Alternative spelling -> canonical TF name for the Dense layers whose first call happens in a nested scope (nar_model.py:390-392:
-        "user_personalized_contextual_article_embedding/input"; :476: "recommendations_ranking/cos_sim_positive")."""
+        """Alternative spelling -> canonical TF name: the CONSTRUCTION-scope spelling of the Dense layers whose first call happens in a
+        nested scope (CAR_dense: built in "CAR", nar_model.py:383-387; the matching layers: built in "recommendations_ranking", :447-471)."""
         a = OrderedDict()
-        for tf_l in ('PreCAR_representation', 'CAR_representation'):
-            for v in ('kernel', 'bias'):
-                a['main/user_personalized_contextual_article_embedding/input/%s/%s' % (tf_l, v)] = 'main/CAR/%s/%s' % (tf_l, v)
+        for v in ('kernel', 'bias'):
+            a['main/CAR/CAR_representation/' + v] = 'main/user_personalized_contextual_article_embedding/input/CAR_representation/' + v
         for i in range(1, 5):
             for v in ('kernel', 'bias'):
-                a['main/recommendations_ranking/cos_sim_positive/matching_dense_layer_%d/%s' % (i, v)] = \
-                    'main/recommendations_ranking/matching_dense_layer_%d/%s' % (i, v)
+                a['main/recommendations_ranking/matching_dense_layer_%d/%s' % (i, v)] = \
+                    'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_%d/%s' % (i, v)
         return a
 
     def to_tf_variables(self, logical):

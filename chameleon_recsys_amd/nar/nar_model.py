@@ -402,6 +402,13 @@ class NARRuntime:
         self._plans[key] = pl                                      # (re)insert as most recently used
         return pl
 
+    def warm_plans(self, B, Ts, N, n_buf, Bg=None):
+        """Builds the buffer set of every padded length in ``Ts`` now (a trainer's warm-up): hourly session files produce a handful of
+        padded lengths T <= truncate_session_length - 1, and the first batch of each would otherwise allocate and zero-fill several GB
+        in the middle of training (tens of ms).  Bounded by ``max_plans`` / ``plan_bytes_budget`` like any other plan."""
+        for T in Ts:
+            self.plan(B, int(T), N, n_buf, Bg)
+
     # ---- thin kernel wrappers -------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
              dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False):
@@ -697,6 +704,8 @@ class StepPlan:
         if t.shape[0] < self.Rall:
             t = torch.empty(self.Rall, t.shape[1], dtype=t.dtype, device=t.device)
             setattr(self, name, t)
+            if hasattr(self, 'nbytes'):         # what the plan cache's byte budget counts (NARRuntime.plan)
+                self.nbytes = self.allocated_bytes()
         return t
 
     def dropout_buffers(self, rt):
@@ -1028,6 +1037,10 @@ class NARModuleModel:
             check(lib.cham_rows_gather(ptr(pl.neg_ids), ptr(pos), BT, 2 * N, ptr(neg_ids), s), "cham_rows_gather")
             check(lib.cham_rows_gather(ptr(pl.neg_slot), ptr(pos), BT, N, ptr(neg_slot), s), "cham_rows_gather")
         pl.cur_neg_ids, pl.cur_neg_slot = neg_ids, neg_slot
+        # a training-mode forward on this plan that was NOT followed by backward() (a loss-only call, an exception in between) leaves the
+        # side lane's row grouping un-awaited: it reads ids_all and writes perm / seg - wait for it before rewriting ids_all
+        if getattr(pl, 'grouped_ev', None) is not None:
+            torch.cuda.current_stream().wait_event(pl.grouped_ev)
         # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
         pl.ids_all[:BT].copy_(d['ic_rows'])
         pl.ids_all[BT:2 * BT].copy_(d['ln_rows'])

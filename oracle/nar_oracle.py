@@ -1,4 +1,4 @@
-"""Dense float32 CPU restatement of the NAR graph (forward, loss, gradients, TF-Adam).
+"""Dense float32 (optionally float64) CPU restatement of the NAR graph (forward, loss, gradients, TF-Adam).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py) - also the "port" CPU baseline timed by bench.py.
 PARITY UNPINNED at the TF boundary: TensorFlow 1.12 cannot run here, the reference has no golden
@@ -7,6 +7,14 @@ reference's op order: NO de-duplication, NO PreCAR factorisation, padded rows co
 
 Gradients come from PyTorch-CPU autograd over this restatement; the optimizer is a hand-written
 TF-flavoured Adam (nar_model.py:708-722; tf.train.AdamOptimizer semantics).
+
+Two adjudication modes (round 5, tests/golden/loss_curve_200.npz, oracle/make_loss_curve.py):
+  * ``dtype=torch.float64``: weights, activations, gradients and Adam slots in float64 - the trajectory every fp32
+    implementation (this oracle in fp32, TensorFlow's Eigen kernels, the HIP path) is a rounding of.  What the GRAPH
+    itself quantises stays quantised: the int64 -> float32 time-stamp casts (nar_model.py:1058-1059) and the float32
+    popularity placeholder (:1442) are rounded to float32 first, then widened.
+  * ``sum_perm_seed=k``: the same fp32 arithmetic with every contraction summed in another order (a fixed permutation of
+    the K index of each matmul) - a second, equally correct fp32 realisation.
 """
 import math
 from collections import OrderedDict
@@ -176,17 +184,19 @@ def init_params(params, seed=42):
 
 # ----------------------------------------------------------------------------- model
 class NAROracle:
-    def __init__(self, params, weights=None, seed=42):
+    def __init__(self, params, weights=None, seed=42, dtype=torch.float32, sum_perm_seed=None):
         self.p = params
+        self.dt = dtype
+        self.sum_perm_seed, self._perms = sum_perm_seed, {}
         self.specs, self.dims = param_specs(params)
         w = weights if weights is not None else init_params(params, seed)
-        self.w = OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone().requires_grad_(True))
+        self.w = OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=dtype).clone().requires_grad_(True))
                              for k, v in w.items())
         assert list(self.w.keys()) == list(self.specs.keys())
         self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.w.items())
         self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in self.w.items())
         self.global_step = 0
-        self.ace = torch.as_tensor(params['content_article_embeddings_matrix'], dtype=torch.float32)
+        self.ace = torch.as_tensor(np.asarray(params['content_article_embeddings_matrix'], dtype=np.float32)).to(dtype)
         self.meta = {k: torch.as_tensor(np.asarray(v)) for k, v in params['articles_metadata'].items()}
         self.ifc = params.get('internal_features_config',
                               dict(recency=True, novelty=True, article_content_embeddings=True,
@@ -197,9 +207,28 @@ class NAROracle:
         self.gemm_dtype = params.get('gemm_dtype', 'f32')
         self._train, self._step = False, 0          # set by forward(): dropout is active in TRAIN mode only
 
+    def _c(self, x):
+        """Scalar constant in the working dtype."""
+        return torch.tensor(x, dtype=self.dt)
+
+    def _perm(self, K):
+        pm = self._perms.get(K)
+        if pm is None:
+            g = torch.Generator().manual_seed(1000003 * int(self.sum_perm_seed) + K)
+            pm = self._perms[K] = torch.randperm(K, generator=g)
+        return pm
+
+    def _mmf(self, a, b):
+        """a @ b in the working dtype; with ``sum_perm_seed`` the contraction index is visited in a permuted order (same
+        real-number product, another fp32 summation order)."""
+        if self.sum_perm_seed is None:
+            return a @ b
+        pm = self._perm(a.shape[-1])
+        return a[..., pm] @ b[pm]
+
     def _mm(self, a, b):
         """Dense / matmul of the graph; bf16-rounded operands when the bf16 compute mode is emulated."""
-        return _BF16MatMul.apply(a, b) if self.gemm_dtype == 'bf16' else a @ b
+        return _BF16MatMul.apply(a, b) if self.gemm_dtype == 'bf16' else self._mmf(a, b)
 
     # -- nar_model.py:730-773 get_features
     def _get_features(self, values, config, ignore, prefix):
@@ -210,11 +239,11 @@ class NAROracle:
             x = values[name]
             if cfg['type'] == 'categorical':
                 if cfg['cardinality'] <= self.max_ohe:
-                    feats.append(torch.nn.functional.one_hot(x.long(), cfg['cardinality']).float())
+                    feats.append(torch.nn.functional.one_hot(x.long(), cfg['cardinality']).to(self.dt))
                 else:
                     feats.append(self.w[prefix + name][x.long()])
             elif cfg['type'] == 'numerical':
-                feats.append(x.float().unsqueeze(-1))
+                feats.append(x.float().to(self.dt).unsqueeze(-1))      # float32 feature column, widened in f64 mode
             else:
                 raise Exception('Invalid feature type: {}'.format(name))
         return torch.cat(feats, dim=-1) if feats else None
@@ -224,10 +253,10 @@ class NAROracle:
     def _normalize_values(x, stats):
         mean = stats.mean()
         var = ((stats - mean) ** 2).mean()                 # tf.nn.moments: population variance
-        sd = torch.sqrt(var + torch.tensor(1e-24))
+        sd = torch.sqrt(var + torch.tensor(1e-24, dtype=x.dtype))
         z = (x - mean) / sd
         zs = (stats - mean) / sd
-        eps = torch.tensor(1e-24)
+        eps = torch.tensor(1e-24, dtype=x.dtype)
         mn, mx = zs.min(), zs.max()
         scaled = (z - mn + eps) / torch.maximum(mx - mn, 2 * eps)
         return scaled * 2.0 - 1.0
@@ -238,12 +267,12 @@ class NAROracle:
 
     @staticmethod
     def _log1p_base(x, base):
-        return torch.log(x + 1.0) / torch.log(torch.tensor(base, dtype=torch.float32))   # :28-34
+        return torch.log(x + 1.0) / torch.log(torch.tensor(base, dtype=x.dtype))   # :28-34
 
-    @staticmethod
-    def _elapsed_days(created, ref_ts):
-        # nar_model.py:1055-1060: int64 -> float32 BEFORE the subtraction
-        return torch.relu((ref_ts.to(torch.float32) - created.to(torch.float32)) / torch.tensor(MS_PER_DAY, dtype=torch.float32))
+    def _elapsed_days(self, created, ref_ts):
+        # nar_model.py:1055-1060: int64 -> float32 BEFORE the subtraction (the graph's own quantisation: kept in f64 mode, where the
+        # two float32 values are widened and everything after the casts is float64)
+        return torch.relu((ref_ts.to(torch.float32).to(self.dt) - created.to(torch.float32).to(self.dt)) / self._c(MS_PER_DAY))
 
     # -- nar_model.py:1092-1131 + 1062-1089
     def _recency(self, ids, ref_ts, buffer_ids, stats_ref_ts=None):
@@ -260,7 +289,7 @@ class NAROracle:
 
     # -- nar_model.py:1134-1193
     def _novelty(self, ids, buffer_ids, pop_norm):
-        pb = torch.tensor(float(self.p.get('popularity_smooth_log_base', 2.0)))      # nar_model.py:123, 1148
+        pb = self._c(float(self.p.get('popularity_smooth_log_base', 2.0)))      # nar_model.py:123, 1148
         nov = -(torch.log(pop_norm[ids].unsqueeze(-1)) / torch.log(pb))
         last = self._last_buffer_items(buffer_ids)
         if last.numel() == 0:
@@ -306,8 +335,8 @@ class NAROracle:
             r = philox.rand32(c[:, :, None, :], t[:, :, None, :], b[:, :, None, :], np.uint64(site) + np.uint64(256) * n, self.seed, step)
         else:
             r = philox.rand32(c, t, b, site, self.seed, step)
-        mask = torch.from_numpy((np.broadcast_to(r, shp) < np.uint64(thr)).astype(np.float32))
-        return x / torch.tensor(np.float32(keep)) * mask
+        mask = torch.from_numpy((np.broadcast_to(r, shp) < np.uint64(thr)).astype(np.float32)).to(self.dt)
+        return x / self._c(float(np.float32(keep))) * mask
 
     def _store(self, x):
         """Candidate-row matrices are bf16-resident in the bf16 configuration; identity otherwise."""
@@ -327,7 +356,7 @@ class NAROracle:
         L = self.p.get('rnn_num_layers', 1)
         out = x
         for l in range(L):
-            h = torch.zeros(B, H)
+            h = torch.zeros(B, H, dtype=self.dt)
             ys = []
             for t in range(T):
                 xt = out[:, t]
@@ -336,7 +365,7 @@ class NAROracle:
                     K = self.w['rnn/%d/kernel' % l]
                     # [x, h] W = x W_x + h W_h; the input half is one hoisted GEMM on the HIP path (bf16 mode rounds it), the
                     # recurrent half runs in the fp32 time-step kernel
-                    z = (self._mm(xt, K[:I]) + h @ K[I:] if self.gemm_dtype == 'bf16' else torch.cat([xt, h], 1) @ K) \
+                    z = (self._mm(xt, K[:I]) + h @ K[I:] if self.gemm_dtype == 'bf16' else self._mmf(torch.cat([xt, h], 1), K)) \
                         + self.w['rnn/%d/bias' % l]
                     g_act, c_act = z[:, :H], z[:, H:]
                     c = torch.tanh(c_act)
@@ -347,12 +376,12 @@ class NAROracle:
                     if self.gemm_dtype == 'bf16':
                         ru = torch.sigmoid(self._mm(xt, Kg[:I]) + h @ Kg[I:] + self.w['rnn/%d/gates/bias' % l])
                     else:
-                        ru = torch.sigmoid(torch.cat([xt, h], 1) @ Kg + self.w['rnn/%d/gates/bias' % l])
+                        ru = torch.sigmoid(self._mmf(torch.cat([xt, h], 1), Kg) + self.w['rnn/%d/gates/bias' % l])
                     r, u = ru[:, :H], ru[:, H:]
                     if self.gemm_dtype == 'bf16':
                         c = torch.tanh(self._mm(xt, Kc[:I]) + (r * h) @ Kc[I:] + self.w['rnn/%d/candidate/bias' % l])
                     else:
-                        c = torch.tanh(torch.cat([xt, r * h], 1) @ Kc + self.w['rnn/%d/candidate/bias' % l])
+                        c = torch.tanh(self._mmf(torch.cat([xt, r * h], 1), Kc) + self.w['rnn/%d/candidate/bias' % l])
                     hn = u * h + (1 - u) * c
                 valid = (t < lengths).unsqueeze(1)
                 ys.append(torch.where(valid, hn, torch.zeros_like(hn)))   # dynamic_rnn: zero output past length
@@ -366,7 +395,7 @@ class NAROracle:
         s2 = self._leaky_site('S2', self._mm(s1, w['match2/kernel']) + w['match2/bias'])
         s3 = self._store(self._leaky_site('S3', self._mm(s2, w['match3/kernel']) + w['match3/bias']))
         self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
-        return s3 @ w['match4/kernel'] + w['match4/bias']       # last layer: fused into the softmax kernel, fp32 in every mode
+        return self._mmf(s3, w['match4/kernel']) + w['match4/bias']       # last layer: fused into the softmax kernel, fp32 in every mode
 
     def _stage(self, name):
         """Optional wall-clock accounting per stage (bench.py's cpu_baseline leg sets ``self.timers = {}``)."""
@@ -392,7 +421,7 @@ class NAROracle:
         if ov and ov.get(name):
             sign, valid = ov[name].pop(0)
             pos = torch.where(valid, sign, x.detach() > 0)
-            return x * torch.where(pos, torch.ones(()), torch.full((), 0.2))
+            return x * torch.where(pos, self._c(1.0), self._c(0.2))
         return _leaky(x)
 
     def _tap(self, name, t):
@@ -403,7 +432,7 @@ class NAROracle:
 
     def reg_loss(self):
         lam = self.p['reg_weight_decay']
-        tot = torch.zeros(())
+        tot = torch.zeros((), dtype=self.dt)
         for name, (_, _, reg) in self.specs.items():
             if reg:
                 tot = tot + lam * (self.w[name] ** 2).sum() / 2.0     # l2_regularizer = scale * l2_loss
@@ -429,7 +458,7 @@ class NAROracle:
         all_clicked = torch.cat([item_clicked, label_last], 1)                            # :241
         buffer_np = np.asarray(buffer_ids, dtype=np.int64)
         buffer_t = torch.as_tensor(buffer_np)
-        pop_t = torch.as_tensor(np.asarray(pop_norm, dtype=np.float32))                   # placeholder is tf.float32
+        pop_t = torch.as_tensor(np.asarray(pop_norm, dtype=np.float32)).to(self.dt)       # placeholder is tf.float32 (:1442): rounded first
         if neg_items is None:
             with self._stage('sampler'):
                 neg_items = osampler.batch_negative_samples(all_clicked.numpy(), buffer_np, N, n_buf, self.seed, step)
@@ -439,7 +468,7 @@ class NAROracle:
         ctx_vals = {n: torch.as_tensor(features[n]) for n in scfg if n not in SESSION_REQ_SEQ_FEATURES}
         ctx = self._get_features(ctx_vals, scfg, SESSION_REQ_SEQ_FEATURES, 'ctx_emb/')    # :315-317
         if ctx is None:
-            ctx = torch.zeros(B, T, 1)                                                     # :323-325
+            ctx = torch.zeros(B, T, 1, dtype=self.dt)                                      # :323-325
         gamma, beta = self.w['gamma'], self.w['beta']
         self._train, self._step = train, step
         with self._stage('gather'):
@@ -461,15 +490,15 @@ class NAROracle:
             s_pos = self._scorer(car_pos * pred)                                                                      # :478-485
             s_neg = self._scorer(car_neg * pred.unsqueeze(2)).squeeze(-1)                                             # :493-500
             logits = torch.cat([s_pos, s_neg], 2)                                                                     # :511
-            tau = torch.tensor(p['softmax_temperature'], dtype=torch.float32)
+            tau = self._c(float(p['softmax_temperature']))
             probs = torch.softmax(logits / tau, dim=-1)                                                               # :514-515
-            loss_mask = mask.float()
+            loss_mask = mask.to(self.dt)
             xe = -(torch.log(probs[:, :, 0]) * loss_mask).sum() / loss_mask.sum()                                     # :660-664
             reg = self.reg_loss()                                                                                     # :655
             total = xe + reg
         if p.get('novelty_reg_factor', 0.0) > 0.0:                                                                # :673-683
             neg_prob = torch.softmax(s_neg / tau, dim=-1)
-            neg_nov = -(torch.log(pop_t[neg]) / torch.log(torch.tensor(float(p.get('popularity_smooth_log_base', 2.0)))))       # :544, 1148
+            neg_nov = -(torch.log(pop_t[neg]) / torch.log(self._c(float(p.get('popularity_smooth_log_base', 2.0)))))       # :544, 1148
             nov = (p['novelty_reg_factor'] * (neg_prob * neg_nov * loss_mask.unsqueeze(-1)).sum(-1)).sum() / loss_mask.sum()
             total = total - nov
         out = dict(total_loss=total, xe_loss=xe, reg_loss=reg, logits=logits, probs=probs, neg_items=neg,

@@ -27,12 +27,17 @@ def update_state(st, f, l):
     st.update_items_state(ids, ts)
 
 
-def make_pair(p, seed=3):
-    """(hip NARModuleModel(train), NAROracle) sharing weights."""
-    from chameleon_recsys_amd.nar.nar_model import NARModuleModel, NARRuntime, ModeKeys
-    from oracle.nar_oracle import NAROracle
-    rt = NARRuntime(p, seed=seed)
-    w = rt.logical_weights()
+def pair_weights(p, seed=3):
+    """The initial logical weights make_pair() gives both sides - host only (no GPU, no HIP library): the committed loss-curve
+    fixture (oracle/make_loss_curve.py) is generated from exactly these in the build container."""
+    from chameleon_recsys_amd.nar.layout import ParamLayout
+    acfg = p['articles_features_config']
+    ace = p['content_article_embeddings_matrix']
+    n_items = acfg['article_id'].get('cardinality', ace.shape[0]) if 'article_id' in acfg else ace.shape[0]
+    L = ParamLayout(p['session_features_config'], acfg, n_items, ace.shape[1], p['CAR_embedding_size'], p['rnn_units'],
+                    p.get('rnn_num_layers', 1), p.get('rnn_cell', 'ugrnn'), p.get('internal_features_config'),
+                    p.get('max_cardinality_for_ohe', 10))
+    w = L.unpack(L.pack(L.init_logical(seed)))
     # make biases / gamma / beta non-trivial so their gradients and uses are exercised
     rng = np.random.default_rng(seed)
     for k in w:
@@ -40,7 +45,15 @@ def make_pair(p, seed=3):
             w[k] = (0.05 * rng.standard_normal(w[k].shape)).astype(np.float32)
         if k == 'gamma':
             w[k] = (1.0 + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
-    rt.load_logical_weights(w)
+    return w
+
+
+def make_pair(p, seed=3):
+    """(hip NARModuleModel(train), NAROracle) sharing weights."""
+    from chameleon_recsys_amd.nar.nar_model import NARModuleModel, NARRuntime, ModeKeys
+    from oracle.nar_oracle import NAROracle
+    w = pair_weights(p, seed)
+    rt = NARRuntime(p, seed=seed, weights=w)
     model = NARModuleModel(ModeKeys.TRAIN, None, None, p['session_features_config'], p['articles_features_config'],
                            p['batch_size'], p['lr'], p.get('dropout_keep_prob', 1.0), p['train_total_negative_samples'],
                            p['train_negative_samples_from_buffer'], p['content_article_embeddings_matrix'],
@@ -135,3 +148,25 @@ def assert_flat_close(layout, flat_a, m_a, flat_b, m_b, lr, n_steps=1, m_tol=2e-
 
 def assert_runtimes_close(rt_a, rt_b, lr, n_steps=1, **kw):
     return assert_flat_close(rt_a.layout, rt_a.flat, rt_a.m, rt_b.flat, rt_b.m, lr, n_steps, **kw)
+
+
+# ---- the 200-step loss curve (tests/golden/loss_curve_200.npz) ---------------------------------------------------------------
+LOSS_CURVE = dict(B=64, steps=200, eval_batches=4, batch_seed=21, weight_seed=13)
+
+
+def g1_params(B, **over):
+    """BASELINE configs[1] widths (46k articles, 250-d ACE, seq_len 20, 50 negatives, C 1024, H 255) at a batch of B sessions."""
+    return synthetic.default_params(46000, 250, seq_len=20, batch_size=B, neg=50, neg_from_buffer=3000, buffer_size=20000,
+                                    for_norm=2000, C=1024, H=255, **over)
+
+
+def loss_curve_setup(steps=None, **over):
+    """Inputs of the loss-curve test and of its committed float64 trajectory (oracle/make_loss_curve.py) - host only, seeded:
+    (params, batches [2 warm-up + steps + eval], warmed ClickedItemsState, initial logical weights)."""
+    c = LOSS_CURVE
+    steps = c['steps'] if steps is None else steps
+    p = g1_params(c['B'], **over)
+    batches = synthetic.make_batches(2 + c['steps'] + c['eval_batches'], c['B'], 20, 46000, p['session_features_config'],
+                                     length_dist='g1', sessions_per_hour=4 * c['B'], seed=c['batch_seed'])
+    st = warm_state(p, batches[:2])
+    return p, batches, st, pair_weights(p, c['weight_seed'])

@@ -213,3 +213,43 @@ def test_checkpoint_decision_is_rank0s_and_taken_every_k_steps(tmp_path):
     want = np.zeros(3 * every, bool)
     want[2 * every - 1] = True                                            # step 2K: rank 0 is due (rank 1's own clock is not)
     assert np.array_equal(d0, want), np.flatnonzero(d0)                   # step 3K: only rank 1 would be due -> nobody saves
+
+
+# ---- the cooperative-kernel time-out word under data parallelism (estimator._check_device_health / _checkpoint_due): the word
+# ---- is per process; MAX-reduced over the data-parallel group so that EVERY rank raises - one rank raising alone leaves the others in the
+# ---- next collective
+def _health_worker(rank, world, port, out_dir):
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chameleon_recsys_amd.nar.estimator import Estimator, RunConfig
+    est = Estimator(model_fn=None, config=RunConfig(save_checkpoints_secs=1000))
+    pg = dist.new_group(list(range(world)))
+    bad = {"now": False}
+    est._store['runtime'] = types.SimpleNamespace(dp_active=True, dp_pg=pg, device="cpu", _rnn_coop_ws={64: None},
+                                                  rnn_coop_timed_out=lambda: bad["now"])
+    res = []
+    est._check_device_health(); res.append("ok")                          # nobody timed out: no rank raises
+    bad["now"] = rank == 1                                                # rank 1's kernels gave up a spin
+    try:
+        est._check_device_health(); res.append("ok")
+    except RuntimeError as ex:
+        res.append("raised other" if "another data-parallel rank" in str(ex) else "raised own")
+    every = Estimator.CKPT_DECISION_EVERY
+    try:
+        for _ in range(every):
+            est._checkpoint_due()
+        res.append("ok")
+    except RuntimeError:
+        res.append("poll raised")
+    with open(os.path.join(out_dir, "health_rank%d.txt" % rank), "w") as fh:
+        fh.write(",".join(res))
+    dist.destroy_process_group()
+
+
+def test_kernel_timeout_word_raises_on_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_health_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (open(str(tmp_path / ("health_rank%d.txt" % r))).read().split(",") for r in range(world))
+    assert r0 == ["ok", "raised other", "poll raised"], r0
+    assert r1 == ["ok", "raised own", "poll raised"], r1

@@ -29,17 +29,18 @@ def test_g1_variable_inventory_matches_survey_a10():
         ucf + 'input_features_center_scale/gamma_scale': (477,),
         ucf + 'input_features_center_scale/beta_center': (477,),
         'main/CAR/PreCAR_representation/kernel': (477, 1024), 'main/CAR/PreCAR_representation/bias': (1024,),
-        'main/CAR/CAR_representation/kernel': (1024, 1024), 'main/CAR/CAR_representation/bias': (1024,),
+        'main/user_personalized_contextual_article_embedding/input/CAR_representation/kernel': (1024, 1024),
+        'main/user_personalized_contextual_article_embedding/input/CAR_representation/bias': (1024,),
         'main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/kernel': (1279, 510), 'main/RNN/rnn/multi_rnn_cell/cell_0/ugrnn_cell/bias': (510,),
         'main/session_representation/FC1/kernel': (255, 512), 'main/session_representation/FC1/bias': (512,),
         'main/session_representation/FC2/kernel': (512, 1024), 'main/session_representation/FC2/bias': (1024,),
-        'main/recommendations_ranking/matching_dense_layer_1/kernel': (1024, 128), 'main/recommendations_ranking/matching_dense_layer_1/bias': (128,),
-        'main/recommendations_ranking/matching_dense_layer_2/kernel': (128, 64), 'main/recommendations_ranking/matching_dense_layer_2/bias': (64,),
-        'main/recommendations_ranking/matching_dense_layer_3/kernel': (64, 32), 'main/recommendations_ranking/matching_dense_layer_3/bias': (32,),
-        'main/recommendations_ranking/matching_dense_layer_4/kernel': (32, 1), 'main/recommendations_ranking/matching_dense_layer_4/bias': (1,),
+        'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_1/kernel': (1024, 128), 'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_1/bias': (128,),
+        'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_2/kernel': (128, 64), 'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_2/bias': (64,),
+        'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_3/kernel': (64, 32), 'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_3/bias': (32,),
+        'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_4/kernel': (32, 1), 'main/recommendations_ranking/cos_sim_positive/matching_dense_layer_4/bias': (1,),
     }
     assert shapes == expect
-    n_dense = sum(int(np.prod(s)) for k, s in shapes.items() if 'embedding' not in k)
+    n_dense = sum(int(np.prod(s)) for k, s in shapes.items() if '_embedding' not in k.rsplit('/', 1)[1])
     assert 2.9e6 < n_dense < 3.1e6 and sum(int(np.prod(s)) for s in shapes.values()) == n_dense + 46000 * 117 + 461 * 37 + 23 * 17 + 12 * 14 + 29 * 18
 
 
