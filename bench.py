@@ -142,6 +142,8 @@ def gemm_symbol(r):
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
         return "void k_dm_mulpred_fused<%d>(DmfParams)" % (2 if r.get('bf16') else (1 if r.get('h2out') else 0))
+    if r.get('h2w'):      # ... NT form on the 64-byte-source-piece kernel (round 5)
+        return "void gemm_h2w_kernel<%d>(H2Params)" % epi
     if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
         return "void gemm_h2_kernel<%s, %d>(H2Params)" % (tf(bool(r['transA'])), epi)
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)

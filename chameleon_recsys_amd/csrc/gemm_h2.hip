@@ -124,6 +124,32 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
         const int limM = p.M - m0, limN = p.N - n0;
         const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
         const __amdgpu_buffer_rsrc_t dw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
+        if (limM >= wm0 + TM * 32 && limN >= wn0 + TNN * 32) {
+            // interior wave tile (wave-uniform test; round 5): the row part of an element's address is uniform - c(e) * ld with
+            // c(e) = (e & 3) + 8 (e >> 2) - and rides in the SGPR soffset of the buffer instructions, one VGPR offset per 32x32 block
+            // and matrix: no per-element address arithmetic or range selects (the generic form below: ~10 VALU per element of an
+            // epilogue that is VALU-bound; same device as gemm_epilogue's interior path)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNN; ++j) {
+                    const unsigned col = (unsigned)(wn0 + j * 32 + fl), rowb = (unsigned)(wm0 + i * 32 + 4 * kl);
+                    const unsigned voff = (rowb * (unsigned)p.ldc + col) * 4u, voffr = (rowb * (unsigned)p.ldr + col) * 2u;
+                    unsigned short y[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ce = (e & 3) + 8 * (e >> 2);
+                        y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, voffr, ce * p.ldr * 2, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ce = (e & 3) + 8 * (e >> 2);
+                        const float v = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, voff, ce * p.ldc * 4, 0);
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -309,6 +335,177 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
 }
 
 // ================================================================================================================================
+// NT with 64-BYTE SOURCE PIECES (round 5).  The NT kernel above stages a 16-k chunk per step: an LDS-DMA request of a wave fetches
+// 32 rows x 32 bytes - 32 DIFFERENT 128-byte lines, a quarter of each - and the next quarter of the same lines a step (~2 000 cycles
+// and 1 000 other lines) later, when the 32 KB vector L1 has long dropped them: per step and CU 1 024 line fills = 128 KB through a
+// 64 B / clk L1 fill path = 2 048 cycles, against 1 536 cycles of MFMA work per step (48 x 32) - which is the 2 160 cycles per step
+// the NT forms measured (matrix pipe busy 52 % of the kernel against the TN form's 89 %, whose k-row pieces are 512 contiguous
+// bytes: profiles/r04_h2_sq_counters.txt; profiles/r05_notes.md).  Here a request fetches 16 rows x 64 bytes (two 16-k chunks of a
+// row: half the line fills per byte used, 1 024 cycles per step - under the MFMA time), i.e. the ring holds TWO buffers of a 32-k
+// double chunk D_j = chunks (2j, 2j + 1) instead of four single-chunk stages (same 128 KB):
+//   slab = [256 rows][64 bytes], four 16-byte pieces per row; LDS piece q of row r holds SOURCE piece q ^ ((r >> 2) & 3) (the swizzle
+//   goes on the source address of the lane that owns a destination piece - LDS-DMA writes lane-linear - and again on the fragment
+//   read): a ds_read_b128 of 16 lanes = 16 consecutive rows, one k-piece: bank group (4 r + (x ^ ((r >> 2) & 3))) mod 16, all
+//   different.  k-half h of the double chunk = source pieces 2h, 2h + 1: fragment offset of half 1 = offset of half 0 ^ 32.
+//   step 2j   (half 0 of D_j): top   the B half of D_{j+1} (4 requests; L2-resident operand, 1.5 steps to land)
+//                              P0 | P1 | P2 as above, NO barrier: chunk 2j + 1 sits in the buffer that is being read
+//   step 2j+1 (half 1 of D_j): P0 | P1 | s_waitcnt vmcnt(0) + barrier (D_{j+1} has landed; D_j's last fragment reads are behind
+//                              every wave) | the A half of D_{j+2} into D_j's buffer (4 requests; the HBM-streamed operand, 2 steps
+//                              to land) | P2 reads the early fragments of chunk 2j + 2 from D_{j+1}
+// One barrier per TWO steps, 8 DMA requests per two steps as before.  K % 32 == 0 (the caller keeps the kernel above otherwise).
+#define H2W_SLAB 16384
+#define H2W_BUF (4 * H2W_SLAB)
+
+// four requests: (r0 @ v0 -> l0), (r0 @ v1 -> l0 + 1024), (r1 @ v0 -> l1), (r1 @ v1 -> l1 + 1024): the two 16-row halves of a wave's
+// 32 rows in the h plane's slab and in the l plane's slab
+__device__ __forceinline__ void h2w_dma4(unsigned l0, unsigned l1, unsigned v0, unsigned v1, const u32x4& r0, const u32x4& r1) {
+    unsigned keep;
+    const unsigned l0b = l0 + 1024u, l1b = l1 + 1024u;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, 0 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, 0 offen lds\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, 0 offen lds\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(l0), "s"(l0b), "s"(l1), "s"(l1b), "v"(v0), "v"(v1), "s"(r0), "s"(r1)
+        : "memory");
+}
+
+// EPI: 0 plain, 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_h2w_kernel(H2Params p) {
+    constexpr int BM = 256, BN = 256, TM = 4, TNN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char h2_smem[];
+
+    const int nwg = p.nbm * p.nbn;
+    const int id = blockIdx.x;
+    const int q8 = nwg / 8, rr = nwg % 8, xcd = id % 8;       // XCD-aware bijective swizzle: the column tiles of an A panel share an L2
+    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + id / 8;
+    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nd = p.K >> 5;                                   // double chunks
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+    // ---- descriptors (one per plane: rows beyond the operand arrive as zeros) and per-lane source offsets
+    u32x4 ra[2], rb[2];
+    const size_t aall = (size_t)max(p.M - m0, 0) * p.lda * 2, ball = (size_t)max(p.N - n0, 0) * p.ldb * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda, (unsigned)min(aall, (size_t)0xFFFFFFF0u));
+        rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)n0 * p.ldb, (unsigned)min(ball, (size_t)0xFFFFFFF0u));
+    }
+    // lane l of wave w, request half r: LDS piece (row 32 w + 16 r + l / 4, piece l & 3) <- source piece (l & 3) ^ ((row >> 2) & 3),
+    // and (row >> 2) & 3 == (l >> 4) & 3 for every w, r
+    const unsigned row = 32u * (unsigned)wave + (unsigned)(lane >> 2), sp = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+    unsigned va0 = (row * (unsigned)p.lda + 8u * sp) * 2u, va1 = va0 + 16u * (unsigned)p.lda * 2u;
+    unsigned vb0 = (row * (unsigned)p.ldb + 8u * sp) * 2u, vb1 = vb0 + 16u * (unsigned)p.ldb * 2u;
+
+    // ---- per-lane fragment offsets inside a slab, k-half 0 (half 1: ^ 32)
+    unsigned fa0[TM], fb0[TNN], fa1[TM], fb1[TNN];
+    {
+        const int l31 = lane & 31;
+        const unsigned fo = (unsigned)l31 * 64u + (unsigned)((lane >> 5) ^ ((l31 >> 2) & 3)) * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { fa0[i] = (unsigned)(wm0 + 32 * i) * 64u + fo; fa1[i] = fa0[i] ^ 32u; }
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) { fb0[j] = (unsigned)(wn0 + 32 * j) * 64u + fo; fb1[j] = fb0[j] ^ 32u; }
+    }
+
+    floatx16 acc[TM][TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)h2_smem;
+    const unsigned wave_off = (unsigned)wave * 2048u;
+    half8 AH[TM], AL[TM], BH[TNN], BL[TNN];
+
+    auto mma = [&](const half8 (&X)[TM], const half8 (&Y)[TNN]) {
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[ii], Y[j], acc[ii][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto dma_a = [&](unsigned buf) {          // (A_h, A_l) of the next double chunk of A
+        h2w_dma4(lds_base + buf + 0 * H2W_SLAB + wave_off, lds_base + buf + 1 * H2W_SLAB + wave_off, va0, va1, ra[0], ra[1]);
+        va0 += 64u; va1 += 64u;
+    };
+    auto dma_b = [&](unsigned buf) {          // (B_h, B_l)
+        h2w_dma4(lds_base + buf + 2 * H2W_SLAB + wave_off, lds_base + buf + 3 * H2W_SLAB + wave_off, vb0, vb1, rb[0], rb[1]);
+        vb0 += 64u; vb1 += 64u;
+    };
+
+    if (nd > 0) {
+        // prologue: D_0 whole, the A half of D_1 (its B half goes out at the top of step 0, like every D_{j+1})
+        dma_a(0u); dma_b(0u);
+        if (nd > 1) {
+            dma_a((unsigned)H2W_BUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        h2_barrier();
+        {   // early fragments of chunk 0
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) BH[j] = *reinterpret_cast<const half8*>(h2_smem + 2 * H2W_SLAB + fb0[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) AL[i] = *reinterpret_cast<const half8*>(h2_smem + 1 * H2W_SLAB + fa0[i]);
+        }
+        for (int j = 0; j < nd; ++j) {
+            const unsigned b0 = (unsigned)(j & 1) * (unsigned)H2W_BUF, b1 = (unsigned)H2W_BUF - b0;
+            const unsigned char* S0 = h2_smem + b0;           // D_j
+            const unsigned char* S1 = h2_smem + b1;           // D_{j+1}
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- step 2j: k-half 0 of D_j.  top: the B half of D_{j+1} (its buffer's last B reads - late fragments of chunk 2j - 1 -
+            // are behind the barrier of step 2j - 1)
+            if (j + 1 < nd) dma_b(b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AH[ii] = *reinterpret_cast<const half8*>(S0 + 0 * H2W_SLAB + fa0[ii]);
+#pragma unroll
+            for (int jn = 0; jn < TNN; ++jn) BL[jn] = *reinterpret_cast<const half8*>(S0 + 3 * H2W_SLAB + fb0[jn]);
+            mma(AL, BH);                                       // P0: A_l x B_h
+            mma(AH, BH);                                       // P1: A_h x B_h
+#pragma unroll
+            for (int jn = 0; jn < TNN; ++jn) BH[jn] = *reinterpret_cast<const half8*>(S0 + 2 * H2W_SLAB + fb1[jn]);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AL[ii] = *reinterpret_cast<const half8*>(S0 + 1 * H2W_SLAB + fa1[ii]);
+            mma(AH, BL);                                       // P2: A_h x B_l; early fragments of chunk 2j + 1 (same buffer: no barrier)
+            // ---- step 2j + 1: k-half 1 of D_j
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AH[ii] = *reinterpret_cast<const half8*>(S0 + 0 * H2W_SLAB + fa1[ii]);
+#pragma unroll
+            for (int jn = 0; jn < TNN; ++jn) BL[jn] = *reinterpret_cast<const half8*>(S0 + 3 * H2W_SLAB + fb1[jn]);
+            mma(AL, BH);
+            mma(AH, BH);
+            // mid: every request of this wave for D_{j+1} has landed; after the barrier every wave's have, and every wave is past its last
+            // fragment read of D_j
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            h2_barrier();
+            if (j + 2 < nd) dma_a(b0);                         // the A half of D_{j+2} into D_j's buffer
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jn = 0; jn < TNN; ++jn) BH[jn] = *reinterpret_cast<const half8*>(S1 + 2 * H2W_SLAB + fb0[jn]);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) AL[ii] = *reinterpret_cast<const half8*>(S1 + 1 * H2W_SLAB + fa0[ii]);
+            mma(AH, BL);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
+    }
+
+    h2_epilogue<EPI, TM, TNN>(p, acc, m0, n0, wm0, wn0, 0, lane);
+}
+
+// ================================================================================================================================
 // Scales.  A record (H2Scale, 32 bytes, zero-initialised once by the caller) receives {scale, 1 / scale, bound}; words 4-6 are the
 // kernels' scratch (running maxima as the bit patterns of non-negative floats - monotone as unsigned integers - and a ticket): every
 // workgroup folds its maximum in with atomicMax (order-independent: bit-reproducible), the LAST one to finish - atomic ticket behind a
@@ -468,10 +665,25 @@ extern "C" int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, lo
     return CHAM_OK;
 }
 
-// launch counters: [0] NT launches, [1] TN launches, [6] epilogue and [7] K-splits of the last launch
+// launch counters: [0] NT launches, [1] TN launches, [2] NT launches on the 64-byte-piece kernel, [6] epilogue and [7] K-splits of the last launch
 static long long g_h2_launches[8];
 extern "C" void cham_gemm_h2_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_h2_launches[i]; if (reset) g_h2_launches[i] = 0; }
+}
+
+// NT launches take the 64-byte-piece kernel (gemm_h2w_kernel) when K % 32 == 0, unless switched off (A/B arm, tests): counter [2]
+static int g_h2_nt_wide = 1;
+extern "C" int cham_gemm_h2_set_nt_wide(int on) { const int was = g_h2_nt_wide; g_h2_nt_wide = on ? 1 : 0; return was; }
+
+template <int EPI>
+static int h2w_launch(H2Params& p, hipStream_t st) {
+    g_h2_launches[6] = EPI; g_h2_launches[7] = 1; ++g_h2_launches[2];
+    constexpr int smem = 2 * H2W_BUF;
+    auto k = gemm_h2w_kernel<EPI>;
+    CHAM_SET_DYNAMIC_LDS(k, smem);
+    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
 }
 
 template <bool TN, int EPI>
@@ -512,6 +724,11 @@ extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, co
         if (dref_h && (bias || act != ACT_NONE || dact != ACT_LEAKY)) return -CHAM_ERR_ARG;
         if (act != ACT_NONE && !(bias && act == ACT_TANH)) return -CHAM_ERR_ARG;
         ++g_h2_launches[0];
+        if (g_h2_nt_wide && (K & 31) == 0) {
+            if (dref_h) return h2w_launch<3>(p, st);
+            if (bias) return act == ACT_TANH ? h2w_launch<2>(p, st) : h2w_launch<5>(p, st);
+            return h2w_launch<0>(p, st);
+        }
         if (dref_h) return h2_launch<false, 3>(p, st);
         if (bias) return act == ACT_TANH ? h2_launch<false, 2>(p, st) : h2_launch<false, 5>(p, st);
         return h2_launch<false, 0>(p, st);

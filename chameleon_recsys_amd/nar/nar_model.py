@@ -198,6 +198,9 @@ class NARRuntime:
         # from a bound of the matrix, THREE plane products instead of six - the kernels were power-limited, so halving the MFMA count is
         # what moves them; same float64-error bar as the six-product form (tests/test_gemm_h2_gpu.py).  CHAM_GEMM_H2=0: the three-bf16-plane arm
         self.h2 = self.p3 and os.environ.get("CHAM_GEMM_H2", "1") == "1"
+        # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
+        # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A library-wide setting.
+        self.lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -514,17 +517,19 @@ class NARRuntime:
             ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
         prof = self.profile
         if prof is not None:
+            import ctypes
+            c0 = (ctypes.c_longlong * 8)()
+            self.lib.cham_gemm_h2_launch_counts(c0, 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         check(self.lib.cham_gemm_h2(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
                                     ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_h2")
         if prof is not None:
             e1.record()
-            import ctypes
             c = (ctypes.c_longlong * 8)()
             self.lib.cham_gemm_h2_launch_counts(c, 0)
             prof.append(dict(M=M, N=N, K=K, transA=tn, transB=0 if tn else 1, splits=int(c[7]), act=act, dref=dref_h is not None, dact=dact,
-                             bias=bias is not None, rowscale=False, bf16=False, h2=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
+                             bias=bias is not None, rowscale=False, bf16=False, h2=True, h2w=bool(c[2] > c0[2]), tile=0, epi=int(c[6]), ev=(e0, e1)))
 
     def _tile_counts_b16(self):
         import ctypes

@@ -188,7 +188,10 @@ int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plan
  *   cham_gemm_h2: A, B = plane 0 (h) of each operand, the l plane `*_plane_stride` ELEMENTS further; a_scale / b_scale = the operands'
  *   records; tn / epilogues / split-K / return codes exactly as cham_gemm_p3 (dref_h = the fp16 h plane of the saved activation: its sign
  *   is kept even where the value underflows).  cham_gemm_h2_launch_counts: out8[0] / out8[1] = NT / TN launches since the last reset,
- *   out8[6] / out8[7] = epilogue variant / K-splits of the last launch. */
+ *   out8[2] = the NT launches among them that ran the 64-byte-source-piece kernel (round 5: K % 32 == 0; two 16-k chunks of a row per
+ *   LDS-DMA request, half the L1 line fills per byte used), out8[6] / out8[7] = epilogue variant / K-splits of the last launch.
+ *   cham_gemm_h2_set_nt_wide(on): 1 (default) = NT launches with K % 32 == 0 take that kernel, 0 = always the 32-byte-piece kernel of
+ *   round 4 (A/B arm; results are bit-identical: same products, same summation order); returns the previous setting. */
 int cham_h2_scale_absmax(const float* x0, size_t n0, const float* x1, size_t n1, void* rec, void* stream);
 int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream);
 int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
@@ -197,6 +200,7 @@ int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* 
                  const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr,
                  int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 void cham_gemm_h2_launch_counts(long long* out8, int reset);
+int cham_gemm_h2_set_nt_wide(int on);
 /* producers of two-plane matrices (csrc/scorer.hip, csrc/dm_fused.hip): cham_combine_fwd_p3 / cham_mulpred_bwd_p3 / cham_dm_mulpred_p3
  * with the output written as (h, l) fp16 planes x the scale of `scale_rec` (filled BEFORE the call: max|U| + max|V| for the PreCAR output,
  * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */

@@ -19,7 +19,7 @@ a, b = steps[-3], steps[-2]
 step = rows[a:b]
 t0 = step[0]['s']
 print("step wall %.3f ms, %d kernels, sum of kernel time %.3f ms" % ((rows[b]['s'] - t0) / 1e6, len(step), sum(r['e'] - r['s'] for r in step) / 1e6))
-isg = lambda r: any(k in r['Kernel_Name'] for k in ('gemm_f32_kernel', 'gemm_bf16_kernel', 'gemm_x3_kernel', 'gemm_b16_kernel', 'gemm_p3_kernel', 'gemm_h2_kernel', 'gemm_b1_kernel'))
+isg = lambda r: any(k in r['Kernel_Name'] for k in ('gemm_f32_kernel', 'gemm_bf16_kernel', 'gemm_x3_kernel', 'gemm_b16_kernel', 'gemm_p3_kernel', 'gemm_h2_kernel', 'gemm_h2w_kernel', 'gemm_b1_kernel'))
 # union of GEMM-active intervals
 iv = sorted((r['s'], r['e']) for r in step if isg(r))
 merged = []

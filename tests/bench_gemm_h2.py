@@ -1,7 +1,7 @@
 """Manual tool (not a test): the two-fp16-plane GEMM (csrc/gemm_h2.hip, three plane products) next to the three-bf16-plane one
 (csrc/gemm_p3.hip, six products) at the three CAR shapes of the G1 step - time, fp32-equivalent TFLOP/s, fraction of the plane-product
 ceilings (2500 / 3 and 2500 / 6 TFLOP/s), error against float64 next to the native fp32 MFMA's.  python -m tests.bench_gemm_h2 [rows]
-H2_ONLY=1: only the h2 kernels, few launches (PMC passes: scripts/h2_pmc.sh)."""
+H2_ONLY=1: only the h2 kernels, few launches (PMC passes: scripts/h2_pmc.sh).  H2_NT_WIDE=0: the NT forms on round 4's 32-byte-piece kernel."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +26,7 @@ def timed(fn, n=10):
 
 def main():
     lib = _lib.load()
+    lib.cham_gemm_h2_set_nt_wide(int(os.environ.get("H2_NT_WIDE", "1")))       # NT forms: 64-byte-source-piece kernel (1, default) or round 4's (0)
     dev = torch.device("cuda:0")
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 248064
     C = 1024

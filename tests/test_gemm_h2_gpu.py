@@ -56,8 +56,15 @@ def _gemm(lib, Ap, a_ps, lda, ra, Bp, b_ps, ldb, rb, tn, C, ldc, M, N, K, bias=N
                            accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, torch.cuda.current_stream().cuda_stream), "cham_gemm_h2")
 
 
-def _nt(gpu, M, N, K, bias=False, act=0, dref=False, seed=0, scale=1.0, check_ref=True, reps=1, row_spread=0.0):
+def _nt(gpu, M, N, K, bias=False, act=0, dref=False, seed=0, scale=1.0, check_ref=True, reps=1, row_spread=0.0, wide=None):
+    """wide: None = the library's current NT kernel choice; 0 / 1 = force the 32-byte-piece (round 4) / 64-byte-piece (round 5) kernel."""
     lib = _lib_()
+    if wide is not None:
+        was = lib.cham_gemm_h2_set_nt_wide(int(wide))
+        try:
+            return _nt(gpu, M, N, K, bias, act, dref, seed, scale, check_ref, reps, row_spread)
+        finally:
+            lib.cham_gemm_h2_set_nt_wide(was)
     g = torch.Generator(device=gpu).manual_seed(seed)
     A = torch.randn(M, K, device=gpu, generator=g) * scale
     if row_spread:
@@ -155,6 +162,34 @@ def test_h2_nt(gpu, M, N, K):
     assert _nt(gpu, M, N, K, bias=True, act=2) < 5e-5
     assert _nt(gpu, M, N, K, bias=True) < 5e-5
     assert _nt(gpu, M, N, K, dref=True) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 256, 64), (256, 256, 96), (512, 512, 128), (300, 260, 96), (1000, 1024, 1024), (77, 520, 416),
+                                   (1, 4, 32), (513, 256, 1024), (4096, 1024, 1024)])
+def test_h2_nt_wide_pieces_bit_identical_to_narrow(gpu, M, N, K):
+    """gemm_h2w_kernel (64-byte source pieces: two 16-k chunks of a row per LDS-DMA request, two 32-k buffers, one barrier per two steps)
+    against gemm_h2_kernel<false> (32-byte pieces, four 16-k stages): the same three plane products per chunk in the same order, so the
+    outputs must be BIT-identical - every epilogue, ragged rows / columns (descriptor range checks of the new piece map), one to 32
+    double chunks (prologue / branchy tail of the ring), repeated launches (race screen: a fragment read overtaking its DMA is noise)."""
+    lib = _lib_()
+    for kw in (dict(), dict(bias=True, act=2), dict(bias=True), dict(dref=True)):
+        _counts(lib, reset=True)
+        a = _nt(gpu, M, N, K, check_ref=False, wide=0, seed=11, **kw)
+        assert _counts(lib)[2] == 0
+        b = _nt(gpu, M, N, K, check_ref=False, wide=1, seed=11, reps=3, **kw)
+        assert _counts(lib)[2] == 3, _counts(lib)
+        assert torch.equal(a, b), (kw, float((a - b).abs().max()))
+        assert _nt(gpu, M, N, K, wide=1, seed=11, **kw) < 5e-5
+
+
+def test_h2_nt_wide_is_the_default_and_needs_k_mod_32(gpu):
+    lib = _lib_()
+    assert lib.cham_gemm_h2_set_nt_wide(1) in (0, 1)
+    _counts(lib, reset=True)
+    _nt(gpu, 256, 256, 64, check_ref=False)
+    _nt(gpu, 256, 256, 48, check_ref=False)          # K % 32 != 0: the 32-byte-piece kernel keeps it
+    c = _counts(lib)
+    assert c[0] == 2 and c[2] == 1, c
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16), (256, 256, 40), (256, 256, 70), (256, 512, 777), (512, 256, 3001), (1024, 1024, 5000), (256, 256, 1)])
@@ -267,7 +302,7 @@ def test_h2_big_car_forward_and_dgrad(gpu):
     print("CAR dgrad: two-plane fp16 %.2e, native fp32 MFMA %.2e (of max)" % (e_h2, e_nat))
     assert e_h2 < 5e-5 and e_h2 < 1.5 * e_nat + 1e-7, (e_h2, e_nat)
     c = _counts(lib)
-    assert c[0] == 2 and c[1] == 0, c
+    assert c[0] == 2 and c[1] == 0 and c[2] == 2, c          # both NT launches on the 64-byte-piece kernel (K = 1024)
 
 
 def test_h2_big_w2_wgrad_splitk(gpu):
