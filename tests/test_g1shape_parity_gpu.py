@@ -112,8 +112,7 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, 
 
 
 def _g1_params(B, **over):
-    return synthetic.default_params(46000, 250, seq_len=20, batch_size=B, neg=50, neg_from_buffer=3000, buffer_size=20000,
-                                    for_norm=2000, C=1024, H=255, **over)
+    return H.g1_params(B, **over)
 
 
 def x3_counts(lib, reset=False):
@@ -330,76 +329,80 @@ def _dump_curve(name, payload):
 
 def test_loss_curve_g1_shape_and_hitrate(gpu):
     """north_star: "loss curve matching CPU reference within 1e-3" over the horizon SURVEY 7.5 names - 200 consecutive optimizer steps at
-    the G1 widths (64 sessions of G1-like lengths per step - at 32 the loss is a mean over ~100 positions and BOTH fp32 arms leave 1e-3 by
-    step 13, measured - shipped lr 1e-4, the recent-clicks state evolving, nar_trainer_gcom.py:511-525)
-    from the same initial weights.  The oracle runs ONE trajectory; two HIP runtimes follow it free-running (no re-synchronisation of
-    weights): the default arithmetic (two-fp16-plane CAR GEMMs + bf16x3 elsewhere) and every GEMM on the native fp32 MFMA.  Negatives
-    bit-exact at every step on both.
-    Loss: two correct fp32 trainers drift apart under Adam (an entry whose gradient is roundoff moves by +-lr per step in either run; a
-    leaky-ReLU branch decided differently within an ulp of zero moves a small tensor's gradient by 1e-3) and the drift is chaotic: the
-    NATIVE fp32 MFMA arm is 2.8e-2 away from the oracle at step 148 (measured on MI355X, round 4).  So: 1e-3 asserted for the first 20 steps
-    (measured to hold for 38-43 steps on either arm in the recorded runs, profiles/r04_loss_curve_*.json), 3e-3 through step 30, 6e-3 through
-    step 50, a sanity bound of 0.1 (3 % of the loss) after that - and the statement that matters, on both arms' whole curves:
-    the default arithmetic's worst deviation so far never exceeds 6 x the native arm's + 1e-3 (measured worst ratio 3.6, final 0.56), and its mean deviation over the 200 steps
-    is within 2.5 x the native arm's + 5e-4 (the two arms are two realisations of the same drift; see the comment at the assertion).
-    The curve is written to gpurun_out/loss_curve_200.json.
-    Horizon: 200 steps (CHAM_CURVE_STEPS), 8 minutes on the GPU box, almost all of it the CPU oracle (2.4 s per step on 32 host threads) -
-    the whole `-m gpu` suite then takes ~830 of the driver's 1 200 s.  Safety valve for a slower host: the curve is time-boxed at
-    CHAM_CURVE_SECONDS (560) and stops early - never before step 100 - instead of running the suite out of its budget; every assertion
-    is on running maxima / means, i.e. holds on any prefix (the full 200-step curve of round 4: profiles/r04_loss_curve_200.json).
+    the G1 widths (64 sessions of G1-like lengths per step, shipped lr 1e-4, the recent-clicks state evolving,
+    nar_trainer_gcom.py:511-525) from the same initial weights - adjudicated by a FLOAT64 trajectory.
+
+    tests/golden/loss_curve_200.npz (oracle/make_loss_curve.py, generated in the build container: the CPU oracle no longer runs 200 steps
+    inside the GPU suite) holds the oracle's per-step loss in float64 and in FOUR float32 realisations (the oracle as every parity test
+    uses it + three with every contraction summed in a permuted order).  What it shows, before any HIP kernel is involved: every fp32
+    realisation of the ORACLE ITSELF leaves 1e-3 of the float64 curve after 37-42 steps and is 2.1e-2 ... 3.7e-2 away at its worst
+    (mean 2.7e-3 ... 4.7e-3) - under TF-Adam an entry whose gradient is roundoff moves by +-lr per step in either run, and the
+    difference is amplified chaotically.  "Within 1e-3 for 200 steps" is therefore not a property any fp32 implementation of this
+    training loop can have (TensorFlow's own Eigen kernels included); the criterion that CAN fail is stated against the spread of the
+    fp32 realisations:
+      * every step i of the 200: |HIP - f64|_i <= 4 x E_i + 1e-4, E_i = running max over steps <= i of the largest |oracle_f32 - f64| of
+        the four realisations (leave-one-out among the oracle's own four arms: worst 2.78 x the other three's running max - the factor 2
+        of the round-4 verdict is exceeded by the oracle itself; 4 leaves ~1.4 x room), both HIP arms (default two-fp16-plane arithmetic
+        and every GEMM on the native fp32 MFMA);
+      * plain 1e-3 for the first 25 steps (the fp32 realisations: <= 2.0e-4 by step 20, 5.7e-4 by step 30) and the step up to which
+        1e-3 holds printed for all six curves;
+      * mean |HIP - f64| <= 2 x the worst realisation's mean + 1e-4;
+      * negatives bit-exact at every step (SHA-1 of the drawn ids against the fixture: the integer path of all five oracle arms);
+      * and, because a free-running comparison cannot see a systematic error below the drift, the TIGHT criterion at steps
+        0, 50, 100, 150 and 199 of the default arm's own trajectory: the oracle (fp32) is loaded with the HIP weights of that step and
+        both evaluate that step's batch - logits / loss within 1e-3 (measured ~1e-6), every gradient tensor within 1e-4 relative L2
+        (compare_step_large, the per-step parity criterion) - the HIP step is as exact on trained weights as on the initial ones.
     Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric): the
-    HIP path, the oracle trained separately, and the oracle evaluating the HIP-trained weights (the eval path alone: must agree to the
-    last hit)."""
+    HIP-trained weights evaluated by the HIP path and by the oracle (the eval path alone: at most one tie broken differently), and
+    against the fixture's five oracle-trained values (0.3389 ... 0.3507: two trainings differ by the same drift)."""
+    import hashlib
     from chameleon_recsys_amd.nar import metrics
     from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel
     from oracle.nar_oracle import NAROracle
-    B, STEPS = 64, int(os.environ.get("CHAM_CURVE_STEPS", "200"))
-    time_box = float(os.environ.get("CHAM_CURVE_SECONDS", "560"))
-    p = _g1_params(B)
-    batches = synthetic.make_batches(2 + STEPS + 4, B, 20, 46000, p['session_features_config'], length_dist='g1', sessions_per_hour=4 * B, seed=21)
-    st = H.warm_state(p, batches[:2])
-    model, orc = H.make_pair(p, seed=13)
-    native, _ = H.make_pair(_g1_params(B, gemm_dtype='f32_native'), seed=13)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_curve_200.npz"))
+    B, STEPS = H.LOSS_CURVE['B'], int(os.environ.get("CHAM_CURVE_STEPS", str(H.LOSS_CURVE['steps'])))
+    f64, f32 = fx['loss_f64'], fx['loss_f32']
+    assert STEPS <= len(f64) and f32.shape == (4, len(f64))
+    env = np.maximum.accumulate(np.abs(f32 - f64[None]).max(0))
+    p, batches, st, w = H.loss_curve_setup()
+    model, _ = H.make_pair(p, seed=H.LOSS_CURVE['weight_seed'])
+    native, _ = H.make_pair(H.g1_params(B, gemm_dtype='f32_native'), seed=H.LOSS_CURVE['weight_seed'])
     assert model.rt.h2 and not native.rt.x3
+    assert all(np.array_equal(w[k], v) for k, v in model.rt.logical_weights().items())          # the fixture's initial weights
     dev = {"default": [], "native": []}
-    oracle_loss = []
-    t_start, TOTAL = time.time(), STEPS
-    for i, (f, l) in enumerate(batches[2:2 + TOTAL]):
-        if i >= 100 and time.time() - t_start > time_box:
-            print("loss curve stopped after %d of %d steps: %.0f s of wall time (CHAM_CURVE_SECONDS)" % (i, STEPS, time.time() - t_start))
-            STEPS = i
-            break
+    CHECK = (0, 50, 100, 150, STEPS - 1)
+    t_start = time.time()
+    for i, (f, l) in enumerate(batches[2:2 + STEPS]):
+        if i in CHECK:      # the tight one-step criterion on the weights the default arm has reached
+            orc_k = NAROracle(p, weights=model.rt.logical_weights())
+            orc_k.global_step = model.rt.global_step            # (the sampler is keyed by the step)
+            flips = compare_step_large(model, orc_k, f, l, st)
+            print("step %d: one optimizer step from the HIP-trained weights against the oracle on the same weights: ok (%d kink flips)" % (i, flips))
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
-        ref = orc.train_step(f, l, buf, pop)
-        oracle_loss.append(float(ref['total_loss']))
         for name, m in (("default", model), ("native", native)):
             m.feed_state(pop, buf)
             loss = m.train_step(m.upload_batch(f, l)).cpu().numpy()
-            assert np.array_equal(m._plan.neg_ids.cpu().numpy(), ref['neg_items'].numpy()), "step %d (%s): negative samples differ" % (i, name)
-            d = abs(float(loss[0]) - float(ref['total_loss']))
+            sha = hashlib.sha1(np.ascontiguousarray(m._plan.neg_ids.cpu().numpy().astype(np.int64)).tobytes()).hexdigest()
+            assert sha == str(fx['neg_sha1'][i]), "step %d (%s): negative samples differ from the oracle's" % (i, name)
+            d = abs(float(loss[0]) - float(f64[i]))
             dev[name].append(d)
-            # the deviation grows ~10 x per 10 steps until it saturates near 1e-2 (both arms, two recorded runs: <= 1.3e-4 before step 20,
-            # <= 8.2e-4 before step 30, <= 1.8e-3 before step 50): bounds with >= 3 x room over those, 1e-3 itself for the first 20 steps
-            bound = LOGIT_TOL if i < 20 else (3 * LOGIT_TOL if i < 30 else (6 * LOGIT_TOL if i < 50 else 0.1))
-            assert d < bound, "step %d (%s): loss %r vs oracle %g" % (i, name, loss, float(ref['total_loss']))
+            assert d <= 4.0 * env[i] + 1e-4, "step %d (%s): |loss - f64| %.3e, fp32 realisations of the oracle so far <= %.3e" % (i, name, d, env[i])
+            assert i >= 25 or d < LOGIT_TOL, "step %d (%s): loss %r vs float64 oracle %.6f" % (i, name, loss, float(f64[i]))
         H.update_state(st, f, l)
-    w_def, w_nat = max(dev["default"]), max(dev["native"])
-    within = lambda x: next((i for i, d in enumerate(x) if d >= LOGIT_TOL), STEPS)
-    print("%d-step loss curve: worst |loss - oracle| default %.2e (1e-3 held for %d steps), native fp32 MFMA %.2e (%d steps); final loss %.5f"
-          % (STEPS, w_def, within(dev["default"]), w_nat, within(dev["native"]), float(loss[0])))
-    _dump_curve("loss_curve_%d.json" % STEPS, dict(batch=B, steps=STEPS, oracle_loss=oracle_loss, abs_dev_default=dev["default"], abs_dev_native=dev["native"],
-                                            held_1e3_default=within(dev["default"]), held_1e3_native=within(dev["native"])))
-    # the default arithmetic's drift is the native fp32 MFMA's drift: both arms are realisations of the same chaotic amplification of
-    # fp32 rounding noise along the oracle's trajectory, so the RATIO of their running maxima wanders (measured on MI355X: 3.96e-3 vs
-    # 2.38e-3 at step 58, the other way round earlier in the same run) - bounded at 6 x + 1e-3 at every step (measured: worst 3.6 early, 0.56 at the end; means 3.0e-3 vs 4.4e-3), and the mean deviations at
-    # 2.5 x + 5e-4; a wrong kernel leaves both within a step or two (and breaks the per-step parity tests above)
-    rm_d = np.maximum.accumulate(dev["default"]); rm_n = np.maximum.accumulate(dev["native"])
-    worst_ratio = float(np.max(rm_d / (rm_n + 1e-12)))
-    print("running-max drift ratio default / native: worst %.2f, final %.2f; mean |dev| default %.2e, native %.2e" % (
-        worst_ratio, float(rm_d[-1] / rm_n[-1]), float(np.mean(dev["default"])), float(np.mean(dev["native"]))))
-    bad = np.flatnonzero(rm_d >= 6.0 * rm_n + 1e-3)
-    assert bad.size == 0, "step %d: default arithmetic drifted %.2e, native fp32 %.2e" % (bad[0], rm_d[bad[0]], rm_n[bad[0]])
-    assert float(np.mean(dev["default"])) < 2.5 * float(np.mean(dev["native"])) + 5e-4
+    within = lambda x: int(next((i for i, d in enumerate(x) if d >= LOGIT_TOL), len(x)))
+    held = {"hip default": within(dev["default"]), "hip native fp32 MFMA": within(dev["native"])}
+    held.update({"oracle " + str(a): within(np.abs(r - f64)[:STEPS]) for a, r in zip(fx['f32_arms'], f32)})
+    print("%d-step loss curve against the float64 oracle (%.0f s): 1e-3 holds for %r steps; worst |dev| default %.2e native %.2e, fp32 oracle arms %s; "
+          "mean default %.2e native %.2e, arms %s" % (STEPS, time.time() - t_start, held, max(dev["default"]), max(dev["native"]),
+                                                      ["%.2e" % x for x in np.abs(f32 - f64[None])[:, :STEPS].max(1)], float(np.mean(dev["default"])),
+                                                      float(np.mean(dev["native"])), ["%.2e" % x for x in np.abs(f32 - f64[None])[:, :STEPS].mean(1)]))
+    worst_mean = float(np.abs(f32 - f64[None])[:, :STEPS].mean(1).max())
+    for name in dev:
+        assert float(np.mean(dev[name])) <= 2.0 * worst_mean + 1e-4, (name, float(np.mean(dev[name])), worst_mean)
+    _dump_curve("loss_curve_%d.json" % STEPS, dict(batch=B, steps=STEPS, loss_f64=[float(x) for x in f64[:STEPS]], abs_dev_default=dev["default"],
+                                            abs_dev_native=dev["native"], envelope_fp32_oracle=[float(x) for x in env[:STEPS]], held_1e3=held))
+    if STEPS != H.LOSS_CURVE['steps']:
+        return
     ev = NARModuleModel(ModeKeys.EVAL, None, None, p['session_features_config'], p['articles_features_config'], B, p['lr'], 1.0,
                         p['eval_total_negative_samples'], p['eval_negative_samples_from_buffer'], p['content_article_embeddings_matrix'],
                         softmax_temperature=p['softmax_temperature'], reg_weight_decay=p['reg_weight_decay'],
@@ -407,23 +410,25 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
                         recent_clicks_for_normalization=p['recent_clicks_for_normalization'], articles_metadata=p['articles_metadata'],
                         CAR_embedding_size=p['CAR_embedding_size'], rnn_units=p['rnn_units'], runtime=model.rt)
     orc_hw = NAROracle(p, weights=model.rt.logical_weights())
-    m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "oracle", "oracle_on_hip_weights")}
-    for i, (f, l) in enumerate(batches[2 + TOTAL:]):
+    m = {k: (metrics.HitRate(5), metrics.MRR(5)) for k in ("hip", "oracle_on_hip_weights")}
+    for i, (f, l) in enumerate(batches[2 + STEPS:]):
         buf, pop = st.get_recent_clicks_buffer().copy(), st.get_articles_recent_pop_norm().copy()
         ev.feed_state(pop, buf); ev.evaluate_step(ev.upload_batch(f, l))
-        ids = ev.predicted_item_ids.eval()
-        key = NARModuleModel.eval_step_key(orc.global_step, i)
-        preds = {"hip": ids, "oracle": orc.forward(f, l, buf, pop, mode='eval', step=key)['predicted_item_ids'].numpy(),
+        key = NARModuleModel.eval_step_key(model.rt.global_step, i)
+        preds = {"hip": ev.predicted_item_ids.eval(),
                  "oracle_on_hip_weights": orc_hw.forward(f, l, buf, pop, mode='eval', step=key)['predicted_item_ids'].numpy()}
         for k, pred in preds.items():
             m[k][0].add(pred, l['label_next_item']); m[k][1].add(pred, l['label_next_item'])
         H.update_state(st, f, l)
     hr = {k: float(v[0].result()) for k, v in m.items()}
     mrr = {k: float(v[1].result()) for k, v in m.items()}
-    print("HitRate@5 %r MRR@5 %r" % (hr, mrr))
-    n_pos = sum(int((l['label_next_item'] != 0).sum()) for _, l in batches[2 + TOTAL:])
+    hr_ref = [float(fx['hitrate5_f64'])] + [float(x) for x in fx['hitrate5_f32']]
+    mrr_ref = [float(fx['mrr5_f64'])] + [float(x) for x in fx['mrr5_f32']]
+    print("HitRate@5 %r MRR@5 %r; oracle-trained (f64, four fp32 realisations): HitRate@5 %s MRR@5 %s" % (
+        hr, mrr, ["%.4f" % x for x in hr_ref], ["%.4f" % x for x in mrr_ref]))
+    n_pos = sum(int((l['label_next_item'] != 0).sum()) for _, l in batches[2 + STEPS:])
     assert abs(hr["hip"] - hr["oracle_on_hip_weights"]) <= 1.5 / n_pos, hr          # same weights: at most one tie broken differently
-    assert abs(hr["hip"] - hr["oracle"]) < 0.02 and abs(mrr["hip"] - mrr["oracle"]) < 0.02, (hr, mrr)
+    assert min(hr_ref) - 0.02 < hr["hip"] < max(hr_ref) + 0.02 and min(mrr_ref) - 0.02 < mrr["hip"] < max(mrr_ref) + 0.02, (hr, mrr, hr_ref, mrr_ref)
 
 
 def test_loss_curve_50_steps_bf16_g1_shape(gpu):

@@ -6,8 +6,8 @@ Here the SAME optimizer step runs twice on the full-size table: once with the ba
 every non-pad id moved up by 4 500 000 ("high": byte offsets 6.8 - 6.9 GB into the table, 5.1 G into the ACE matrix) and the catalog /
 table rows moved with them.  The remap is monotone (0 stays 0), so the sampler's integer path, every gather, the radix-sorted row
 grouping, the embedding-gradient segments, L2 and TF-Adam see the same values in another place: negatives equal after the remap,
-logits / probabilities / loss, every dense gradient, the touched rows' gradients and post-Adam rows + slots BIT-identical, no row outside
-the remapped set written.  A 32-bit byte offset in a buffer descriptor, a radix sort with too few digit passes for 23-bit ids or an int32
+logits / probabilities / cross-entropy, every dense gradient, the touched rows' gradients and post-Adam rows + slots BIT-identical (the
+L2 loss - a sum over all 1.9 G table entries in another order - to 1e-5), no row outside the remapped set written.  A 32-bit byte offset in a buffer descriptor, a radix sort with too few digit passes for 23-bit ids or an int32
 element index in k_adam_tf / k_sumsq_partial breaks one of these."""
 import gc
 
@@ -112,8 +112,13 @@ def test_item_rows_beyond_4gib_match_the_compact_id_run(gpu):
     hi = _run(OFFSET)
     assert int(hi['rows'][1]) * 378 * 4 > (1 << 32) and int(hi['rows'][1]) * ACE_DIM * 4 > (1 << 31)
     assert np.array_equal(_remap(lo['neg'], OFFSET), hi['neg']), "negatives differ after the id remap"
-    for k in ('logits', 'probs', 'loss'):
+    for k in ('logits', 'probs'):
         assert np.array_equal(lo[k], hi[k]), "%s not bit-identical: max |d| %g" % (k, float(np.abs(lo[k] - hi[k]).max()))
+    # loss = [total, cross-entropy, L2]: the cross-entropy is bit-identical; the L2 term sums the squares of ALL 1.9 G table entries - the
+    # same multiset of values at other positions, i.e. in another order of fp32 partial sums (measured: 1.0303863 vs 1.0303853)
+    assert lo['loss'][1] == hi['loss'][1], (lo['loss'], hi['loss'])
+    assert abs(float(lo['loss'][2]) - float(hi['loss'][2])) <= 1e-5 * float(lo['loss'][2]) and float(lo['loss'][2]) > 0.5, (lo['loss'], hi['loss'])
+    assert abs(float(lo['loss'][0]) - float(hi['loss'][0])) <= 1e-5 * float(lo['loss'][0])
     for k, v in lo['g_dense'].items():
         assert np.array_equal(v, hi['g_dense'][k]), "gradient of %s differs" % k
     assert lo['g_touched'].size > 100 and np.array_equal(_remap(lo['g_touched'], OFFSET), hi['g_touched']), \
