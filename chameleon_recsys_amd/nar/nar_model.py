@@ -238,6 +238,16 @@ class NARRuntime:
         self._side_raw = self.side_stream.cuda_stream
         self.gemm_ws_side = torch.empty(32 << 20, dtype=torch.float32, device=dev)       # split-K partials of the side lane
         self.colsum_ws_side = torch.empty(2 << 20, dtype=torch.float32, device=dev)
+        # third lane (round 5, CHAM_WGRAD_AUX): the small weight / bias gradients of the backward pass leave the side lane, whose W2 weight
+        # gradient then starts the moment the main lane's CAR dgrad has finished instead of behind ~1 ms of small launches
+        self.wgrad_aux = os.environ.get("CHAM_WGRAD_AUX", "1") == "1"
+        self.aux_stream = lane_stream(dev, "aux", 0)
+        self._aux_raw = self.aux_stream.cuda_stream
+        self.gemm_ws_aux = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+        self.colsum_ws_aux = torch.empty(2 << 20, dtype=torch.float32, device=dev)
+        # head of the step (round 5, CHAM_HEAD_SPLIT): the clicked rows' PreCAR combine + CAR layer 2 feed the recurrent branch only - they
+        # run at the head of the side lane instead of in front of the main lane's plane producer and CAR forward GEMM
+        self.head_split = os.environ.get("CHAM_HEAD_SPLIT", "1") == "1"
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"           # CHAM_OVERLAP=0: the same program order on one stream
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
@@ -405,6 +415,15 @@ class NARRuntime:
         self._plans[key] = pl                                      # (re)insert as most recently used
         return pl
 
+    def _lane_ws(self, name):
+        """The split-K / column-sum workspace of the lane (stream) the caller is enqueuing on: lanes run concurrently."""
+        st = _stream()
+        if st == self._side_raw:
+            return getattr(self, name + '_side')
+        if st == self._aux_raw:
+            return getattr(self, name + '_aux')
+        return getattr(self, name)
+
     def warm_plans(self, B, Ts, N, n_buf, Bg=None):
         """Builds the buffer set of every padded length in ``Ts`` now (a trainer's warm-up): hourly session files produce a handful of
         padded lengths T <= truncate_session_length - 1, and the first batch of each would otherwise allocate and zero-fill several GB
@@ -417,7 +436,7 @@ class NARRuntime:
              dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False):
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+            ws = self._lane_ws('gemm_ws')
         prof = self.profile
         bf16 = self.gemm_dtype == 'bf16' and not force_f32
         x3 = self.x3 and not force_f32
@@ -461,7 +480,7 @@ class NARRuntime:
         (cham_gemm_b16_dma; NT with bf16 output / TN with fp32 output, M and N multiples of 256 for TN)."""
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+            ws = self._lane_ws('gemm_ws')
         prof = self.profile
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -494,7 +513,7 @@ class NARRuntime:
         """Plane-product GEMM over pre-split bf16 planes (csrc/gemm_p3.hip): NT (tn=0) or TN (tn=1, split-K)."""
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+            ws = self._lane_ws('gemm_ws')
         prof = self.profile
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -514,7 +533,7 @@ class NARRuntime:
         """Plane-product GEMM over two fp16 planes + scale records (csrc/gemm_h2.hip): NT (tn=0) or TN (tn=1, split-K)."""
         ws = None
         if splits != 1:
-            ws = self.gemm_ws_side if _stream() == self._side_raw else self.gemm_ws
+            ws = self._lane_ws('gemm_ws')
         prof = self.profile
         if prof is not None:
             import ctypes
@@ -538,7 +557,7 @@ class NARRuntime:
         return list(out)
 
     def colsum(self, X, ld, R, F, out, w=None, accumulate=0, b16=False):
-        ws = self.colsum_ws_side if _stream() == self._side_raw else self.colsum_ws
+        ws = self._lane_ws('colsum_ws')
         check((self.lib.cham_colsum_b16 if b16 else self.lib.cham_colsum)(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws),
                                                                            ws.numel() * 4, _stream()), "cham_colsum")
 
@@ -1103,6 +1122,7 @@ class NARModuleModel:
         else:
             rt.refresh_shadows()
         drop = self.is_training and self.keep_prob < 1.0
+        head_split = rt.head_split and rt.overlap
         pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])
         if drop:
             # dropout_keep_prob < 1 (nar_model.py:338, 352, 368): the per-element masks make every CAR row occurrence-specific, so
@@ -1128,10 +1148,16 @@ class NARModuleModel:
             rt.gemm(pl.Xc_s, p('W1c'), pl.U, BT, C, Fc, Fc, C, C, bias=p('b1'))
             rt.gemm(pl.Xi_s, p('W1i'), pl.V, RV, C, Fi, Fi, C, C)
             # PreCAR combine + CAR layer 2 on the clicked-input rows first: they feed the recurrent branch ...
-            check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
-        rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
+            if not head_split:
+                check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, s), "cham_combine_fwd")
+        if not head_split:
+            rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
         rt.fork()
         with rt.side():   # ... which is latency-bound (one workgroup per 32 sessions) and overlaps with ...
+            if head_split:      # (round 5) ... at the head of THIS lane: only the recurrent branch reads the clicked rows' CAR output
+                if not drop:
+                    check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), 0, BT, _stream()), "cham_combine_fwd")
+                rt.gemm(pl.Z1, p('W2'), pl.Z2, BT, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
             x, ldx, K = pl.Z2, C, C
             if pos is not None:          # clicked rows back into the [B, T] layout of the recurrent stack (zeros at padded steps)
                 pl.Z2f.zero_()
@@ -1268,6 +1294,14 @@ class NARModuleModel:
             if on:
                 main_stream.wait_event(ev)
 
+        @contextlib.contextmanager
+        def aux(*events):                # run the block on the third lane after `events`
+            for ev in events:
+                rt.aux_stream.wait_event(ev)
+            with torch.cuda.stream(rt.aux_stream):
+                yield
+        e_auxdone = None
+
         rt.grads[:L.emb_end].zero_()
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
         check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
@@ -1389,6 +1423,9 @@ class NARModuleModel:
             rt.gemm(pl.dZ2[BT:Rall], p('W2'), pl.dZ1[BT:Rall], Rc, C, C, C, C, C, transB=1, dref=pl.Z1[BT:Rall], ldr=C, dact=ACT_LEAKY)
         e_cdgrad = mark()
         w2_main = bool(on and use_p3 and 0 < Rc <= rt.w2_main_rows)
+        # third lane for the small weight gradients (full batches of the default / six-plane fp32 arithmetic, one recurrent layer of the
+        # UGRNN kind: with more layers the per-layer gradients read a buffer the next layer's backward overwrites)
+        use_aux = bool(on and rt.wgrad_aux and use_p3 and not w2_main and not b16 and L.L == 1 and cell == 0 and not L.rnn_stepwise and not drop)
         e_w2main = None
         if w2_main:      # candidate rows' share of the W2 weight gradient here, in the main lane's wait for the side lane's recurrent chain
             w2_wgrad_planes(0)
@@ -1452,7 +1489,7 @@ class NARModuleModel:
                     # 256 workgroups fill every CU's register file for 4 ms) - the main lane's PreCAR backward waits for it ...
                     rt.gemm(pl.dZ2, p('W2'), pl.dZ1, BT, C, C, C, C, C, transB=1, dref=pl.Z1, ldr=C, dact=ACT_LEAKY)
                     e_dZ1in = mark()
-                    if crit_first:
+                    if crit_first and not use_aux:
                         fc_wgrads()
                     if b16:
                         # ... and the CAR layer-2 weight gradient: the candidate rows (bf16, TN) + the clicked-input rows (fp32), runs beside it
@@ -1463,6 +1500,23 @@ class NARModuleModel:
                         else:
                             rt.colsum(dZ2c, C, Rc, C, g('b2'), b16=True)
                         rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
+                    elif use_p3 and use_aux:
+                        # (round 5) the small weight / bias gradients leave this lane for the third one - every producer they read is
+                        # final at e_dZ1in - and the W2 weight gradient (candidate rows from the planes, TN split-K, + the clicked rows)
+                        # starts the moment the main lane's CAR dgrad has finished, not behind ~1 ms of small launches
+                        with aux(e_dZ1in):
+                            if crit_first:
+                                fc_wgrads()
+                            rt.colsum(pl.b2part, C, BT, C, g('b2'))
+                            rt.colsum(pl.dZ2, C, BT, C, g('b2'), accumulate=1)
+                            rt.gemm(pl.Z2, dxp, g('rnn0/Wx'), C, NGH, BT, C, NGH, NGH, transA=1, splits=0)
+                            rt.gemm(pl.hprev[0], pl.dxproj, g('rnn0/Wh'), Hp, 2 * Hp, BTf, Hp, NGH, 2 * Hp, transA=1, splits=0, force_f32=True)
+                            rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn0/b'))
+                            e_auxdone = mark()
+                        rt.side_stream.wait_event(e_cdgrad)
+                        w2_wgrad_planes(rt.p3_w2_splits)
+                        rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
+                        continue
                     elif use_p3:
                         # ... and the CAR layer-2 weight gradient: the candidate rows from their planes (TN, split-K), the clicked-input
                         # rows (fp32) added by the on-the-fly kernel; b2 from the per-position partial sums of k_mulpred_bwd_p3
@@ -1555,6 +1609,8 @@ class NARModuleModel:
             main_wait(e_dZ1in)
         precar_backward(rt.gemm_ws)      # beside the W2 wgrad of the side lane
         rt.join()
+        if e_auxdone is not None:
+            main_stream.wait_event(e_auxdone)
 
     def apply_gradients(self):
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""

@@ -83,7 +83,7 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, 
         gu = g_unpinned if g_unpinned is not None else _oracle_grads(orc)
         wu = ("", 0.0)
         for k, rg in gu.items():
-            if float(np.abs(rg).max()) < 1e-5 * gmax:
+            if float(np.abs(rg).max()) < 1e-5 * gmax or k == 'match4/bias':
                 continue
             e = float(np.abs(g[k].astype(np.float64) - rg).max()) / float(np.abs(rg).max())
             wu = max(wu, (k, e), key=lambda kv: kv[1])
@@ -92,10 +92,12 @@ def compare_step_large(model, orc, f, l, st, logit_tol=LOGIT_TOL, grad_l2=1e-4, 
     for k, v in orc.w.items():
         rg = v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)
         d = g[k].astype(np.float64) - rg
-        if float(np.abs(rg).max()) < 1e-5 * gmax:
-            # the true gradient of this tensor is identically zero (match4/bias: the softmax is shift invariant) - both sides hold
-            # roundoff; only its absolute size can be checked
-            assert float(np.abs(d).max()) < 1e-5 * gmax + 1e-7, "grad %s (zero gradient): |err| %g" % (k, float(np.abs(d).max()))
+        if float(np.abs(rg).max()) < 1e-5 * gmax or k == 'match4/bias':
+            # the true gradient of this tensor is identically zero (match4/bias: the softmax is shift invariant, sum_c (p_c - y_c) = 0 at
+            # every position) - both sides hold roundoff of a sum over all candidate rows (at 64 ragged sessions the oracle's own value is
+            # 2e-5 of the largest gradient); only its absolute size can be checked
+            assert float(np.abs(rg).max()) < 1e-4 * gmax, "grad %s should be roundoff: %g of the largest gradient" % (k, float(np.abs(rg).max()) / gmax)
+            assert float(np.abs(d).max()) < 1e-4 * gmax + 1e-7, "grad %s (zero gradient): |err| %g" % (k, float(np.abs(d).max()))
             continue
         scale = max(1e-6, float(np.abs(rg).max()))
         nrm = float(np.sqrt((rg * rg).sum()))
