@@ -54,7 +54,6 @@ _SIGNATURES = {
     "cham_gemm_h2_launch_counts": (None, [P, c_int]),
     "cham_gemm_h2_set_nt_wide": (c_int, [c_int]),
     "cham_combine_fwd_h2": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, P]),
-    "cham_combine_fwd_h2_range": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, c_int, c_int, P]),
     "cham_mulpred_bwd_h2": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P, P]),
     "cham_dm_mulpred_h2": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
     "cham_dm_mulpred_b16": (c_int, [P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P]),

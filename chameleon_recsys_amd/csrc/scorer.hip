@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void k_combine_fwd_cand_p3(const float* __rest
 __global__ __launch_bounds__(256) void k_combine_fwd_cand_h2(const float* __restrict__ U, const float* __restrict__ V, int C,
                                                              int BT, int N, int pmax, const int* __restrict__ neg_slot,
                                                              _Float16* __restrict__ Z1p /* plane 0, candidate rows */, long long ps,
-                                                             const H2Scale* __restrict__ rec, int bt0 /* first position of this launch */) {
-    const int bt = bt0 + blockIdx.x, NC = N + 1;
+                                                             const H2Scale* __restrict__ rec) {
+    const int bt = blockIdx.x, NC = N + 1;
     const float sc = rec->scale;
     const float4* pu = reinterpret_cast<const float4*>(U + (size_t)bt * C);
     _Float16* po = Z1p + (size_t)bt * NC * C;
@@ -701,21 +701,14 @@ extern "C" int cham_mulpred_bwd_p3(const float* dM, const float* Z2c, const floa
     return CHAM_OK;
 }
 
-// positions [bt_begin, bt_begin + bt_count) of the BT positions only (round 5: the producer of the second half of the candidate rows runs
-// beside the CAR forward GEMM of the first half); same pointers / BT as the whole launch
-extern "C" int cham_combine_fwd_h2_range(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
-                                         long long plane_stride, const void* scale_rec, int bt_begin, int bt_count, void* stream) {
-    if (!U || !V || !neg_slot || !Z1p || !scale_rec || C <= 0 || (C & 3) || BT < 0 || N < 0 || (plane_stride & 3)) return -CHAM_ERR_ARG;
-    if (bt_begin < 0 || bt_count < 0 || bt_begin + bt_count > BT) return -CHAM_ERR_ARG;
-    if (bt_count == 0) return CHAM_OK;
-    hipLaunchKernelGGL(k_combine_fwd_cand_h2, dim3(bt_count), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
-                       reinterpret_cast<_Float16*>(Z1p), plane_stride, reinterpret_cast<const H2Scale*>(scale_rec), bt_begin);
-    CHAM_CHECK_LAUNCH();
-    return CHAM_OK;
-}
 extern "C" int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
                                    long long plane_stride, const void* scale_rec, void* stream) {
-    return cham_combine_fwd_h2_range(U, V, C, BT, N, pmax, neg_slot, Z1p, plane_stride, scale_rec, 0, BT < 0 ? 0 : BT, stream);
+    if (!U || !V || !neg_slot || !Z1p || !scale_rec || C <= 0 || (C & 3) || BT < 0 || N < 0 || (plane_stride & 3)) return -CHAM_ERR_ARG;
+    if (BT == 0) return CHAM_OK;
+    hipLaunchKernelGGL(k_combine_fwd_cand_h2, dim3(BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
+                       reinterpret_cast<_Float16*>(Z1p), plane_stride, reinterpret_cast<const H2Scale*>(scale_rec));
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
 }
 
 extern "C" int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,

@@ -248,11 +248,6 @@ class NARRuntime:
         # head of the step (round 5, CHAM_HEAD_SPLIT): the clicked rows' PreCAR combine + CAR layer 2 feed the recurrent branch only - they
         # run at the head of the side lane instead of in front of the main lane's plane producer and CAR forward GEMM
         self.head_split = os.environ.get("CHAM_HEAD_SPLIT", "1") == "1"
-        self.ws1_late = os.environ.get("CHAM_WS1_LATE", "0") == "1"        # see backward(): the scorer layer-1 weight gradient in the tail
-        # (round 5, CHAM_PIPE_HALVES) full batches: the HBM-bound producers in front of the two NT CAR GEMMs (the plane-writing PreCAR
-        # combine: 1 GB of stores; the fused scorer dgrad: 2 GB) run in two halves of the positions, the second half on the third lane
-        # BESIDE the GEMM over the first half (small-LDS / streaming kernels do share a CU with a plane-GEMM workgroup)
-        self.pipe_halves = os.environ.get("CHAM_PIPE_HALVES", "1") == "1"
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"           # CHAM_OVERLAP=0: the same program order on one stream
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
@@ -1222,31 +1217,13 @@ class NARModuleModel:
                 rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
             elif use_p3 and rt.h2:      # candidate rows straight into two fp16 planes x 2^k, k from the bound max|U| + max|V| (no fp32 copy)
                 check(lib.cham_h2_scale_absmax(ptr(pl.U), BT * C, ptr(pl.V), RV * C, ptr(pl.sc_z1), s), "cham_h2_scale_absmax")
-                halves = rt.pipe_halves and rt.overlap and Rc > rt.w2_main_rows and BT >= 64
-                if halves:      # positions [0, P1) here, [P1, BT) on the third lane beside the GEMM over the first half
-                    P1 = (BT + 1) // 2
-                    check(lib.cham_combine_fwd_h2_range(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, ptr(pl.sc_z1),
-                                                        0, P1, s), "cham_combine_fwd_h2_range")
-                    e_h1 = torch.cuda.Event(); e_h1.record()
-                    rt.aux_stream.wait_event(e_h1)
-                    with torch.cuda.stream(rt.aux_stream):
-                        check(lib.cham_combine_fwd_h2_range(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps,
-                                                            ptr(pl.sc_z1), P1, BT - P1, _stream()), "cham_combine_fwd_h2_range")
-                        e_h2 = torch.cuda.Event(); e_h2.record()
-                else:
-                    check(lib.cham_combine_fwd_h2(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, ptr(pl.sc_z1), s),
-                          "cham_combine_fwd_h2")
+                check(lib.cham_combine_fwd_h2(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, ptr(pl.sc_z1), s),
+                      "cham_combine_fwd_h2")
             elif use_p3:      # candidate rows straight into three bf16 planes (no fp32 copy)
                 check(lib.cham_combine_fwd_p3(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, s), "cham_combine_fwd_p3")
             else:
                 check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
-            if use_p3 and rt.h2 and halves:
-                R1 = P1 * NC
-                rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT:], C, R1, C, C, bias=p('b2'), act=ACT_TANH)
-                torch.cuda.current_stream().wait_event(e_h2)
-                rt.gemm_h2(pl.Z1p[0, R1:], pl.p3_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT + R1:], C, Rc - R1, C, C,
-                           bias=p('b2'), act=ACT_TANH)
-            elif use_p3 and rt.h2:
+            if use_p3 and rt.h2:
                 rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
             elif use_p3:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, rt.w2tp, C * C, C, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
@@ -1388,12 +1365,6 @@ class NARModuleModel:
         # third lane for the small weight gradients (full batches of the default / six-plane fp32 arithmetic, one recurrent layer of the
         # UGRNN kind: with more layers the per-layer gradients read a buffer the next layer's backward overwrites)
         use_aux = bool(on and rt.wgrad_aux and use_p3 and not w2_main and not b16 and L.L == 1 and cell == 0 and not L.rnn_stepwise and not drop)
-        # (round 5) the scorer layer-1 weight gradient (on-the-fly bf16-plane kernel: one 55-110 KB workgroup per CU) does not OVERLAP the fused
-        # scorer dgrad (another one-workgroup-per-CU kernel) - the two time-slice the CUs: 1.2 ms for the pair against 0.71 + 0.52 ms alone
-        # (profiles/r05_notes.md).  With the third lane in use it moves to the tail of the backward, in front of the W2 weight gradient, where
-        # its neighbours are the small-LDS HBM-bound kernels of the PreCAR backward; the fused dgrad then has the chip to itself
-        ws1_late = use_aux and rt.ws1_late
-
         def ws1_wgrad():
             if b16:      # weight gradients: activations^T x gradients, both bf16 [rows, *] (TN through the LDS transpose read)
                 rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
@@ -1402,37 +1373,10 @@ class NARModuleModel:
                 rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
         with side(e_start, e_dS1):
-            if not ws1_late:
-                ws1_wgrad()
+            ws1_wgrad()
             if not crit_first:
                 scorer_small_wgrads()
-        # (round 5) full batches: the fused scorer dgrad (HBM-bound, 2 GB) in two halves of the positions - the second half on the third lane
-        # beside the CAR dgrad GEMM over the first half (forward(): the same for the plane-writing PreCAR combine)
-        halves_b = bool(dm_fused and h2 and on and rt.pipe_halves and Rc > rt.w2_main_rows and BT >= 64)
-        e_dm2 = None
-        if halves_b:
-            P1 = (BT + 1) // 2
-            R1 = P1 * NC
-
-            def dm_half(p0, np_, st_):
-                r0 = p0 * NC
-                prof = rt.profile
-                if prof is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(lib.cham_dm_mulpred_h2(pl.dS1[r0:].data_ptr(), 128, 128, ptr(rt.ws1p), C * 128, Z2c[r0:].data_ptr(), pl.pred[p0:].data_ptr(), C,
-                                             np_, N, pl.dZ2p[0, r0:].data_ptr(), pl.p3_ps, ptr(pl.sc_dz2), pl.dpred[p0:].data_ptr(),
-                                             pl.b2part[p0:].data_ptr(), st_), "cham_dm_mulpred_h2")
-                if prof is not None:
-                    e1.record()
-                    prof.append(dict(M=np_ * NC, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False,
-                                     bf16=False, dmf=True, h2out=True, tile=0, epi=0, ev=(e0, e1)))
-            dm_half(0, P1, s)
-            e_dm1 = mark()
-            with aux(e_dm1):
-                dm_half(P1, BT - P1, _stream())
-                e_dm2 = mark()
-        elif dm_fused:
+        if dm_fused:
             prof = rt.profile
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1467,7 +1411,7 @@ class NARModuleModel:
         else:             # k_mulpred_bwd: HBM-bound (3 GB), between two MFMA-bound GEMMs
             check((lib.cham_mulpred_bwd_b16 if b16 else lib.cham_mulpred_bwd)(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), s),
                   "cham_mulpred_bwd")
-        e_dZ2c = e_dm2 if halves_b else mark()              # dZ2c final + dpred
+        e_dZ2c = mark()              # dZ2c final + dpred
         # The candidate-row dgrad of CAR layer 2 on the main lane (needs dZ2c only): the largest GEMM of the backward, ENQUEUED BEFORE the
         # side lane's long launch sequence below - in the bf16 configuration the GPU keeps up with the host, and the ~25 launches of the
         # side block (0.5-0.8 ms of host time) left this lane idle for that long (kernel-trace timeline, profiles/r02_notes.md);
@@ -1479,12 +1423,7 @@ class NARModuleModel:
                 rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, 1, g('W2'), C, C, C, Rc, splits=splits)
             else:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=splits)
-        if h2 and halves_b:
-            rt.gemm_h2(pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, R1, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
-            main_wait(e_dm2)
-            rt.gemm_h2(pl.dZ2p[0, R1:], pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT + R1:], C, Rc - R1, C, C,
-                       dref_h=pl.Z1p[0, R1:], ldr=C, dact=ACT_LEAKY)
-        elif h2:          # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
+        if h2:          # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
             rt.gemm_h2(pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         elif use_p3:
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
@@ -1509,7 +1448,7 @@ class NARModuleModel:
                 rt.colsum(pl.dFC1, 512, BT, 512, g('bf1'))
                 if crit_first:
                     scorer_small_wgrads()
-                if rt.dp_early_bucket is not None and not self._accumulating and not ws1_late:
+                if rt.dp_early_bucket is not None and not self._accumulating:
                     rt.dp_early_bucket(rt.grads)     # data parallel: [Wf1 .. Ws4] gradients are final - their all-reduce starts now
             rt.gemm(pl.dpred, p('Wf2'), pl.dFC1, BT, 512, C, C, C, 512, transB=1, dref=pl.FC1, ldr=512, dact=ACT_LEAKY)
             if drop:                     # (mask and leaky' are both element-wise factors: the order does not matter)
@@ -1579,11 +1518,6 @@ class NARModuleModel:
                             rt.colsum(pl.dxproj, NGH, BTf, NGH, g('rnn0/b'))
                             e_auxdone = mark()
                         rt.side_stream.wait_event(e_cdgrad)
-                        if ws1_late:
-                            ws1_wgrad()
-                            if rt.dp_early_bucket is not None and not self._accumulating:
-                                rt.side_stream.wait_event(e_auxdone)      # [Wf1 .. Ws4] final: Ws1 here, the others on the third lane
-                                rt.dp_early_bucket(rt.grads)
                         w2_wgrad_planes(rt.p3_w2_splits)
                         rt.gemm(pl.Z1, pl.dZ2, g('W2'), C, C, BT, C, C, C, transA=1, splits=0, accumulate=1)
                         continue

@@ -206,10 +206,6 @@ int cham_gemm_h2_set_nt_wide(int on);
  * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */
 int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
                         long long plane_stride, const void* scale_rec, void* stream);
-/* positions [bt_begin, bt_begin + bt_count) only - same pointers and BT as the whole launch (the producer of one half of the candidate rows
- * beside the CAR forward GEMM of the other half) */
-int cham_combine_fwd_h2_range(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
-                              long long plane_stride, const void* scale_rec, int bt_begin, int bt_count, void* stream);
 int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,
                         long long plane_stride, float* col_part, const void* scale_rec, void* stream);
 int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c, const float* pred,
