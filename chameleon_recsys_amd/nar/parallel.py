@@ -66,6 +66,18 @@ class DataParallelNAR:
         rt.dp_pg = process_group
         rt.dp_mode = self.mode
         self._early, self._early_work, self._early_bytes = None, None, 0
+        # dtype of the dense gradient exchange ("12-13 MB fp32 / 6.5 MB bf16"): CHAM_DP_GRAD_DTYPE = f32 | bf16 | auto
+        # (default: bf16 exactly when the runtime computes in bf16 - BASELINE configs[2]).  bf16: the flat gradients are rounded to bf16
+        # (nearest even) into a communication buffer, summed by the collective in bf16 and widened back into the fp32 buffer Adam reads -
+        # identical values on every rank.  The touched embedding rows of the sparse modes stay fp32 (a few MB of sparse sums).
+        want = os.environ.get("CHAM_DP_GRAD_DTYPE", "auto")
+        if want not in ("auto", "f32", "bf16"):
+            raise ValueError("CHAM_DP_GRAD_DTYPE must be 'auto', 'f32' or 'bf16'")
+        if want == "bf16" and self.mode == "sharded":
+            raise ValueError("CHAM_DP_MODE=sharded exchanges fp32 (the owner rank's Adam reads the reduce-scatter's output): CHAM_DP_GRAD_DTYPE=bf16 "
+                             "is for the allreduce / sparse / sparse_rs modes")
+        self.comm_bf16 = self.mode != "sharded" and (want == "bf16" or (want == "auto" and getattr(rt, 'gemm_dtype', 'f32') == 'bf16'))
+        self._comm16 = None
         self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
         # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
         # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
@@ -104,16 +116,36 @@ class DataParallelNAR:
             rt.weights_version = getattr(rt, 'weights_version', 0) + 1
 
     # ---- early bucket (see __init__)
+    def _comm_buffer(self, flat_grads):
+        """bf16 image of the flat gradient buffer (allocated once; slices of it go through the collectives)."""
+        if self._comm16 is None or self._comm16.numel() != flat_grads.numel() or self._comm16.device != flat_grads.device:
+            self._comm16 = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
+        return self._comm16
+
+    def _reduce_range(self, flat_grads, a, b, async_op=False):
+        """all-reduce(SUM) of flat_grads[a:b] in the exchange dtype; returns (work or None, bytes handed to the collective).  In bf16 the
+        caller widens the reduced slice back with _widen_range once the collective has finished."""
+        if self.comm_bf16:
+            buf = self._comm_buffer(flat_grads)[a:b]
+            buf.copy_(flat_grads[a:b])           # fp32 -> bf16, round to nearest even
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 2 * (b - a)
+        return dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 4 * (b - a)
+
+    def _widen_range(self, flat_grads, a, b):
+        if self.comm_bf16:
+            flat_grads[a:b].copy_(self._comm16[a:b])
+
     def _issue_early_bucket(self, flat_grads):
         """Called by the backward pass on the lane that produced the bucket, right after its last gradient was written."""
         a, b = self._early
-        self._early_bytes = 4 * (b - a)
-        self._early_work = dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._early_work, self._early_bytes = self._reduce_range(flat_grads, a, b, async_op=True)
+        self._early_grads = flat_grads
 
     def _wait_early_bucket(self):
         if self._early_work is not None:
             self._early_work.wait()            # (stream-ordered for RCCL: the current stream waits for the collective)
             self._early_work = None
+            self._widen_range(self._early_grads, *self._early)
             return True
         return False
 
@@ -133,8 +165,9 @@ class DataParallelNAR:
         early = self._wait_early_bucket()
         self.last_exchange_bytes = self._early_bytes if early else 0
         for a, b in self._ranges_without_early(0, flat_grads.numel(), early):
-            dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg)
-            self.last_exchange_bytes += 4 * (b - a)
+            _, nbytes = self._reduce_range(flat_grads, a, b)
+            self._widen_range(flat_grads, a, b)
+            self.last_exchange_bytes += nbytes
 
     def _sparse_allreduce(self, flat_grads):
         """ONE collective for everything but the early bucket: [flat buffer without the item table | touched item-table rows] packed
@@ -162,8 +195,15 @@ class DataParallelNAR:
             comm[o:o + b - a].copy_(flat_grads[a:b]); o += b - a
         rows = comm[n_dense:].view(L, dim)
         check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
+        dense16 = None
+        if self.comm_bf16 and n_dense:          # dense remainder in bf16 (its own collective), the touched rows fp32
+            dense16 = self._comm_buffer(flat_grads)[:n_dense]
+            dense16.copy_(comm[:n_dense])
+            dist.all_reduce(dense16, op=dist.ReduceOp.SUM, group=self.pg)
+            comm[:n_dense].copy_(dense16)
         if self.mode == "sparse_rs" and dist.get_backend(self.pg) != "gloo":      # (gloo has no reduce_scatter: the all-reduce below)
-            dist.all_reduce(comm[:n_dense], op=dist.ReduceOp.SUM, group=self.pg)
+            if dense16 is None:
+                dist.all_reduce(comm[:n_dense], op=dist.ReduceOp.SUM, group=self.pg)
             # the row list padded to a multiple of the world size (pad rows: zeros, never written back)
             per = -(-L // self.world)
             if self._rs is None or self._rs[0].numel() < per * self.world * dim:
@@ -175,9 +215,11 @@ class DataParallelNAR:
             dist.reduce_scatter_tensor(mine, packed, op=dist.ReduceOp.SUM, group=self.pg)       # C2: this rank's rows, summed
             dist.all_gather_into_tensor(packed, mine, group=self.pg)
             rows.view(-1).copy_(packed[:L * dim])
+        elif dense16 is not None:
+            dist.all_reduce(comm[n_dense:], op=dist.ReduceOp.SUM, group=self.pg)
         else:
             dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
-        self.last_exchange_bytes = 4 * need + (self._early_bytes if early else 0)
+        self.last_exchange_bytes = (2 if dense16 is not None else 4) * n_dense + 4 * L * dim + (self._early_bytes if early else 0)
         self.last_touched_rows = L
         o = 0
         for a, b in ranges:

@@ -109,7 +109,7 @@ MODES = ["allreduce", "sharded", "sparse", "sparse_rs"]
 
 
 def _worker_arith(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CHAM_DP_GRAD_DTYPE="f32")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = {}
@@ -122,6 +122,14 @@ def _worker_arith(rank, world, port, out_dir):
             out["%s/%s/losses" % (dtype, mode)] = losses
             out["%s/%s/flat" % (dtype, mode)] = flat
             out["%s/%s/m" % (dtype, mode)] = m_ckpt          # complete slots (gathered) whatever the mode
+    # ... and configs[2] with the exchange SURVEY 8e sizes for it: the dense gradients through the collectives in bf16 (CHAM_DP_GRAD_DTYPE=auto
+    # picks that for a bf16 runtime), in the default mode and in the C1 + C2 pair
+    os.environ["CHAM_DP_GRAD_DTYPE"] = "auto"
+    p = _params(C=256, gemm_dtype="bf16")
+    batches = synthetic.make_batches(2 + STEPS, 48, 8, 1000, p['session_features_config'], length_dist='g1', seed=6)
+    for mode in ("allreduce", "sparse_rs"):
+        losses, flat, m, E, m_ckpt, ckpt_mode = _run(world, rank, batches, p, mode=mode)
+        out["bf16x/%s/losses" % mode], out["bf16x/%s/flat" % mode], out["bf16x/%s/m" % mode] = losses, flat, m_ckpt
     np.savez(os.path.join(out_dir, "arith_rank%d.npz" % rank), **out)
     dist.destroy_process_group()
 
@@ -156,3 +164,9 @@ def test_two_rank_training_in_every_arithmetic_and_exchange_mode(gpu, tmp_path):
                 H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=5e-2, w_tol=0.5, floor=0.25)
             else:
                 H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=1e-4)
+        if dtype == 'bf16':       # the bf16 EXCHANGE on top (gradients rounded to bf16 on their way through the collective: 2^-8 relative per entry)
+            for mode in ("allreduce", "sparse_rs"):
+                k = "bf16x/%s/" % mode
+                assert np.array_equal(r0[k + 'flat'], r1[k + 'flat']) and np.array_equal(r0[k + 'm'], r1[k + 'm']), k
+                assert np.abs(losses[0] - r0[k + 'losses'][0]).max() < 2e-5 and np.abs(losses - r0[k + 'losses']).max() < 3e-3, (k, losses, r0[k + 'losses'])
+                H.assert_flat_close(rt.layout, r0[k + 'flat'], r0[k + 'm'], flat, m, p['lr'], n_steps=STEPS, m_tol=5e-2, w_tol=0.5, floor=0.25)

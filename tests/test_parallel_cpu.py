@@ -253,3 +253,62 @@ def test_kernel_timeout_word_raises_on_every_rank(tmp_path):
     r0, r1 = (open(str(tmp_path / ("health_rank%d.txt" % r))).read().split(",") for r in range(world))
     assert r0 == ["ok", "raised other", "poll raised"], r0
     assert r1 == ["ok", "raised own", "poll raised"], r1
+
+
+# ---- bf16 gradient exchange ("6.5 MB bf16"; CHAM_DP_GRAD_DTYPE, default bf16 exactly when the runtime computes in bf16 -
+# ---- BASELINE configs[2]): the flat gradients go through the collectives rounded to bf16 - early bucket and remainder alike - and come back
+# ---- widened into the fp32 buffer Adam reads, identical on every rank
+def _bf16_worker(rank, world, port, out_dir, dtype_env, gemm_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CHAM_DP_GRAD_DTYPE=dtype_env)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+
+    class _E:
+        def __init__(self, name, offset, size):
+            self.name, self.offset, self.size = name, offset, size
+
+    class _Layout:
+        emb_end = _N_EMB
+        entries = {n: _E(n, o, sz) for n, o, sz in (('emb', 0, _N_EMB), ('W2', _N_EMB, 500), ('Wf1', 2000, 300), ('Wf2', 2300, 200),
+                                                    ('Ws1', 2500, 100), ('Ws2', 2600, 60), ('Ws3', 2660, 40), ('Ws4', 2700, 20),
+                                                    ('b1', 2720, _N_TOTAL - 2720))}
+
+    class _RT:
+        flat = torch.zeros(_N_TOTAL)
+        layout = _Layout()
+        dp_rank = dp_world = dp_allreduce = dp_sharded = dp_early_bucket = dp_gather_slots = None
+    _RT.gemm_dtype = gemm_dtype
+
+    class _Model:
+        rt = _RT()
+    dp = parallel.DataParallelNAR(_Model(), mode="allreduce")
+    outs = []
+    for step in range(2):
+        grads = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(300 + 10 * step + rank))
+        if step == 0:
+            _Model.rt.dp_early_bucket(grads)
+        _Model.rt.dp_allreduce(grads)
+        outs.append(grads.numpy().copy())
+    np.savez(os.path.join(out_dir, "bf16_rank%d.npz" % rank), g0=outs[0], g1=outs[1], comm_bf16=dp.comm_bf16, nbytes=dp.last_exchange_bytes)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_env,gemm_dtype,want_bf16", [("auto", "bf16", True), ("auto", "f32", False), ("bf16", "f32", True), ("f32", "bf16", False)])
+def test_bf16_gradient_exchange(tmp_path, dtype_env, gemm_dtype, want_bf16):
+    world = 2
+    mp.spawn(_bf16_worker, args=(world, _free_port(), str(tmp_path), dtype_env, gemm_dtype), nprocs=world, join=True)
+    got = [np.load(str(tmp_path / ("bf16_rank%d.npz" % r))) for r in range(world)]
+    assert all(bool(g['comm_bf16']) == want_bf16 for g in got)
+    for step, key in enumerate(("g0", "g1")):
+        gs = [torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(300 + 10 * step + r)) for r in range(world)]
+        if want_bf16:
+            ref = (gs[0].bfloat16() + gs[1].bfloat16()).float()         # two-rank sum in bf16: one rounding of the sum of two roundings
+        else:
+            ref = gs[0] + gs[1]
+        for r in range(world):
+            assert np.array_equal(got[r][key], ref.numpy()), (key, r, float(np.abs(got[r][key] - ref.numpy()).max()))
+        if want_bf16:       # ... and within bf16 resolution of the fp32 sum
+            full = (gs[0] + gs[1]).numpy()
+            assert np.abs(got[0][key] - full).max() <= 2.0 ** -7 * np.abs(full).max()
+    # bytes handed to the collectives of the last step (no early bucket there): the whole flat buffer at 2 or 4 bytes per gradient
+    assert int(got[0]['nbytes']) == (2 if want_bf16 else 4) * _N_TOTAL
