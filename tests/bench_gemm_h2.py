@@ -60,6 +60,9 @@ def main():
          None if only else (lambda: check(lib.cham_gemm_p3(ptr(Ap), R * C, C, ptr(WTp), C * C, C, 0, ptr(Out), C, R, C, C, ptr(bias), 2, None, 0, 0, 0, None, 0, 1, st), "p3")),
          native(A, 0, W, 0, Out, R, C, C, bias_=bias, act=2),
          lambda: Out[rows], lambda: torch.tanh(A[rows].double() @ W.double() + bias.double())),
+        ("CAR fwd, bias only (no tanh)",
+         h2(Ah, R * C, C, ra, WTh, C * C, C, rw, 0, Out, R, C, C, bias_=bias, act=0), None, native(A, 0, W, 0, Out, R, C, C, bias_=bias, act=0),
+         lambda: Out[rows], lambda: A[rows].double() @ W.double() + bias.double()),
         ("CAR dgrad (D W^T) leaky'",
          h2(Dh, R * C, C, rd, Wh, C * C, C, rw, 0, Out, R, C, C, dref=Yh2, dact=1),
          None if only else (lambda: check(lib.cham_gemm_p3(ptr(Dp), R * C, C, ptr(Wp), C * C, C, 0, ptr(Out), C, R, C, C, None, 0, ptr(Yh), C, 1, 0, None, 0, 1, st), "p3")),
