@@ -284,10 +284,11 @@ def through_boundary(cfg, length_dist, warm_steps=50, timed_steps=200, seed=42, 
         shutil.rmtree(d, ignore_errors=True)
 
 
-def stress_arm(n_items=5_000_000, batch=4096, neg=200, micro=512, steps=2):
+def stress_arm(n_items=5_000_000, batch=4096, neg=200, micro=2048, steps=2):
     """BASELINE.json configs[4] AS WRITTEN (large-catalog stress: 5 M articles, 128-d ACE, batch 4096, 200 negatives, item-embedding width
     floor(8 n^0.25) = 378 -> a 7.56 GB table, 1.89 G parameters under TF-dense Adam) as a child process (scripts/stress_large_catalog.py:
-    micro-batched optimizer step, the HBM rooflines of the gather, TF-dense Adam and embedding-gradient kernels): ~8 s of set-up + 0.7 s per
+    micro-batched optimizer step - two micro-batches of 2048 sessions, 176 GB of HBM: 0.468 s/step against 0.523 with eight of 512,
+    profiles/r05_notes.md - the HBM rooflines of the gather, TF-dense Adam and embedding-gradient kernels): ~8 s of set-up + 0.5 s per
     step.  `stress_arm_1m` in the line is the same script at 1 M articles x 1024 sessions (rounds 3-4 reported only that one)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "stress_large_catalog.py"), "--n-items", str(n_items), "--batch", str(batch),
@@ -707,8 +708,10 @@ def main():
                        "gemm": {"f32": ("fp32 accumulate / epilogues, fp32-grade error (float64-error bar next to the native fp32 MFMA: tests/test_gemm_h2_gpu.py, "
                                         "tests/test_gemm_x3_gpu.py): the three candidate-row CAR GEMMs as THREE fp16-plane products per fp32 product over "
                                         "(h, l) fp16 planes x a device-derived power-of-two scale that their producers wrote to HBM (csrc/gemm_h2.hip, "
-                                        "v_mfma_f32_32x32x16_f16); the other GEMMs with N > 64 as six bf16-plane products split while staged "
-                                        "(csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32") if getattr(rt, 'h2', False) else
+                                        "v_mfma_f32_32x32x16_f16; the NT forms stage 64-byte source pieces: gemm_h2w_kernel); the other GEMMs with N > 64 as six bf16-plane "
+                                        "products split while staged (csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32.  Accuracy contract of the "
+                                        "two-plane operands: relative to the MATRIX bound, not to each row - fp32 grade for rows within 2^-18 of the largest "
+                                        "entry, an absolute error of 2^-40 of the bound below that (INTEGRATION.md)") if getattr(rt, 'h2', False) else
                                        ("fp32 accumulate / epilogues; GEMMs with N > 64 as six bf16-plane products per fp32 product on "
                                         "v_mfma_f32_32x32x16_bf16 (fp32-grade error: tests/test_gemm_x3_gpu.py, tests/test_gemm_p3_gpu.py) - the three candidate-row "
                                         "CAR GEMMs over planes their producers wrote to HBM (csrc/gemm_p3.hip), the others split while staged "
@@ -759,7 +762,7 @@ def main():
             out["bf16_arm"] = child_arm(args, ["--dtype", "bf16"])
             out["adressa_arm"] = child_arm(args, ["--config", "adressa", "--no-ragged-leg"])
             out["stress_arm"] = stress_arm()          # configs[4] at its full size: 5 M articles x 4096 sessions x 200 negatives
-            out["stress_arm_1m"] = stress_arm(n_items=1_000_000, batch=1024)
+            out["stress_arm_1m"] = stress_arm(n_items=1_000_000, batch=1024, micro=512)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.length_dist, args.seed)
             out["accuracy_vs_cpu_ref"] = hitrate_parity(args.seed)

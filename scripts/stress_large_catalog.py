@@ -6,7 +6,7 @@ activations stay bounded; the embedding tables (item table 5M x 378 fp32 = 7.56 
 (28 B/param/step) make gather / scatter / optimizer the HBM-bound part.  Prints one JSON line with the step time and the
 HBM-roofline fractions of the optimizer and gather kernels (HIP-event timed).
 
-  python scripts/stress_large_catalog.py [--n-items 5000000] [--batch 4096] [--neg 200] [--micro 512] [--steps 2]
+  python scripts/stress_large_catalog.py [--n-items 5000000] [--batch 4096] [--neg 200] [--micro 2048] [--steps 2]
 """
 import argparse
 import json
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--ace-dim", type=int, default=128)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--neg", type=int, default=200)
-    ap.add_argument("--micro", type=int, default=512)
+    ap.add_argument("--micro", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=2)
     args = ap.parse_args()
     import torch

@@ -238,6 +238,43 @@ def test_h2_rows_of_very_different_magnitude(gpu, spread):
     assert _nt(gpu, 1000, 512, 256, row_spread=spread, seed=3) < 5e-5
 
 
+def test_h2_row_relative_error_follows_the_documented_contract(gpu):
+    """The accuracy contract of a two-plane operand is relative to the matrix's BOUND, not to each row ("accuracy of the
+    default fp32 arithmetic"): with the bound scaled to [2^14, 2^15), an element keeps 22 bits while |x s| >= 2^-3 and an ABSOLUTE error of
+    2^-25 / s below that (fp16 subnormal low plane).  For an output row whose A row sits 2^-d below the bound that is a relative error of
+    max(~2^-21, ~2^(d - 40)) - fp32 grade down to d = 18, 1e-3 at d = 30 (the round-4 verdict's example) - which this test MEASURES row by
+    row against float64 (rows spread over 2^40) and holds to 4 x that model, next to the native fp32 MFMA on the same operands (row-relative
+    ~1e-6 at every magnitude).  What it means for the step: the two-plane operands are Z1 (PreCAR output, rows within a few binary orders
+    of each other) and dZ2 (gradient at the CAR tanh): a dZ2 row 2^-30 below the largest one carries 1e-3 relative error into its dZ1 row
+    and its share of the W2 gradient - entries 2^-30 below the largest gradient entry, which TF-Adam's epsilon (1e-8 against sqrt(v))
+    flattens anyway.  A per-row scale would factor out of the NT product but not out of the W2 weight gradient (the contraction runs over
+    the rows), so the planes would have to be written twice: rejected on cost, contract stated instead."""
+    lib = _lib_()
+    M, N, K = 2048, 256, 512
+    g = torch.Generator(device=gpu).manual_seed(21)
+    d = torch.linspace(0.0, 40.0, M, device=gpu).unsqueeze(1)                    # row r sits 2^-d(r) below the largest row
+    A = torch.randn(M, K, device=gpu, generator=g) * torch.exp2(-d)
+    B = torch.randn(N, K, device=gpu, generator=g) * (K ** -0.5)
+    (Ap, ra), (Bp, rb) = split2h_dev(A), split2h_dev(B)
+    C = torch.empty(M, N, device=gpu)
+    _gemm(lib, Ap, M * K, K, ra, Bp, N * K, K, rb, 0, C, N, M, N, K)
+    Cn = torch.empty(M, N, device=gpu)
+    _native(lib, A, K, 0, B, K, 1, Cn, M, N, K, None, 0, None, 0, None, 1)
+    torch.cuda.synchronize()
+    R = A.double() @ B.double().t()
+    row_max = R.abs().amax(1)
+    e_h2 = ((C.double() - R).abs().amax(1) / row_max).cpu().numpy()
+    e_nat = ((Cn.double() - R).abs().amax(1) / row_max).cpu().numpy()
+    dd = d.flatten().cpu().numpy()
+    # the matrix bound is max |A| (row 0 region, ~4 sigma): rows sit d + ~2 binary orders below it
+    model = np.maximum(2.0 ** -21, 2.0 ** (dd + 2.5 - 40.0))
+    print("row-relative error, two-plane vs native fp32 MFMA, at d = 0 / 10 / 18 / 24 / 30 / 36: %s vs %s" % (
+        ["%.1e" % e_h2[int(x / 40.0 * (M - 1))] for x in (0, 10, 18, 24, 30, 36)], ["%.1e" % e_nat[int(x / 40.0 * (M - 1))] for x in (0, 10, 18, 24, 30, 36)]))
+    assert (e_h2 <= 4.0 * model).all(), (float((e_h2 / model).max()), int((e_h2 / model).argmax()))
+    assert e_h2[dd <= 16.0].max() < 3e-6 and e_nat.max() < 1e-5               # fp32 grade while rows are within 2^-16 of the bound; native: everywhere
+    assert e_h2[dd >= 34.0].min() > 1e-4                                      # ... and the degradation is real: the contract is not vacuous
+
+
 def test_h2_is_repeatable_under_load(gpu):
     """Race screen: the same launch five times, bit-identical (a fragment read that overtakes its DMA shows up as run-to-run noise)."""
     _nt(gpu, 4096, 1024, 1024, bias=True, act=2, check_ref=False, reps=5)
