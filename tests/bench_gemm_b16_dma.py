@@ -39,6 +39,9 @@ for name, old, new in (
     ("CAR forward  tanh(X W^T + b)",
      lambda: check(lib.cham_gemm_b16(ptr(X), C, 0, ptr(W), C, 1, ptr(ob), C, 0, R, C, C, ptr(bias), 2, None, 0, 0, 0, None, 0, 1, s), "b16"),
      lambda: check(lib.cham_gemm_b16_dma(ptr(X), C, ptr(W), C, 0, ptr(ob), C, R, C, C, ptr(bias), 2, None, 0, 0, 0, None, 0, 1, s), "dma")),
+    ("CAR forward  plain bf16(X W^T)",
+     lambda: check(lib.cham_gemm_b16(ptr(X), C, 0, ptr(W), C, 1, ptr(ob), C, 0, R, C, C, None, 0, None, 0, 0, 0, None, 0, 1, s), "b16"),
+     lambda: check(lib.cham_gemm_b16_dma(ptr(X), C, ptr(W), C, 0, ptr(ob), C, R, C, C, None, 0, None, 0, 0, 0, None, 0, 1, s), "dma")),
     ("CAR dgrad    (D W) x leaky'",
      lambda: check(lib.cham_gemm_b16(ptr(D), C, 0, ptr(W), C, 1, ptr(ob), C, 0, R, C, C, None, 0, ptr(Y), C, 1, 0, None, 0, 1, s), "b16"),
      lambda: check(lib.cham_gemm_b16_dma(ptr(D), C, ptr(W), C, 0, ptr(ob), C, R, C, C, None, 0, ptr(Y), C, 1, 0, None, 0, 1, s), "dma")),
