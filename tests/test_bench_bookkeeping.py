@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _stats_names():
-    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")) as fh:
         return {r["Name"] for r in csv.DictReader(fh)}
 
 
@@ -19,19 +19,19 @@ def test_rebuilt_gemm_symbols_are_the_names_rocprof_lists():
     import bench
     names = _stats_names()
     base = dict(transA=0, transB=1, rowscale=False, bf16=False, tile=0)
-    recs = [dict(base, h2=True, epi=3), dict(base, h2=True, epi=2), dict(base, h2=True, epi=6, transA=1, transB=0),
+    recs = [dict(base, h2=True, h2w=True, epi=3), dict(base, h2=True, h2w=True, epi=2), dict(base, h2=True, epi=6, transA=1, transB=0),      # h2w: the NT forms on the 64-byte-piece kernel
             dict(base, dmf=True, h2out=True, epi=0),          # -> k_dm_mulpred_fused<1>
             dict(base, x3=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue)
             dict(base, x3=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient
             dict(base, x3=True, tile=0, epi=6, transA=1, transB=0)]
     for r in recs:
         sym = bench.gemm_symbol(r)
-        assert sym in names, "%s is not a kernel of profiles/r04_kernel_stats.csv" % sym
+        assert sym in names, "%s is not a kernel of profiles/r05_kernel_stats.csv" % sym
 
 
 def test_committed_traffic_file_has_the_dominant_kernels():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read())
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read())
     dom = line["roofline"]["kernel"].split(" = ")[0]
     assert dom in d and d[dom]["traffic_bytes_per_launch"] > line["roofline"]["algorithmic_bytes_per_launch"] * 0.9
     for g in line["roofline"]["top_gemms"]:
