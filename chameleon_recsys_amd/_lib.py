@@ -89,7 +89,6 @@ _SIGNATURES = {
     "cham_mulpred_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "cham_score_softmax_fwd": (c_int, [P, c_int, P, P, c_int, c_int, c_float, P, P, P, P, c_float, P, P, P, P]),
     "cham_score_softmax_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, c_float, P, P, c_float, P, P, P, P, P]),
-    "cham_scorer_tail_fused": (c_int, [P, c_int, P, P, c_int, P, P, c_int, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "cham_rank_items": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
     "cham_state_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cham_state_update": (c_int, [P, P, c_int, c_int, c_double, P, P, c_int, P, P, P, c_int, c_int, P, P, c_size_t, P]),

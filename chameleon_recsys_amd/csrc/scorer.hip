@@ -562,182 +562,6 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const T* __restrict__
 }
 
 
-// ================================================================================================================================
-// Scorer layers 2-4 + softmax(/tau) + masked NLL + their backward down to the gradient at the layer-1 output, in ONE launch (round 5;
-// nar_model.py:452-473, 511-517, 639-667 and the autodiff of those lines; TRAIN mode of the fp32 configurations, novelty regulariser off).
-// Replaces ten launches between the scorer's first layer and the fused layer-1 dgrad - two narrow GEMMs (128 -> 64, 64 -> 32), softmax
-// forward, softmax backward, two narrow dgrads and their ~1.1 GB of round trips through HBM (every intermediate written, then read
-// back one or two launches later): 0.37 ms on the step's critical path, 444 MB of compulsory traffic.
-//   one WAVE per position (b, t): lane c owns candidate row (b, t, c) (rows c, c + 64, ... when 1 + N > 64) and carries it through
-//   every layer as a thread-private mat-vec - the 64 / 32 accumulators of a layer are registers, the layer's weights [K][Nout] sit in LDS
-//   and are read wave-uniformly (one ds_read_b128 per 4 weights, broadcast to the 64 lanes: one LDS read per four FMAs); the softmax over
-//   the position's 1 + N logits is the same wavefront-shuffle reduction as k_score_softmax_fwd; the backward re-reads the activations it
-//   has just written (its own stores, L2-resident).  fp32 FMAs throughout (10.2 GFLOP per step at the G1 shape).
-// Outputs are everything the rest of the backward reads: S2, S3 (weight gradients of layers 3 / 4), logits / probs / nll, ds, dS3, dS2
-// (weight / bias gradients of layers 2-4) and dS1 = (dS2 W2^T) leaky'(S1) (fused layer-1 dgrad, layer-1 weight gradient).
-// Summation order differs from the GEMM kernels it replaces (fp32 re-association); the step parity tests hold it to the same tolerances.
-template <int K1, int K2, int K3>
-__global__ __launch_bounds__(256) void k_scorer_tail_fused(const float* __restrict__ S1, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                           const float* __restrict__ W3, const float* __restrict__ b3,
-                                                           const float* __restrict__ w4, const float* __restrict__ b4, int BT, int N,
-                                                           float inv_tau, float scale /* 1 / (tau sum(mask)) */,
-                                                           const unsigned char* __restrict__ mask, float* __restrict__ S2,
-                                                           float* __restrict__ S3, float* __restrict__ logits, float* __restrict__ probs,
-                                                           float* __restrict__ nll, float* __restrict__ ds, float* __restrict__ dS3,
-                                                           float* __restrict__ dS2, float* __restrict__ dS1) {
-    __shared__ __attribute__((aligned(16))) float sW2[K1 * K2];
-    __shared__ __attribute__((aligned(16))) float sW3[K2 * K3];
-    __shared__ float sb2[K2], sb3[K3], sw4[K3];
-    for (int i = threadIdx.x; i < K1 * K2 / 4; i += 256) reinterpret_cast<float4*>(sW2)[i] = reinterpret_cast<const float4*>(W2)[i];
-    for (int i = threadIdx.x; i < K2 * K3 / 4; i += 256) reinterpret_cast<float4*>(sW3)[i] = reinterpret_cast<const float4*>(W3)[i];
-    if (threadIdx.x < K2) sb2[threadIdx.x] = b2[threadIdx.x];
-    if (threadIdx.x < K3) { sb3[threadIdx.x] = b3[threadIdx.x]; sw4[threadIdx.x] = w4[threadIdx.x]; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, bt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (bt >= BT) return;
-    const int NC = N + 1;
-    const float bias4 = b4[0];
-
-    // ---- forward: S2 = leaky(S1 W2 + b2), S3 = leaky(S2 W3 + b3), logit = S3 . w4 + b4
-    // (the K loops are NOT unrolled: an unrolled body lets the scheduler hoist every LDS weight read of the next iterations - 64 float4 per
-    // unrolled k4 - on top of the 64 accumulators, and the kernel spills; one weight row = 16 / 8 float4 per iteration keeps ~110 registers live)
-    float mx = -INFINITY;
-    for (int c = lane; c < NC; c += 64) {
-        const size_t row = (size_t)bt * NC + c;
-        const float* x1 = S1 + row * K1;
-        float a2[K2];
-#pragma unroll
-        for (int n = 0; n < K2; ++n) a2[n] = sb2[n];
-        float4 xn = ld4(x1);
-#pragma unroll 1
-        for (int k4 = 0; k4 < K1 / 4; ++k4) {
-            const float4 x = xn;
-            if (k4 + 1 < K1 / 4) xn = ld4(x1 + 4 * k4 + 4);          // next four inputs under this iteration's 256 FMAs
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float4* wr = reinterpret_cast<const float4*>(sW2 + (4 * k4 + kk) * K2);
-#pragma unroll
-                for (int n4 = 0; n4 < K2 / 4; ++n4) {
-                    const float4 w = wr[n4];
-                    a2[4 * n4] = fmaf(xs[kk], w.x, a2[4 * n4]); a2[4 * n4 + 1] = fmaf(xs[kk], w.y, a2[4 * n4 + 1]);
-                    a2[4 * n4 + 2] = fmaf(xs[kk], w.z, a2[4 * n4 + 2]); a2[4 * n4 + 3] = fmaf(xs[kk], w.w, a2[4 * n4 + 3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);                 // (one weight row's reads at a time: see above)
-            }
-        }
-#pragma unroll
-        for (int n4 = 0; n4 < K2 / 4; ++n4) {
-            a2[4 * n4] = act_fwd(a2[4 * n4], ACT_LEAKY); a2[4 * n4 + 1] = act_fwd(a2[4 * n4 + 1], ACT_LEAKY);
-            a2[4 * n4 + 2] = act_fwd(a2[4 * n4 + 2], ACT_LEAKY); a2[4 * n4 + 3] = act_fwd(a2[4 * n4 + 3], ACT_LEAKY);
-            st4(S2 + row * K2 + 4 * n4, make_float4(a2[4 * n4], a2[4 * n4 + 1], a2[4 * n4 + 2], a2[4 * n4 + 3]));
-        }
-        float a3[K3];
-#pragma unroll
-        for (int m = 0; m < K3; ++m) a3[m] = sb3[m];
-        const float* y2 = S2 + row * K2;               // (this lane's own stores: read back rather than indexing the register array dynamically)
-#pragma unroll 1
-        for (int n = 0; n < K2; ++n) {
-            const float yn = y2[n];
-            const float4* wr = reinterpret_cast<const float4*>(sW3 + n * K3);
-#pragma unroll
-            for (int m4 = 0; m4 < K3 / 4; ++m4) {
-                const float4 w = wr[m4];
-                a3[4 * m4] = fmaf(yn, w.x, a3[4 * m4]); a3[4 * m4 + 1] = fmaf(yn, w.y, a3[4 * m4 + 1]);
-                a3[4 * m4 + 2] = fmaf(yn, w.z, a3[4 * m4 + 2]); a3[4 * m4 + 3] = fmaf(yn, w.w, a3[4 * m4 + 3]);
-            }
-        }
-        float sl = 0.f;
-#pragma unroll
-        for (int m4 = 0; m4 < K3 / 4; ++m4) {
-            float4 y;
-            y.x = act_fwd(a3[4 * m4], ACT_LEAKY); y.y = act_fwd(a3[4 * m4 + 1], ACT_LEAKY);
-            y.z = act_fwd(a3[4 * m4 + 2], ACT_LEAKY); y.w = act_fwd(a3[4 * m4 + 3], ACT_LEAKY);
-            st4(S3 + row * K3 + 4 * m4, y);
-            sl += y.x * sw4[4 * m4] + y.y * sw4[4 * m4 + 1] + y.z * sw4[4 * m4 + 2] + y.w * sw4[4 * m4 + 3];      // (k_score_softmax_fwd's order)
-        }
-        sl += bias4;
-        logits[row] = sl;
-        mx = fmaxf(mx, sl * inv_tau);
-    }
-    // ---- softmax over the position's 1 + N candidates, masked NLL (as k_score_softmax_fwd)
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int c = lane; c < NC; c += 64) {
-        const float e = expf(logits[(size_t)bt * NC + c] * inv_tau - mx);        // same lane wrote it
-        probs[(size_t)bt * NC + c] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    const bool valid = mask[bt] != 0;
-    if (lane == 0) nll[bt] = valid ? -((logits[(size_t)bt * NC] * inv_tau - mx) - logf(sum)) : 0.f;
-    // ---- backward: ds = (p - [c == 0]) mask / (tau sum(mask)); dS3 = ds w4 leaky'(S3); dS2 = (dS3 W3^T) leaky'(S2); dS1 = (dS2 W2^T) leaky'(S1)
-    for (int c = lane; c < NC; c += 64) {
-        const size_t row = (size_t)bt * NC + c;
-        const float pr = probs[row] * inv;
-        probs[row] = pr;
-        const float g = valid ? (pr - (c == 0 ? 1.f : 0.f)) * scale : 0.f;
-        ds[row] = g;
-        float d3[K3];
-#pragma unroll
-        for (int m4 = 0; m4 < K3 / 4; ++m4) {
-            const float4 x = ld4(S3 + row * K3 + 4 * m4);
-            float4 y;
-            y.x = g * sw4[4 * m4] * act_bwd_from_out(x.x, ACT_LEAKY); y.y = g * sw4[4 * m4 + 1] * act_bwd_from_out(x.y, ACT_LEAKY);
-            y.z = g * sw4[4 * m4 + 2] * act_bwd_from_out(x.z, ACT_LEAKY); y.w = g * sw4[4 * m4 + 3] * act_bwd_from_out(x.w, ACT_LEAKY);
-            st4(dS3 + row * K3 + 4 * m4, y);
-            d3[4 * m4] = y.x; d3[4 * m4 + 1] = y.y; d3[4 * m4 + 2] = y.z; d3[4 * m4 + 3] = y.w;
-        }
-        float d2[K2];
-        {
-            const float* y2 = S2 + row * K2;
-            float* o2 = dS2 + row * K2;
-#pragma unroll 1
-            for (int n = 0; n < K2; ++n) {
-                const float4* wr = reinterpret_cast<const float4*>(sW3 + n * K3);
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-                for (int m4 = 0; m4 < K3 / 4; ++m4) {
-                    const float4 w = wr[m4];
-                    t0 = fmaf(d3[4 * m4], w.x, t0); t1 = fmaf(d3[4 * m4 + 1], w.y, t1); t2 = fmaf(d3[4 * m4 + 2], w.z, t2); t3 = fmaf(d3[4 * m4 + 3], w.w, t3);
-                }
-                o2[n] = ((t0 + t1) + (t2 + t3)) * act_bwd_from_out(y2[n], ACT_LEAKY);
-            }
-#pragma unroll
-            for (int n4 = 0; n4 < K2 / 4; ++n4) {       // (own stores read back into the register array the next layer indexes statically)
-                const float4 v = ld4(o2 + 4 * n4);
-                d2[4 * n4] = v.x; d2[4 * n4 + 1] = v.y; d2[4 * n4 + 2] = v.z; d2[4 * n4 + 3] = v.w;
-            }
-        }
-        {
-            const float* x1 = S1 + row * K1;
-            float* o1 = dS1 + row * K1;
-            float4 xn = ld4(x1);
-#pragma unroll 1
-            for (int k4 = 0; k4 < K1 / 4; ++k4) {
-                const float4 x = xn;
-                if (k4 + 1 < K1 / 4) xn = ld4(x1 + 4 * k4 + 4);
-                const float xs[4] = {x.x, x.y, x.z, x.w};
-                float o[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const float4* wr = reinterpret_cast<const float4*>(sW2 + (4 * k4 + kk) * K2);
-                    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-                    for (int n4 = 0; n4 < K2 / 4; ++n4) {
-                        const float4 w = wr[n4];
-                        t0 = fmaf(d2[4 * n4], w.x, t0); t1 = fmaf(d2[4 * n4 + 1], w.y, t1); t2 = fmaf(d2[4 * n4 + 2], w.z, t2); t3 = fmaf(d2[4 * n4 + 3], w.w, t3);
-                    }
-                    o[kk] = ((t0 + t1) + (t2 + t3)) * act_bwd_from_out(xs[kk], ACT_LEAKY);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                st4(o1 + 4 * k4, make_float4(o[0], o[1], o[2], o[3]));
-            }
-        }
-    }
-}
-
 // rank_items_by_predicted_prob (nar_model.py:777-794): tf.nn.top_k over the 1+N candidates = descending stable sort
 // (lowest index wins ties).  One wave per click; rank by counting; also emits the rank of the positive (c = 0).
 __global__ __launch_bounds__(256) void k_rank_items(const float* __restrict__ probs, const int64_t* __restrict__ label_next,
@@ -956,23 +780,6 @@ extern "C" int cham_score_softmax_bwd_b16(const void* S3, int K3, const float* w
                                           void* stream) {
     return score_softmax_bwd_impl<__bf16>(reinterpret_cast<const __bf16*>(S3), K3, w4, probs, mask, BT, N, tau, sum_mask, ds,
                                           reinterpret_cast<__bf16*>(dS3), novelty_reg_factor, neg_ids, pop_norm, logits, nov_aux, stream);
-}
-
-// scorer layers 2-4 + softmax + NLL + backward to dS1 in one launch (k_scorer_tail_fused): S1 [BT (1+N), 128] -> S2 [., 64], S3 [., 32], logits /
-// probs [BT, 1+N], nll [BT], ds [BT (1+N)], dS3, dS2, dS1.  Layer widths 128 -> 64 -> 32 -> 1 only (nar_model.py:452-473); -EINVAL otherwise
-// (the caller keeps the separate kernels).  sum_mask = the GLOBAL number of valid positions (the loss denominator, nar_model.py:664).
-extern "C" int cham_scorer_tail_fused(const float* S1, int K1, const float* W2, const float* b2, int K2, const float* W3, const float* b3, int K3,
-                                      const float* w4, const float* b4, int BT, int N, float tau, float sum_mask, const uint8_t* mask, float* S2,
-                                      float* S3, float* logits, float* probs, float* nll, float* ds, float* dS3, float* dS2, float* dS1,
-                                      void* stream) {
-    if (!S1 || !W2 || !b2 || !W3 || !b3 || !w4 || !b4 || !mask || !S2 || !S3 || !logits || !probs || !nll || !ds || !dS3 || !dS2 || !dS1) return -CHAM_ERR_ARG;
-    if (K1 != 128 || K2 != 64 || K3 != 32 || BT < 0 || N < 0 || !(tau > 0.f) || !(sum_mask > 0.f)) return -CHAM_ERR_ARG;
-    if (((uintptr_t)S1 | (uintptr_t)W2 | (uintptr_t)W3 | (uintptr_t)S2 | (uintptr_t)S3 | (uintptr_t)dS3 | (uintptr_t)dS2 | (uintptr_t)dS1) & 15) return -CHAM_ERR_ARG;
-    if (BT == 0) return CHAM_OK;
-    hipLaunchKernelGGL((k_scorer_tail_fused<128, 64, 32>), dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, S1, W2, b2, W3, b3, w4, b4, BT, N,
-                       1.f / tau, 1.f / (tau * sum_mask), mask, S2, S3, logits, probs, nll, ds, dS3, dS2, dS1);
-    CHAM_CHECK_LAUNCH();
-    return CHAM_OK;
 }
 
 extern "C" int cham_rank_items(const float* probs, const int64_t* label_next, const int64_t* neg_ids, const uint8_t* mask, int BT,

@@ -248,9 +248,6 @@ class NARRuntime:
         # head of the step (round 5, CHAM_HEAD_SPLIT): the clicked rows' PreCAR combine + CAR layer 2 feed the recurrent branch only - they
         # run at the head of the side lane instead of in front of the main lane's plane producer and CAR forward GEMM
         self.head_split = os.environ.get("CHAM_HEAD_SPLIT", "1") == "1"
-        # scorer layers 2-4 + softmax + their backward in one launch (csrc/scorer.hip k_scorer_tail_fused, round 5) in TRAIN mode of the fp32
-        # configurations; CHAM_SCORER_TAIL=0: the ten separate launches (narrow GEMMs, softmax forward / backward, narrow dgrads)
-        self.scorer_tail = os.environ.get("CHAM_SCORER_TAIL", "1") == "1"
         self.overlap = os.environ.get("CHAM_OVERLAP", "1") == "1"           # CHAM_OVERLAP=0: the same program order on one stream
         # row-wise stages on the non-padded (session, time) positions only (upload_batch); CHAM_COMPACT=0 computes the padded
         # positions too and masks them, like the reference graph does
@@ -1019,7 +1016,6 @@ class NARModuleModel:
         pl = rt.plan(B, T, N, self.negative_sample_from_buffer, d['Bg'])
         self._plan, self._d = pl, d
         pl.used_p3 = False
-        pl.tail_fused = False
         check(lib.cham_set_log_bases(self.elapsed_days_smooth_log_base, self.popularity_smooth_log_base), "cham_set_log_bases")
         torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
@@ -1237,22 +1233,12 @@ class NARModuleModel:
             # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
             Z2c = pl.Z2[BT:Rall]
             rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
-            # layers 2-4 + softmax + NLL and - in TRAIN mode - their backward down to dS1, one launch (what backward() then skips)
-            pl.tail_fused = bool(rt.scorer_tail and self.is_training and self.novelty_reg_factor == 0.0 and Rc > 0 and d['sum_mask'] > 0
-                                 and L.entries['Ws2'].shape == (128, 64) and L.entries['Ws3'].shape == (64, 32))
-            if pl.tail_fused:
-                check(lib.cham_scorer_tail_fused(ptr(pl.S1), 128, ptr(p('Ws2')), ptr(p('bs2')), 64, ptr(p('Ws3')), ptr(p('bs3')), 32, ptr(p('Ws4')),
-                                                 ptr(p('bs4')), BT, N, float(self.softmax_temperature), float(d['sum_mask']), ptr(pl.mask), ptr(pl.S2),
-                                                 ptr(pl.S3), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), ptr(pl.ds), ptr(pl.dS3), ptr(pl.dS2),
-                                                 ptr(pl.dS1), s), "cham_scorer_tail_fused")
-            else:
-                rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
-                rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
+            rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
+            rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
             softmax_fwd = lib.cham_score_softmax_fwd
-        if not getattr(pl, 'tail_fused', False):
-            check(softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
-                              ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
-                              ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
+        check(softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
+                          ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
+                          ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
@@ -1320,12 +1306,10 @@ class NARModuleModel:
 
         rt.grads[:L.emb_end].zero_()
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
-        tail_fused = getattr(pl, 'tail_fused', False)      # forward() already ran the scorer's layers 2-4 backward (ds, dS3, dS2, dS1)
-        if not tail_fused:
-            check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
-                ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), d['sum_mask'],
-                ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
-                ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
+        check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
+            ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), d['sum_mask'],
+            ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
+            ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
         if self._dev_state.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
@@ -1336,9 +1320,8 @@ class NARModuleModel:
             rt.gemm_b16(pl.dS2, 64, 0, sh['Ws2'], 64, 1, pl.dS1, 128, 0, Rc, 128, 64, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
             Z2c, dZ2c = pl.Z2c[:Rc], pl.dZ2c[:Rc]
         else:
-            if not tail_fused:
-                rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
-                rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
+            rt.gemm(pl.dS3, p('Ws3'), pl.dS2, Rc, 64, 32, 32, 32, 64, transB=1, dref=pl.S2, ldr=64, dact=ACT_LEAKY)
+            rt.gemm(pl.dS2, p('Ws2'), pl.dS1, Rc, 128, 64, 64, 64, 128, transB=1, dref=pl.S1, ldr=128, dact=ACT_LEAKY)
             if not (use_p3 and rt.dm_fused and 32 <= NC <= 256):
                 pl.ensure_rows('dZ2')          # the scorer layer-1 dgrad goes through HBM
             Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]

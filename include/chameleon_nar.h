@@ -341,16 +341,6 @@ int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float
                            float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor, const int64_t* neg_ids,
                            const float* pop_norm, const float* logits, const float* nov_aux, void* stream);
 
-/* Scorer layers 2-4 + softmax(/tau) + masked NLL + their backward down to the gradient at the layer-1 OUTPUT in one launch (round 5;
- * nar_model.py:452-473 matching_dense_layer_2..4, :511-517 softmax, :639-667 loss, and the autodiff of those lines): one wave per position,
- * a candidate row per lane, weights in LDS.  S1 [BT (1+N), K1 = 128] (layer-1 output) -> S2 [., 64], S3 [., 32], logits / probs [BT, 1+N],
- * nll [BT], ds [BT (1+N)] = dL/dlogit, dS3, dS2, dS1 = (dS2 W2^T) leaky'(S1).  Replaces cham_gemm_* (layers 2, 3 and their dgrads) +
- * cham_score_softmax_fwd / _bwd in TRAIN mode of the fp32 configurations when the novelty regulariser is off; widths 128 -> 64 -> 32 -> 1 only,
- * -EINVAL otherwise.  sum_mask = the GLOBAL number of valid positions (the loss denominator). */
-int cham_scorer_tail_fused(const float* S1, int K1, const float* W2, const float* b2, int K2, const float* W3, const float* b3, int K3,
-                           const float* w4, const float* b4, int BT, int N, float tau, float sum_mask, const uint8_t* mask, float* S2, float* S3,
-                           float* logits, float* probs, float* nll, float* ds, float* dS3, float* dS2, float* dS1, void* stream);
-
 /* evaluation: rank_items_by_predicted_prob, nar_model.py:777-794 (tf.nn.top_k over 1+N: descending, lowest index wins
  * ties).  pred_ids/pred_probs [BT, 1+N]; label_rank[bt] = 0-based rank of the positive, -1 for padded clicks - the input of
  * HitRate@n / MRR@n (metrics.py:40-66, 109-134; TF twins nar_model.py:826-835, 859-885) */
