@@ -517,6 +517,89 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(P3Params p) {
         const __amdgpu_buffer_rsrc_t cw = make_window(Cb + (size_t)m0 * p.ldc + n0);
         const __amdgpu_buffer_rsrc_t dw = make_window(EPI == 13 ? (const void*)(p.dref + (size_t)m0 * p.ldr + n0) : (const void*)Cb);
         const __amdgpu_buffer_rsrc_t bw = make_window(EPI == 12 ? (const void*)(p.bias + n0) : (const void*)Cb);
+        // ---- interior wave tiles: the epilogue goes THROUGH LDS (round 5).  With swapped operands a lane owns a ROW and four consecutive
+        // columns: its 8-byte stores (and the dgrad's 8-byte loads of the saved activation) hit 32 different rows per instruction - 32
+        // sixteen-byte fragments of 32 different lines.  Measured with the stores compiled out: 0.548 ms against 0.713 ms for the plain
+        // NT product, and another 0.15 ms for the dgrad's loads (profiles/r05_notes.md section 6): the NT forms' gap to the TN form is this
+        // access pattern.  Here a wave packs its 128 x 64 bf16 outputs into 16 KB of the (now free) ring - row pitch 128 bytes, 16-byte piece
+        // q of row r at slot q ^ ((r >> 1) & 7), the two 8-byte halves of a piece swapped on rows with bit 4 set (ds_write_b64 of 32 rows x one
+        // column group: 32 different bank pairs) - reads it back 16 bytes per lane (8 lanes = one whole 128-byte row segment; two rows per 16
+        // lanes = all 64 banks) and stores / loads global memory in whole lines: 16 b128 accesses per lane instead of 32 b64.
+        // The dgrad (EPI 13) works in two halves of 64 rows: [saved activation | outputs] share the wave's 16 KB.
+        p3_barrier();                 // every wave is past its last fragment read; no DMA in flight (vmcnt(0) above): the ring is free
+        if (limM >= wm0 + 128 && limN >= wn0 + 64) {          // wave-uniform
+            unsigned char* Rg = p3_smem + (unsigned)wave * 16384u;
+            const unsigned lr = (unsigned)(lane >> 3), ls = (unsigned)(lane & 7);
+            auto slot_off = [](unsigned r, unsigned pp, unsigned half) -> unsigned {
+                return r * 128u + (((pp ^ (r >> 1)) & 7u) << 4) + (((half ^ (r >> 4)) & 1u) << 3);
+            };
+            if constexpr (EPI != 13) {
+#pragma unroll
+                for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4 bv;
+                        if constexpr (EPI == 12) bv = __builtin_amdgcn_raw_buffer_load_b128(bw, (unsigned)(wn0 + j * 32 + 8 * q + 4 * kl) * 4u, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            if constexpr (EPI == 12) {
+                                v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
+                                v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
+                            }
+                            u32x2 w;
+                            w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(Rg + slot_off((unsigned)(32 * i + fl), (unsigned)(4 * j + q), (unsigned)kl)) = w;
+                        }
+                    }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const unsigned r = 8u * t + lr;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(Rg + r * 128u + ls * 16u);
+                    if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
+                    const unsigned pp = (ls ^ (r >> 1)) & 7u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                }
+            } else {
+                unsigned char* Dg = Rg;                     // saved activation, 64 rows
+                unsigned char* Og = Rg + 8192;              // outputs, 64 rows
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned r = 8u * t + lr, pp = (ls ^ (r >> 1)) & 7u;
+                        u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(dw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldr + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                        if ((r >> 4) & 1u) { const unsigned a = y.x, b = y.y; y.x = y.z; y.y = y.w; y.z = a; y.w = b; }
+                        *reinterpret_cast<u32x4*>(Dg + r * 128u + ls * 16u) = y;
+                    }
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int i = 2 * h + ih;
+                                const unsigned off = slot_off((unsigned)(32 * ih + fl), (unsigned)(4 * j + q), (unsigned)kl);
+                                const u32x2 y = *reinterpret_cast<const u32x2*>(Dg + off);
+                                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                                v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
+                                v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
+                                u32x2 w;
+                                w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                                *reinterpret_cast<u32x2*>(Og + off) = w;
+                            }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned r = 8u * t + lr;
+                        u32x4 v = *reinterpret_cast<const u32x4*>(Og + r * 128u + ls * 16u);
+                        if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
+                        const unsigned pp = (ls ^ (r >> 1)) & 7u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = wm0 + i * 32 + fl;
