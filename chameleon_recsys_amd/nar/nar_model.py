@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import _roctx
 from .._lib import check, ptr
 from .clicked_items_state import lane_stream
 from .layout import COL_ITEMEMB, ParamLayout
@@ -1039,6 +1040,7 @@ class NARModuleModel:
             step = rt.global_step if self.is_training else self.eval_step_key(rt.global_step, self._eval_iter)
         p = rt.p
         # K0 negative sampling (nar_model.py:265-276) - unless presample() already drew this batch's negatives for this key
+        _roctx.push("K0 negative sampling")
         ps = d.pop('_presampled', None)
         if ps is not None and ps[0] is pl and ps[2] == step and st.get('device'):
             pl.use_sampler_set(ps[1])
@@ -1066,6 +1068,7 @@ class NARModuleModel:
         if getattr(pl, 'grouped_ev', None) is not None:
             torch.cuda.current_stream().wait_event(pl.grouped_ev)
         # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
+        _roctx.pop(); _roctx.push("K1 features (gather, normalise, scale / center)")
         pl.ids_all[:BT].copy_(d['ic_rows'])
         pl.ids_all[BT:2 * BT].copy_(d['ln_rows'])
         pl.ids_all[2 * BT:2 * BT + pmax].copy_(pl.pool)
@@ -1121,6 +1124,7 @@ class NARModuleModel:
             torch.cuda.current_stream().wait_event(shadows_ev)
         else:
             rt.refresh_shadows()
+        _roctx.pop(); _roctx.push("K2 PreCAR + CAR, K3 recurrent branch (side lane)")
         drop = self.is_training and self.keep_prob < 1.0
         # (full batches only: with ragged sessions the side lane's recurrent chain IS the critical path and the two launches are better
         # off on the main lane - G1-like lengths 114-115 k vs 111-112 k sessions/s, profiles/r05_notes.md)
@@ -1231,6 +1235,7 @@ class NARModuleModel:
                 rt.gemm(pl.Z1[BT:], p('W2'), pl.Z2[BT:], Rc, C, C, C, C, C, bias=p('b2'), act=ACT_TANH)
             rt.join()
             # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
+            _roctx.pop(); _roctx.push("K5 scorer, softmax, loss")
             Z2c = pl.Z2[BT:Rall]
             rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
             rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
@@ -1242,6 +1247,7 @@ class NARModuleModel:
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
         check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
               "cham_loss_finalize")
+        _roctx.pop()
         self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
         if not self.is_training and st.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in an EVAL step
@@ -1686,11 +1692,14 @@ class NARModuleModel:
                 d = staged[1]
             else:
                 d = self.upload_batch(self.inputs, self.labels)
-        pl = self.forward(d)
+        with _roctx.range_("NAR step: forward (K0 sampler .. loss)"):        # (CHAM_ROCTX=1: roctx ranges for rocprofv3 --marker-trace)
+            pl = self.forward(d)
         if self.eval_cold_start:       # nar_model.py:520: the ranked candidates are also needed while TRAINING for the cold-start analysis
             self._rank_items(pl, d)
-        self.backward()
-        self.apply_gradients()
+        with _roctx.range_("NAR step: backward"):
+            self.backward()
+        with _roctx.range_("NAR step: exchange + L2 + TF-Adam"):
+            self.apply_gradients()
         return self.total_loss
 
     @staticmethod

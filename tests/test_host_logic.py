@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: the StepPlan cache policy and the environment-switch defaults documented in DESIGN.md."""
+import os
 import re
 
 from chameleon_recsys_amd.nar import nar_model
@@ -63,3 +64,23 @@ def test_documented_switch_defaults_match_the_code():
         assert row, name
         if name in ("CHAM_COMPACT", "CHAM_OVERLAP", "CHAM_PRESAMPLE", "CHAM_GEMM_H2", "CHAM_GEMM_P3"):
             assert "| %s |" % default in row[0], (name, default, row[0])
+
+
+def test_roctx_ranges_are_noops_unless_asked_for():
+    """chameleon_recsys_amd/_roctx.py: without CHAM_ROCTX the stage ranges of a step cost nothing and load nothing; with CHAM_ROCTX=1 they go through
+    the ROCm tools extension library (rocprofv3 --marker-trace shows them)."""
+    import subprocess
+    import sys
+    from chameleon_recsys_amd import _roctx
+    if os.environ.get("CHAM_ROCTX", "0") != "1":
+        assert not _roctx.enabled() and _roctx.push("x") == -1 and _roctx.pop() == -1
+        with _roctx.range_("y"):
+            pass
+    code = ("import os; os.environ['CHAM_ROCTX'] = '1'\n"
+            "from chameleon_recsys_amd import _roctx\n"
+            "print(int(_roctx.enabled()), _roctx.push('a') if _roctx.enabled() else 0, _roctx.pop() if _roctx.enabled() else 0)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr
+    on, a, b = (int(x) for x in r.stdout.split())
+    if os.path.exists("/opt/rocm/lib/libroctx64.so") or os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so"):
+        assert on == 1 and a >= 0 and b >= 0, r.stdout
