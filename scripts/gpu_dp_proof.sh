@@ -12,7 +12,7 @@ export TMPDIR=/tmp PYTHONPATH=$R CHAM_DIST_BACKEND=gloo
 for cfg in "allreduce weak" "sparse weak" "allreduce strong" "sparse strong" "sparse_rs weak"; do
   set -- $cfg
   CHAM_DP_MODE=$1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 8 --steps 4 --warmup 2 --no-cpu-baseline --no-boundary-leg --no-ragged-leg --scaling $2 2>&1 | grep '^{' | python -c "
+    bench.py --gpus 8 --steps 4 --warmup 2 --no-cpu-baseline --no-boundary-leg --no-ragged-leg --no-native-arm --no-arms --no-pmc --scaling $2 2>&1 | grep '^{' | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 print(json.dumps(dict(dp_mode='$1', scaling=d['scaling'], transport='gloo, 8 ranks on ONE MI355X (functional proof, not a scaling result)', n_gpus=d['n_gpus'],
