@@ -116,10 +116,13 @@ class DataParallelNAR:
             rt.weights_version = getattr(rt, 'weights_version', 0) + 1
 
     # ---- early bucket (see __init__)
-    def _comm_buffer(self, flat_grads):
-        """bf16 image of the flat gradient buffer (allocated once; slices of it go through the collectives)."""
-        if self._comm16 is None or self._comm16.numel() != flat_grads.numel() or self._comm16.device != flat_grads.device:
-            self._comm16 = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
+    def _comm_buffer(self, flat_grads, n=None):
+        """bf16 communication buffer (allocated once; slices of it go through the collectives): an image of the whole flat gradient
+        buffer in the dense mode, `n` elements - the dense remainder - in the sparse modes (at config 5 the flat buffer is 1.9 G entries,
+        the dense remainder 3 M)."""
+        need = flat_grads.numel() if n is None else int(n)
+        if self._comm16 is None or self._comm16.numel() < need or self._comm16.device != flat_grads.device:
+            self._comm16 = torch.empty(need, dtype=torch.bfloat16, device=flat_grads.device)
         return self._comm16
 
     def _reduce_range(self, flat_grads, a, b, async_op=False):
@@ -197,7 +200,7 @@ class DataParallelNAR:
         check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
         dense16 = None
         if self.comm_bf16 and n_dense:          # dense remainder in bf16 (its own collective), the touched rows fp32
-            dense16 = self._comm_buffer(flat_grads)[:n_dense]
+            dense16 = self._comm_buffer(flat_grads, n_dense)[:n_dense]
             dense16.copy_(comm[:n_dense])
             dist.all_reduce(dense16, op=dist.ReduceOp.SUM, group=self.pg)
             comm[:n_dense].copy_(dense16)
