@@ -77,7 +77,7 @@ class DataParallelNAR:
             raise ValueError("CHAM_DP_MODE=sharded exchanges fp32 (the owner rank's Adam reads the reduce-scatter's output): CHAM_DP_GRAD_DTYPE=bf16 "
                              "is for the allreduce / sparse / sparse_rs modes")
         self.comm_bf16 = self.mode != "sharded" and (want == "bf16" or (want == "auto" and getattr(rt, 'gemm_dtype', 'f32') == 'bf16'))
-        self._comm16 = None
+        self._comm16, self._early16 = None, None
         self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
         # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
         # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
@@ -125,30 +125,33 @@ class DataParallelNAR:
             self._comm16 = torch.empty(need, dtype=torch.bfloat16, device=flat_grads.device)
         return self._comm16
 
-    def _reduce_range(self, flat_grads, a, b, async_op=False):
+    def _reduce_range(self, flat_grads, a, b, async_op=False, buf16=None):
         """all-reduce(SUM) of flat_grads[a:b] in the exchange dtype; returns (work or None, bytes handed to the collective).  In bf16 the
-        caller widens the reduced slice back with _widen_range once the collective has finished."""
+        range is rounded into `buf16` (default: its place in the whole-buffer image) and the caller widens it back with _widen_range once
+        the collective has finished."""
         if self.comm_bf16:
-            buf = self._comm_buffer(flat_grads)[a:b]
+            buf = self._comm_buffer(flat_grads)[a:b] if buf16 is None else buf16
             buf.copy_(flat_grads[a:b])           # fp32 -> bf16, round to nearest even
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 2 * (b - a)
         return dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 4 * (b - a)
 
-    def _widen_range(self, flat_grads, a, b):
+    def _widen_range(self, flat_grads, a, b, buf16=None):
         if self.comm_bf16:
-            flat_grads[a:b].copy_(self._comm16[a:b])
+            flat_grads[a:b].copy_(self._comm16[a:b] if buf16 is None else buf16)
 
     def _issue_early_bucket(self, flat_grads):
         """Called by the backward pass on the lane that produced the bucket, right after its last gradient was written."""
         a, b = self._early
-        self._early_work, self._early_bytes = self._reduce_range(flat_grads, a, b, async_op=True)
+        if self.comm_bf16 and (self._early16 is None or self._early16.numel() != b - a or self._early16.device != flat_grads.device):
+            self._early16 = torch.empty(b - a, dtype=torch.bfloat16, device=flat_grads.device)      # (its own small buffer: the sparse modes never build the whole-buffer image)
+        self._early_work, self._early_bytes = self._reduce_range(flat_grads, a, b, async_op=True, buf16=self._early16 if self.comm_bf16 else None)
         self._early_grads = flat_grads
 
     def _wait_early_bucket(self):
         if self._early_work is not None:
             self._early_work.wait()            # (stream-ordered for RCCL: the current stream waits for the collective)
             self._early_work = None
-            self._widen_range(self._early_grads, *self._early)
+            self._widen_range(self._early_grads, *self._early, buf16=self._early16)
             return True
         return False
 
