@@ -15,6 +15,7 @@ _SIGNATURES = {
                                 P, c_size_t, P]),
     "cham_ctx_assemble": (c_int, [P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "cham_set_log_bases": (c_int, [c_float, c_float]),
+    "cham_step_ints": (c_int, [P, P, P, P, c_int64, c_int, c_int, P, c_int, P, P, P, P, P, P]),
     "cham_item_dynamic_raw": (c_int, [P, P, c_int, P, P, P, P, P]),
     "cham_norm_stats_from_recent": (c_int, [P, c_int, c_int64, P, P, P, P, P]),
     "cham_norm_stats_from_buffer": (c_int, [P, c_int, c_int64, P, P, P, P, P]),

@@ -807,3 +807,38 @@ extern "C" int cham_dense_rows(const float* Xc_s, int Fc, const float* Xi_s, int
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+
+// ---- head of a step: the integer row sets in ONE launch (round 5; eight copy / fill launches of NARModuleModel.forward before):
+//   ids_all = [clicked ids (BT) | positive ids (BT) | candidate pool (pmax) | pad item 0], ref_ts = [click time stamps (BT) | max_ts ...],
+//   seq_len (B, int32) and mask (BT, uint8) into the plan's buffers.  nar_model.py:217-248 (inputs / mask block), :343, 356 (reference time
+//   stamps of positive / negative rows = the batch's max time stamp).
+__global__ __launch_bounds__(256) void k_step_ints(const int64_t* __restrict__ ic, const int64_t* __restrict__ ln, const int64_t* __restrict__ pool,
+                                                   const int64_t* __restrict__ ets, int64_t max_ts, int BT, int pmax,
+                                                   const int32_t* __restrict__ seq_len_in, int B, const unsigned char* __restrict__ mask_in,
+                                                   int64_t* __restrict__ ids_all, int64_t* __restrict__ ref_ts, int32_t* __restrict__ seq_len,
+                                                   unsigned char* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x, RV = 2 * BT + pmax + 1;
+    if (i < RV) {
+        int64_t id;
+        if (i < BT) id = ic[i];
+        else if (i < 2 * BT) id = ln[i - BT];
+        else if (i < 2 * BT + pmax) id = pool[i - 2 * BT];
+        else id = 0;
+        ids_all[i] = id;
+        ref_ts[i] = i < BT ? ets[i] : max_ts;
+    }
+    if (i < B) seq_len[i] = seq_len_in[i];
+    if (i < BT) mask[i] = mask_in[i];
+}
+
+extern "C" int cham_step_ints(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, int64_t max_ts, int BT,
+                              int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts,
+                              int32_t* seq_len, uint8_t* mask, void* stream) {
+    if (!ic_rows || !ln_rows || !pool || !ets_rows || !seq_len_in || !mask_in || !ids_all || !ref_ts || !seq_len || !mask || BT < 0 || pmax < 0 || B < 0)
+        return -CHAM_ERR_ARG;
+    const int n = 2 * BT + pmax + 1 > B ? 2 * BT + pmax + 1 : B;
+    hipLaunchKernelGGL(k_step_ints, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ic_rows, ln_rows, pool, ets_rows, max_ts, BT, pmax,
+                       seq_len_in, B, mask_in, ids_all, ref_ts, seq_len, mask);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}

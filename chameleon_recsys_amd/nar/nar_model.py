@@ -1069,13 +1069,9 @@ class NARModuleModel:
             torch.cuda.current_stream().wait_event(pl.grouped_ev)
         # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
         _roctx.pop(); _roctx.push("K1 features (gather, normalise, scale / center)")
-        pl.ids_all[:BT].copy_(d['ic_rows'])
-        pl.ids_all[BT:2 * BT].copy_(d['ln_rows'])
-        pl.ids_all[2 * BT:2 * BT + pmax].copy_(pl.pool)
-        if pos is not None:
-            pl.ids_all[2 * BT + pmax:2 * BT + pmax + 1].zero_()      # the pad item row moves with P
-        pl.ref_ts[:BT].copy_(d['ets_rows'])
-        pl.ref_ts[BT:RV].fill_(d['max_ts'])
+        # (one launch - round 5: eight copy / fill launches before - also seq_len and the position mask of the stages below)
+        check(lib.cham_step_ints(ptr(d['ic_rows']), ptr(d['ln_rows']), ptr(pl.pool), ptr(d['ets_rows']), int(d['max_ts']), BT, pmax, ptr(d['seq_len']),
+                                 B, ptr(d['mask']), ptr(pl.ids_all), ptr(pl.ref_ts), ptr(pl.seq_len), ptr(pl.mask), s), "cham_step_ints")
         pl.grouped_ev = None
         if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
             if rt.overlap:        # ~10 launches nobody needs before the end of the backward: on the side lane, behind the id copies above
@@ -1129,7 +1125,6 @@ class NARModuleModel:
         # (full batches only: with ragged sessions the side lane's recurrent chain IS the critical path and the two launches are better
         # off on the main lane - G1-like lengths 114-115 k vs 111-112 k sessions/s, profiles/r05_notes.md)
         head_split = rt.head_split and rt.overlap and BT * NC > rt.w2_main_rows
-        pl.seq_len.copy_(d['seq_len']); pl.mask[:BT].copy_(d['mask'])
         if drop:
             # dropout_keep_prob < 1 (nar_model.py:338, 352, 368): the per-element masks make every CAR row occurrence-specific, so
             # the PreCAR layer runs on the dense [clicked | candidates] x [ctx | item] rows instead of the factorised U + V form

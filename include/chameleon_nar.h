@@ -45,6 +45,12 @@ int cham_ctx_assemble(const int64_t* cat, const float* num, int R, const int64_t
  * > 0 and != 1. */
 int cham_set_log_bases(float elapsed_days_smooth_log_base, float popularity_smooth_log_base);
 
+/* head of a step, the integer row sets in one launch (nar_model.py:217-248, 343, 356): ids_all [2 BT + pmax + 1] = [clicked ids | positive ids |
+ * candidate pool | pad item 0], ref_ts = [click time stamps | max_ts ...], seq_len [B] and mask [BT] copied into the step's buffers */
+int cham_step_ints(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, int64_t max_ts, int BT, int pmax,
+                   const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts, int32_t* seq_len, uint8_t* mask,
+                   void* stream);
+
 /* raw recency log_1.3(1+relu((f32(ts)-f32(created))/86.4e6)) and novelty -log2(pop_norm): nar_model.py:1055-1060,
  * 1074, 1147-1148 */
 int cham_item_dynamic_raw(const int64_t* ids, const int64_t* ref_ts, int R, const int64_t* created, const float* pop_norm,
