@@ -37,6 +37,20 @@ def test_plan_cache_evicts_least_recently_used_shape(monkeypatch):
     assert rt.plan(256, 11, 50, 3000) is not b              # b was dropped and is rebuilt
 
 
+def test_warm_plans_builds_every_padded_length_once(monkeypatch):
+    """NARRuntime.warm_plans (round 5): a trainer's warm-up builds the buffer set of every padded length T <= truncate_session_length - 1, so
+    that no step of the run allocates (bench.py's boundary legs: step_plans_created_in_timed_steps == 0); within the cache's own limits."""
+    rt = _runtime(24, 1 << 60, monkeypatch)
+    rt.warm_plans(256, range(1, 20), 50, 3000)
+    assert [p.key[1] for p in rt._plans.values()] == list(range(1, 20)) and rt.plans_created == 19
+    first = dict(rt._plans)
+    rt.warm_plans(256, range(1, 20), 50, 3000)                            # a second call finds them all
+    assert rt.plans_created == 19 and all(rt._plans[k] is v for k, v in first.items())
+    rt2 = _runtime(4, 1 << 60, monkeypatch)
+    rt2.warm_plans(256, range(1, 20), 50, 3000)                          # more lengths than the cache holds: the last ones stay
+    assert [p.key[1] for p in rt2._plans.values()] == [16, 17, 18, 19]
+
+
 def test_plan_cache_respects_byte_budget(monkeypatch):
     one = nar_model.StepPlan.estimate_bytes(type("L", (), {"C": 1024}), 256, 19, 50)
     assert 4.0e9 < one < 6.0e9                              # G1 shape: ~4.4 GB of CAR / scorer activations
