@@ -151,7 +151,7 @@ def gemm_symbol(r):
     if r.get('x3'):       # fp32 through three bf16 planes (csrc/gemm_x3.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
         rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
-        return "void gemm_x3_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs))
+        return "void gemm_x3_kernel<%d, %d, %d, %d, %s, %s, %d, %s, %d>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs), 2 if r.get('x2h') else 3)
     bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
     rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
     if r['bf16']:
@@ -590,13 +590,15 @@ def main():
              "products per fp32 product, fp32 accumulate, LDS-DMA staging)" if r.get('h2') else
              "fp32-grade (operands resident in HBM as three bf16 planes written by their producers, six bf16 MFMA products per fp32 product, "
              "fp32 accumulate, LDS-DMA staging)" if r.get('p3') else
+             "fp32-grade (two fp16 planes x a power-of-two scale per operand, split while staged, three fp16 MFMA products per fp32 product, "
+             "fp32 accumulate)" if r.get('x2h') else
              "fp32 (three bf16 planes per operand, six bf16 MFMA products per fp32 product, fp32 accumulate)" if r.get('x3') else "fp32"), mode, EPI_NAMES.get(r['epi'], "?"), ", row-scale prologue" if r['rowscale'] else "",
             r['M'], r['N'], r['K'])
 
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (H2_MATRIX_PEAK_TFLOPS if e['r'].get('h2') else
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (H2_MATRIX_PEAK_TFLOPS if (e['r'].get('h2') or e['r'].get('x2h')) else
                                                                X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3') or e['r'].get('dmf')) else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
@@ -708,8 +710,9 @@ def main():
                        "gemm": {"f32": ("fp32 accumulate / epilogues, fp32-grade error (float64-error bar next to the native fp32 MFMA: tests/test_gemm_h2_gpu.py, "
                                         "tests/test_gemm_x3_gpu.py): the three candidate-row CAR GEMMs as THREE fp16-plane products per fp32 product over "
                                         "(h, l) fp16 planes x a device-derived power-of-two scale that their producers wrote to HBM (csrc/gemm_h2.hip, "
-                                        "v_mfma_f32_32x32x16_f16; the NT forms stage 64-byte source pieces: gemm_h2w_kernel); the other GEMMs with N > 64 as six bf16-plane "
-                                        "products split while staged (csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32.  Accuracy contract of the "
+                                        "v_mfma_f32_32x32x16_f16; the NT forms stage 64-byte source pieces: gemm_h2w_kernel); the scorer's first layer over cand (.) pred and its weight gradient as three fp16-plane "
+                                        "products too, split while staged (cham_gemm_f32x2h = gemm_x3_kernel<..., 2>, tests/test_gemm_x2h_gpu.py); the other GEMMs "
+                                        "with N > 64 as six bf16-plane products split while staged (csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32.  Accuracy contract of the "
                                         "two-plane operands: relative to the MATRIX bound, not to each row - fp32 grade for rows within 2^-18 of the largest "
                                         "entry, an absolute error of 2^-40 of the bound below that (INTEGRATION.md)") if getattr(rt, 'h2', False) else
                                        ("fp32 accumulate / epilogues; GEMMs with N > 64 as six bf16-plane products per fp32 product on "

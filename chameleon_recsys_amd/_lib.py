@@ -37,6 +37,8 @@ _SIGNATURES = {
                                P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_f32x3": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int,
                                 P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
+    "cham_gemm_f32x2h": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int,
+                                 P, c_int, c_int, c_int, P, c_size_t, c_int, P, P, P]),
     "cham_gemm_f32x3_set_variant": (None, [c_int]),
     "cham_gemm_f32x3_launch_counts": (None, [P, c_int]),
     "cham_gemm_p3": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
@@ -49,6 +51,7 @@ _SIGNATURES = {
     "cham_dm_mulpred_p3": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
     "cham_h2_scale_absmax": (c_int, [P, c_size_t, P, c_size_t, P, P]),
     "cham_h2_scale_rownorm": (c_int, [P, c_long, c_int, c_int, P, P, P]),
+    "cham_h2_scale_rownorm2": (c_int, [P, c_long, c_int, c_int, P, P, P, P]),
     "cham_split2h": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P, c_int, P]),
     "cham_gemm_h2": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                              P, c_size_t, c_int, P]),

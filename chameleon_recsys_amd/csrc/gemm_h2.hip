@@ -568,9 +568,11 @@ __global__ __launch_bounds__(256) void k_h2_scale_absmax(const float* __restrict
 }
 
 // bound = max over rows of ||X[r, 0:K]||_2, times *factor when given: the Cauchy-Schwarz bound of |d[r,:] . w[c,:]| over all (r, c) is
-// (max row norm of d) x (max row norm of w).  K == 128: half a wave per row; otherwise a wave per row.
+// (max row norm of d) x (max row norm of w).  K == 128: half a wave per row; otherwise a wave per row.  rec_plain (optional): a second
+// record from the same pass WITHOUT the factor - max row norm of X >= max |X|, the scale of X itself as a two-plane operand
+// (cham_gemm_f32x2h: dS1 in the scorer's layer-1 weight gradient).
 __global__ __launch_bounds__(256) void k_h2_scale_rownorm(const float* __restrict__ X, long R, int K, int ld, const float* __restrict__ factor,
-                                                          H2Scale* __restrict__ rec) {
+                                                          H2Scale* __restrict__ rec, H2Scale* __restrict__ rec_plain) {
     __shared__ float red[4];
     __shared__ unsigned last;
     const int lane = threadIdx.x & 63;
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(256) void k_h2_scale_rownorm(const float* __restric
             // be missed by a rounding
             const float b = sqrtf(sq) * (factor ? *factor : 1.f) * 1.0009765625f;
             h2_finish_scale(rec, b);
+            if (rec_plain) h2_finish_scale(rec_plain, sqrtf(sq) * 1.0009765625f);
             rec->max_bits = 0u; rec->ticket = 0u;
         }
     }
@@ -619,15 +622,19 @@ extern "C" int cham_h2_scale_absmax(const float* x0, size_t n0, const float* x1,
     return CHAM_OK;
 }
 
-extern "C" int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream) {
-    if (!X || !rec || R < 0 || K <= 0 || ld < K || ((uintptr_t)rec & 15)) return -CHAM_ERR_ARG;
+extern "C" int cham_h2_scale_rownorm2(const float* X, long R, int K, int ld, const float* factor, void* rec, void* rec_plain, void* stream) {
+    if (!X || !rec || R < 0 || K <= 0 || ld < K || (((uintptr_t)rec | (uintptr_t)rec_plain) & 15) || rec == rec_plain) return -CHAM_ERR_ARG;
     if (K == 128 && ((ld & 3) || ((uintptr_t)X & 15))) return -CHAM_ERR_ARG;
     const long per = K == 128 ? 8 : 4;                 // rows per workgroup and pass
     long blocks = (R + per - 1) / per;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);       // (same-address atomics per workgroup: see cham_h2_scale_absmax)
-    hipLaunchKernelGGL(k_h2_scale_rownorm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, R, K, ld, factor, reinterpret_cast<H2Scale*>(rec));
+    hipLaunchKernelGGL(k_h2_scale_rownorm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, R, K, ld, factor, reinterpret_cast<H2Scale*>(rec),
+                       reinterpret_cast<H2Scale*>(rec_plain));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream) {
+    return cham_h2_scale_rownorm2(X, R, K, ld, factor, rec, nullptr, stream);
 }
 
 // ---- split of an fp32 matrix into its two planes with the scale of `rec` (weights, once per step; test helper for whole operands)

@@ -24,6 +24,7 @@ struct GemmParams {
     int kchunk; int splits; float* partial;
     int nbm, nbn;
     int xcd_split;                  // split-K workgroup placement: one K-split per XCD (see the kernels' tile mapping)
+    const float* sa; const float* sb;      // gemm_x3.hip, two-fp16-plane form only: the operands' H2Scale records (device); NULL otherwise
 };
 
 
@@ -359,7 +360,7 @@ static inline int gemm_plan(GemmParams& p, const float* A, int lda, int transA, 
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.act = act; p.dref = dref; p.ldr = ldr; p.dact = dact;
     p.rs = rowscale; p.ldrs = ldrs; p.rs_div = rs_div > 0 ? rs_div : 1;
-    p.accumulate = accumulate; p.partial = workspace; p.xcd_split = 0;
+    p.accumulate = accumulate; p.partial = workspace; p.xcd_split = 0; p.sa = nullptr; p.sb = nullptr;
     int splits = 1;
     // the split-K reductions (gemm_splitk_reduce / _wide) walk the output in float4 groups of one row and read the bias 16 bytes at a
     // time: an output width that is not a multiple of four (only possible with transB) or a misaligned bias takes the unsplit kernel

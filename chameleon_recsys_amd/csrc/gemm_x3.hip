@@ -29,6 +29,7 @@
 
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 x2h_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void x3_split(float a, __bf16& h, __bf16& m, __bf16& l) {
@@ -42,7 +43,8 @@ __device__ __forceinline__ void x3_split(float a, __bf16& h, __bf16& m, __bf16& 
 //   !XK (free index contiguous: B of NN, A and B of TN): unit = one float4 = 4 consecutive rows of one k; LDS image [k][row], row
 //       stride BF + 8; one ds_write_b64 per plane straight through - the transposition happens in the fragment read
 //       (ds_read_b64_tr_b16, as in gemm_b16.hip), not in registers.
-template <int BF, int BK, bool XK, int NTH, bool RS>
+//   NP = 3: three bf16 planes (x3_split) | NP = 2: TWO fp16 planes of x * scale (split2h of common.h; plane 0 = h, plane 1 = l)
+template <int BF, int BK, bool XK, int NTH, bool RS, int NP = 3>
 struct StageX3 {
     static constexpr int LD = XK ? BK + 8 : BF + 8;
     static constexpr int PLANE = XK ? BF * LD : BK * LD;                    // elements of one plane of one buffer
@@ -58,9 +60,21 @@ struct StageX3 {
     unsigned off[NV];        // window-local byte offset of the unit (OOB_OFF: free index out of range / no unit)
     unsigned soff[NV];
     int k0u[NV];             // tile-local k of the unit's first element
+    float sc;                // NP == 2: the operand's power-of-two scale (H2Scale record, wave-uniform)
+    // one element -> its planes (x = h, z = l, y = the middle bf16 plane of NP == 3)
+    __device__ __forceinline__ void split(float a, __bf16& x, __bf16& y, __bf16& z) const {
+        if constexpr (NP == 2) {
+            _Float16 h, l;
+            split2h(a * sc, h, l);
+            x = __builtin_bit_cast(__bf16, h); z = __builtin_bit_cast(__bf16, l); y = z;
+        } else {
+            x3_split(a, x, y, z);
+        }
+    }
 
-    __device__ __forceinline__ void init(int ld, int limF, int f0, int ldrs, int rs_div, bool has_rs) {
+    __device__ __forceinline__ void init(int ld, int limF, int f0, int ldrs, int rs_div, bool has_rs, float scale = 1.f) {
         const int tid = threadIdx.x;
+        sc = scale;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int u = tid + i * NTH;
@@ -126,29 +140,29 @@ struct StageX3 {
                 const int fr = u / (BK / 8), kc = u % (BK / 8);
                 bf16x8 h, m, l;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { __bf16 x, y, z; x3_split(__uint_as_float(comp(g.r[i][j >> 2], j & 3)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
+                for (int j = 0; j < 8; ++j) { __bf16 x, y, z; split(__uint_as_float(comp(g.r[i][j >> 2], j & 3)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
                 __bf16* d = S + fr * LD + kc * 8;
                 *reinterpret_cast<bf16x8*>(d) = h;
-                *reinterpret_cast<bf16x8*>(d + PLANE) = m;
-                *reinterpret_cast<bf16x8*>(d + 2 * PLANE) = l;
+                if constexpr (NP == 3) *reinterpret_cast<bf16x8*>(d + PLANE) = m;
+                *reinterpret_cast<bf16x8*>(d + (NP - 1) * PLANE) = l;
             } else if (XK) {
                 const int fr = u / (BK / 4), kc = u % (BK / 4);
                 bf16x4 h, m, l;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { __bf16 x, y, z; x3_split(__uint_as_float(comp(g.r[i][0], j)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
+                for (int j = 0; j < 4; ++j) { __bf16 x, y, z; split(__uint_as_float(comp(g.r[i][0], j)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
                 __bf16* d = S + fr * LD + kc * 4;
                 *reinterpret_cast<bf16x4*>(d) = h;
-                *reinterpret_cast<bf16x4*>(d + PLANE) = m;
-                *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = l;
+                if constexpr (NP == 3) *reinterpret_cast<bf16x4*>(d + PLANE) = m;
+                *reinterpret_cast<bf16x4*>(d + (NP - 1) * PLANE) = l;
             } else {
                 const int k = u / (BF / 4), f4 = u % (BF / 4);
                 bf16x4 h, m, l;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { __bf16 x, y, z; x3_split(__uint_as_float(comp(g.r[i][0], j)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
+                for (int j = 0; j < 4; ++j) { __bf16 x, y, z; split(__uint_as_float(comp(g.r[i][0], j)), x, y, z); h[j] = x; m[j] = y; l[j] = z; }
                 __bf16* d = S + k * LD + f4 * 4;
                 *reinterpret_cast<bf16x4*>(d) = h;
-                *reinterpret_cast<bf16x4*>(d + PLANE) = m;
-                *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = l;
+                if constexpr (NP == 3) *reinterpret_cast<bf16x4*>(d + PLANE) = m;
+                *reinterpret_cast<bf16x4*>(d + (NP - 1) * PLANE) = l;
             }
         }
     }
@@ -162,7 +176,7 @@ struct StageX3 {
         float a = __uint_as_float(comp(g.r[i][k >> 2], k & 3));
         if constexpr (RS) a *= __uint_as_float(comp(g.sc[i][k >> 2], k & 3));
         __bf16 x, y, z;
-        x3_split(a, x, y, z);
+        split(a, x, y, z);
         c.h[i][k] = x; c.m[i][k] = y; c.l[i][k] = z;
     }
     __device__ __forceinline__ void write(const Conv& c, __bf16* __restrict__ S) const {
@@ -175,8 +189,8 @@ struct StageX3 {
             if (XK) { const int fr = u / (BK / UK), kc = u % (BK / UK); d = S + fr * LD + kc * UK; }
             else { const int k = u / (BF / 4), f4 = u % (BF / 4); d = S + k * LD + f4 * 4; }
             *reinterpret_cast<vec_t*>(d) = c.h[i];
-            *reinterpret_cast<vec_t*>(d + PLANE) = c.m[i];
-            *reinterpret_cast<vec_t*>(d + 2 * PLANE) = c.l[i];
+            if constexpr (NP == 3) *reinterpret_cast<vec_t*>(d + PLANE) = c.m[i];
+            *reinterpret_cast<vec_t*>(d + (NP - 1) * PLANE) = c.l[i];
         }
     }
 };
@@ -208,14 +222,21 @@ __device__ __forceinline__ bf16x8 x3_frag(const __bf16* __restrict__ S, int f0, 
 //   buffer_load of tile t+3                           (into the register set converted during phase t+1)
 // so nothing after the barrier waits for LDS or HBM before the matrix pipe has work.  The loop is unrolled by two (fragment /
 // register sets alternate by name, no copies); a tile beyond the reduction range stages zeros.
-template <int BM, int BN, int WM, int WN, bool AK, bool BKC, int EPI, bool RS>
+//
+// NP = 2 (round 5, cham_gemm_f32x2h): the same kernel over TWO fp16 planes of (operand x its power-of-two scale, H2Scale records p.sa / p.sb as
+// in gemm_h2.hip) split while staged, THREE products v_mfma_f32_32x32x16_f16 (a_l b_h, a_h b_l, a_h b_h) instead of six, the accumulators
+// scaled back by 1 / (s_a s_b) in front of the shared epilogue.  Half the matrix-pipe work per fp32 product; the conversions of a tile go
+// two to an MFMA slice.  Used where the operand is produced in fp32 anyway and a bound of its magnitude is known on the device (the scorer's
+// first layer over cand (.) pred: |tanh x tanh| <= 1, and its weight gradient).
+template <int BM, int BN, int WM, int WN, bool AK, bool BKC, int EPI, bool RS, int NP>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     constexpr int BK = 16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = WM * WN * 64;
-    using LA = StageX3<BM, BK, AK, NTH, RS>;
-    using LB = StageX3<BN, BK, BKC, NTH, false>;
+    using LA = StageX3<BM, BK, AK, NTH, RS, NP>;
+    using LB = StageX3<BN, BK, BKC, NTH, false, NP>;
     constexpr int APL = LA::PLANE, BPL = LB::PLANE;
-    constexpr int ASZ = 3 * APL, BSZ = 3 * BPL;
+    constexpr int ASZ = NP * APL, BSZ = NP * BPL;
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As = reinterpret_cast<__bf16*>(smem);      // [2][3][plane]
     __bf16* Bs = As + 2 * ASZ;                         // [2][3][plane]
@@ -254,11 +275,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsw = make_window(p.rs);
 
     LA la; LB lb;
-    la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, RS);
-    lb.init(p.ldb, p.N - n0, n0, 0, 1, false);
+    float sa_inv = 1.f, sa = 1.f, sb = 1.f;
+    if constexpr (NP == 2) { sa = p.sa[0]; sb = p.sb[0]; sa_inv = p.sa[1] * p.sb[1]; }
+    la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, RS, sa);
+    lb.init(p.ldb, p.N - n0, n0, 0, 1, false, sb);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    struct Frags { bf16x8 a[3][TM], b[3][TN]; };
+    struct Frags { bf16x8 a[NP][TM], b[NP][TN]; };
     Frags F0, F1;
     typename LA::Regs RA[4];
     typename LB::Regs RB[4];
@@ -273,9 +296,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
         const __bf16* Ac = As + buf * ASZ;
         const __bf16* Bc = Bs + buf * BSZ;
         // in the order the MFMA passes consume them: (a_l, b_h), (a_h, b_l), (a_m, b_m)
-        constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
+        constexpr int QA[3] = {NP - 1, 0, 1}, QB[3] = {0, NP - 1, 1};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) f.a[QA[q]][i] = x3_frag<AK, LA::LD>(Ac + QA[q] * APL, wm0 + i * 32, lane);
 #pragma unroll
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
         }
     };
     // smallest terms first; every pass walks all TM x TN accumulators, so dependent MFMAs are TM * TN instructions apart
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PA[6] = {NP - 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP - 1, NP == 3 ? 1 : 0, 0, 1, 0};          // NP == 2: the first three
     // Phase t: MFMAs on tile t; fragments of tile t + 1 read; tile t + 2 split (register set `c`) and written to LDS; tile t + 5
     // requested from memory into register set `l` (the set phase t - 1 finished splitting).  The operands stream from HBM - the
     // workgroups that share an A panel walk K in step, so every request sees a miss, ~2 us under load, longer than a phase: one
@@ -294,25 +317,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
         const int cur = t & 1;
         typename LA::Conv ca;
         typename LB::Conv cb;
-        constexpr int NEA = LA::NE, NEB = LB::NE, NMF = 6 * TM * TN, NFR = 3 * (TM + TN);
+        constexpr int NEA = LA::NE, NEB = LB::NE, NMF = NPROD * TM * TN, NFR = NP * (TM + TN);
         constexpr int NGA = LA::NV * LA::NL, NGB = LB::NV * LB::NL;
         // slices: one MFMA each, plus - fragment reads in the first NFR slices (they must have landed by the barrier), the global
-        // requests in the first NGA + NGB, B's split / LDS write, then A's
-        constexpr int SB_W = NEB, SA_0 = NEB + 1, SA_W = SA_0 + NEA;
+        // requests in the first NGA + NGB, B's split / LDS write, then A's (CPS conversions per slice: one where they fit, two under
+        // the three-product form's twelve MFMAs)
+        constexpr int CPS = (NEB + 1 + NEA < NMF) ? 1 : 2;
+        constexpr int SB_W = (NEB + CPS - 1) / CPS, SA_0 = SB_W + 1, SA_W = SA_0 + (NEA + CPS - 1) / CPS;
         static_assert(SA_W < NMF && NFR <= NMF && NGA + NGB + 1 <= NMF, "the streams must fit under the MFMAs of one phase");
         const int kn = kbeg + (t + 5) * BK, knb = kbeg + (t + (BRING ? 5 : 3)) * BK;
         const __amdgpu_buffer_rsrc_t awn = make_window(abase + (size_t)(t + 5) * astep);
         const __amdgpu_buffer_rsrc_t bwn = make_window(bbase + (size_t)(t + (BRING ? 5 : 3)) * bstep);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 6; ++s)
+        for (int s = 0; s < NPROD; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int m = (s * TM + i) * TN + j;
                     if ((!(X3_ABL & 8) || s == 0) && (!(X3_ABL & 128) || wave < WM * WN / 2)) {
-                        if (X3_ABL & 64)       // probe: accumulators pinned to the AccVGPR file
+                        if constexpr (NP == 2)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x2h_half8, fc.a[PA[s]][i]),
+                                                                               __builtin_bit_cast(x2h_half8, fc.b[PB[s]][j]), acc[i][j], 0, 0, 0);
+                        else if (X3_ABL & 64)       // probe: accumulators pinned to the AccVGPR file
                             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fc.a[PA[s]][i]), "v"(fc.b[PB[s]][j]));
                         else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc.a[PA[s]][i], fc.b[PB[s]][j], acc[i][j], 0, 0, 0);
@@ -325,13 +353,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
                     }
                     if (!(X3_ABL & 4) && (!(X3_ABL & 128) || wave >= WM * WN / 2) && m < NFR) {          // fragment m of tile t + 1
                         const int q = m / (TM + TN), r = m % (TM + TN);
-                        constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
+                        constexpr int QA[3] = {NP - 1, 0, 1}, QB[3] = {0, NP - 1, 1};
                         if (r < TM) fn.a[QA[q]][r] = x3_frag<AK, LA::LD>(As + (cur ^ 1) * ASZ + QA[q] * APL, wm0 + r * 32, lane);
                         else fn.b[QB[q]][r - TM] = x3_frag<BKC, LB::LD>(Bs + (cur ^ 1) * BSZ + QB[q] * BPL, wn0 + (r - TM) * 32, lane);
                     }
                     if (!(X3_ABL & 16) && (!(X3_ABL & 128) || wave >= WM * WN / 2)) {
-                        if (m < NEB) lb.convert_one(rbc, cb, m);
-                        else if (m >= SA_0 && m < SA_0 + NEA) la.convert_one(rac, ca, m - SA_0);
+#pragma unroll
+                        for (int c = 0; c < CPS; ++c) {
+                            const int eb = m * CPS + c, ea = (m - SA_0) * CPS + c;
+                            if (m < SB_W) { if (eb < NEB) lb.convert_one(rbc, cb, eb); }
+                            else if (m >= SA_0 && m < SA_W) { if (ea < NEA) la.convert_one(rac, ca, ea); }
+                        }
                         if (m == SB_W) lb.write(cb, Bs + cur * BSZ);
                         if (m == SA_W) la.write(ca, As + cur * ASZ);
                     }
@@ -382,38 +414,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int kl = lane_e >> 5, fl = lane_e & 31;
+    if constexpr (NP == 2) {          // back to true units (a power of two: exact)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= sa_inv;
+    }
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }
 
-// launch counters: [0] 128x128, [1] 256x128, [3] delegated to the native fp32 kernels (N <= 64), [6] EPI and [7] K-splits
-// of the last launch
+// launch counters: [0] 128x128, [1] 256x128, [3] delegated to the native fp32 kernels (N <= 64), [4] / [5] the two tiles of the
+// two-fp16-plane form (cham_gemm_f32x2h), [6] EPI and [7] K-splits of the last launch
 static long long g_x3_launches[8];
 extern "C" void cham_gemm_f32x3_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_x3_launches[i]; if (reset) g_x3_launches[i] = 0; }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int EPI, int NP>
 static int x3_launch_epi(GemmParams& p, hipStream_t st) {
     g_x3_launches[6] = EPI; g_x3_launches[7] = p.splits;
-    constexpr size_t smem = (size_t)2 * 3 * (StageX3<BM, 16, AK, WM * WN * 64, false>::PLANE + StageX3<BN, 16, BKC, WM * WN * 64, false>::PLANE) * 2;
+    constexpr size_t smem = (size_t)2 * NP * (StageX3<BM, 16, AK, WM * WN * 64, false>::PLANE + StageX3<BN, 16, BKC, WM * WN * 64, false>::PLANE) * 2;
     constexpr bool RSI = (EPI == 1 && AK && !BKC) || ((EPI == 6 || EPI == 0) && !AK && !BKC);      // as in gemm.hip
     if (p.rs != nullptr && !RSI) return -CHAM_ERR_ARG;
     const dim3 grid(p.nbm * p.nbn, p.splits, 1), block(WM * WN * 64);
     if (RSI && p.rs != nullptr) {
-        auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, RSI>;
+        auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, RSI, NP>;
         CHAM_SET_DYNAMIC_LDS(k, (int)smem);
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
         CHAM_CHECK_LAUNCH();
         return CHAM_OK;
     }
-    auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, false>;
+    auto k = gemm_x3_kernel<BM, BN, WM, WN, AK, BKC, EPI, false, NP>;
     CHAM_SET_DYNAMIC_LDS(k, (int)smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC>
+template <int BM, int BN, int WM, int WN, int BK, bool AK, bool BKC, int NP>
 static int x3_launch_cfg(GemmParams& p, hipStream_t st) {
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.N + BN - 1) / BN;
@@ -422,7 +462,7 @@ static int x3_launch_cfg(GemmParams& p, hipStream_t st) {
     if (p.splits > 1) {
         if constexpr (TN) {
             p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
-            const int rc = x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6>(p, st);
+            const int rc = x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 6, NP>(p, st);
             if (rc != CHAM_OK) return rc;
             launch_splitk_reduce(p, st);
             CHAM_CHECK_LAUNCH();
@@ -434,34 +474,34 @@ static int x3_launch_cfg(GemmParams& p, hipStream_t st) {
     if (p.dref) {
         if (p.bias || p.act != ACT_NONE) return -CHAM_ERR_ARG;
         if constexpr (NT) {
-            if (p.dact == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3>(p, st);
-            if (p.dact == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4>(p, st);
+            if (p.dact == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 3, NP>(p, st);
+            if (p.dact == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 4, NP>(p, st);
         }
         return -CHAM_ERR_ARG;
     }
     if (p.bias || p.act != ACT_NONE) {
         if (!p.bias || p.accumulate) return -CHAM_ERR_ARG;
         if constexpr (NN) {
-            if (p.act == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1>(p, st);
-            if (p.act == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2>(p, st);
-            return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5>(p, st);
+            if (p.act == ACT_LEAKY) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 1, NP>(p, st);
+            if (p.act == ACT_TANH) return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 2, NP>(p, st);
+            return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 5, NP>(p, st);
         }
         return -CHAM_ERR_ARG;
     }
-    return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0>(p, st);
+    return x3_launch_epi<BM, BN, WM, WN, BK, AK, BKC, 0, NP>(p, st);
 }
 
 static int g_x3_variant = -1;     // -1 = automatic; 0 = 128x128 / 4 waves, 2 = 256x128 / 8 waves
 extern "C" void cham_gemm_f32x3_set_variant(int v) { g_x3_variant = v; }
 
-template <bool AK, bool BKC>
+template <bool AK, bool BKC, int NP>
 static int x3_by_shape(GemmParams& p, hipStream_t st) {
     auto grid = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.splits; };
     int v = ((long)p.M * p.N >= (1L << 20) && grid(256, 128) >= 256) ? 2 : 0;
     if (g_x3_variant >= 0) v = g_x3_variant;
     switch (v) {
-        case 2: ++g_x3_launches[1]; return x3_launch_cfg<256, 128, 4, 2, 16, AK, BKC>(p, st);
-        default: ++g_x3_launches[0]; return x3_launch_cfg<128, 128, 2, 2, 16, AK, BKC>(p, st);
+        case 2: ++g_x3_launches[NP == 2 ? 5 : 1]; return x3_launch_cfg<256, 128, 4, 2, 16, AK, BKC, NP>(p, st);
+        default: ++g_x3_launches[NP == 2 ? 4 : 0]; return x3_launch_cfg<128, 128, 2, 2, 16, AK, BKC, NP>(p, st);
     }
 }
 
@@ -486,8 +526,31 @@ extern "C" int cham_gemm_f32x3(const float* A, int lda, int transA, const float*
                              accumulate, workspace, workspace_bytes, splits_hint);
     if (rc != CHAM_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!transA && !transB) return x3_by_shape<true, false>(p, st);
-    if (!transA && transB) return x3_by_shape<true, true>(p, st);
-    if (transA && !transB) return x3_by_shape<false, false>(p, st);
+    if (!transA && !transB) return x3_by_shape<true, false, 3>(p, st);
+    if (!transA && transB) return x3_by_shape<true, true, 3>(p, st);
+    if (transA && !transB) return x3_by_shape<false, false, 3>(p, st);
     return -CHAM_ERR_ARG;
+}
+
+// The same GEMM over two fp16 planes of each operand, split while staged (NP = 2 above): sa_rec / sb_rec = the operands' H2Scale records
+// (device; {scale, 1 / scale, ...}: cham_h2_scale_absmax / _rownorm of gemm_h2.hip, or a constant record for an operand with a known bound).
+// Every |element x scale| must stay below 65 504 (fp16): the caller's bound is the contract, as for cham_gemm_h2.  NN (+ bias, leaky | tanh,
+// row-broadcast scale on A) and TN (plain | split-K, row-broadcast scale on A) forms with N > 64 - the shapes of the scorer's first layer and
+// of its weight gradient (reference nar_model.py:447-451, 478-495: matching_dense_layer_1 over cand (.) pred).
+extern "C" int cham_gemm_f32x2h(const float* A, int lda, int transA, const float* B, int ldb, int transB,
+                                float* C, int ldc, int M, int N, int K,
+                                const float* bias, int act,
+                                const float* rowscale, int ldrs, int rs_div,
+                                int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                                const float* sa_rec, const float* sb_rec, void* stream) {
+    if (!sa_rec || !sb_rec || N <= 64 || transB) return -CHAM_ERR_ARG;
+    if (((uintptr_t)sa_rec | (uintptr_t)sb_rec) & 3) return -CHAM_ERR_ARG;
+    GemmParams p;
+    const int rc = gemm_plan(p, A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, nullptr, 0, 0, rowscale, ldrs, rs_div,
+                             accumulate, workspace, workspace_bytes, splits_hint);
+    if (rc != CHAM_OK) return rc;
+    p.sa = sa_rec; p.sb = sb_rec;
+    hipStream_t st = (hipStream_t)stream;
+    if (!transA) return x3_by_shape<true, false, 2>(p, st);
+    return x3_by_shape<false, false, 2>(p, st);
 }

@@ -202,6 +202,10 @@ class NARRuntime:
         # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
         # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A library-wide setting.
         self.lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
+        # the scorer's first layer over cand (.) pred and its weight gradient on two fp16 planes split while staged (csrc/gemm_x3.hip NP = 2,
+        # cham_gemm_f32x2h, round 5): three plane products instead of six for the 2 x 65 GFLOP that were left on the six-product kernel;
+        # |cand (.) pred| <= 1 (two tanh outputs: a constant scale record), Ws1 and dS1 by their max row norm.  CHAM_S1_H2=0: the bf16x3 arm
+        self.s1_h2 = self.h2 and os.environ.get("CHAM_S1_H2", "1") == "1"
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -297,6 +301,8 @@ class NARRuntime:
             if self.h2:      # H2Scale records (32 bytes each, zero-initialised): W2's scale; max row norm of Ws1 (factor of the dZ2 bound)
                 self.sc_w2 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_ws1n = torch.zeros(8, dtype=torch.float32, device=dev)
+                # constant record of an operand bounded by 1 (cand (.) pred: tanh x tanh): scale 2^14 - a factor of two inside fp16's range
+                self.sc_unit = torch.tensor([16384.0, 1.0 / 16384.0, 1.0, 0, 0, 0, 0, 0], dtype=torch.float32, device=dev)
             # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip) where the kernel takes the shape; otherwise
             # (and for 1 + N outside [32, 256]) the two separate kernels
             self.dm_fused = L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
@@ -434,7 +440,9 @@ class NARRuntime:
 
     # ---- thin kernel wrappers -------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=0, transB=0, bias=None, act=ACT_NONE, dref=None, ldr=0,
-             dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False):
+             dact=ACT_NONE, rowscale=None, ldrs=0, rs_div=1, accumulate=0, splits=1, force_f32=False, h2scales=None):
+        """h2scales = (record of A [x rowscale], record of B): the two-fp16-plane form of the bf16x3 kernel (cham_gemm_f32x2h; default
+        arithmetic only - the other arithmetics ignore it)."""
         ws = None
         if splits != 1:
             ws = self._lane_ws('gemm_ws')
@@ -446,10 +454,18 @@ class NARRuntime:
             c0 = self._tile_counts()
             x0 = self._tile_counts_x3() if x3 else None
             e0.record()       # torch's current stream == the stream the kernel is launched on (_stream())
-        fn = self.lib.cham_gemm_bf16 if bf16 else (self.lib.cham_gemm_f32x3 if x3 else self.lib.cham_gemm_f32)
-        check(fn(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
-                                     ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
-                                     ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
+        x2h = h2scales is not None and x3 and not bf16 and self.s1_h2
+        if x2h:
+            if dref is not None or transB:
+                raise ValueError("the two-plane form takes the NN and TN shapes only")
+            check(self.lib.cham_gemm_f32x2h(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(rowscale), ldrs,
+                                            rs_div, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, ptr(h2scales[0]),
+                                            ptr(h2scales[1]), _stream()), "cham_gemm_f32x2h")
+        else:
+            fn = self.lib.cham_gemm_bf16 if bf16 else (self.lib.cham_gemm_f32x3 if x3 else self.lib.cham_gemm_f32)
+            check(fn(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, M, N, K, ptr(bias), act,
+                     ptr(dref), ldr, dact, ptr(rowscale), ldrs, rs_div, accumulate, ptr(ws),
+                     ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_f32")
         if prof is not None:
             e1.record()
             c1 = self._tile_counts()
@@ -458,9 +474,9 @@ class NARRuntime:
                        bias=bias is not None, rowscale=rowscale is not None, bf16=bf16, tile=tile, epi=int(c1[14]), ev=(e0, e1))
             if x3:
                 x1 = self._tile_counts_x3()
-                xt = next((i for i in range(3) if x1[i] != x0[i]), -1)
+                xt = next((i for i in (0, 1, 2, 4, 5) if x1[i] != x0[i]), -1)
                 if xt >= 0:          # ran on a bf16x3 instance (otherwise: delegated to the native kernels, recorded above)
-                    rec.update(x3=True, tile=xt, epi=int(x1[6]), splits=int(x1[7]))
+                    rec.update(x3=True, tile=xt & 3, x2h=xt >= 4, epi=int(x1[6]), splits=int(x1[7]))
             prof.append(rec)
 
     def _tile_counts(self):
@@ -677,6 +693,7 @@ class StepPlan:
                 self.Z1p, self.dZ2p = (torch.empty(2, Rc, C, dtype=torch.float16, device=dev) for _ in range(2))
                 self.sc_z1 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_dz2 = torch.zeros(8, dtype=torch.float32, device=dev)
+                self.sc_ds1 = torch.zeros(8, dtype=torch.float32, device=dev)          # dS1 itself (operand of the Ws1 weight gradient)
             else:
                 self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
             self.p3_ps = Rc * C
@@ -1232,7 +1249,8 @@ class NARModuleModel:
             # scorer: (cand (.) pred) -> 128 -> 64 -> 32 -> 1, softmax(/tau), masked NLL
             _roctx.pop(); _roctx.push("K5 scorer, softmax, loss")
             Z2c = pl.Z2[BT:Rall]
-            rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC)
+            rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC,
+                    h2scales=(rt.sc_unit, rt.sc_ws1n) if rt.s1_h2 else None)
             rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
             rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
             softmax_fwd = lib.cham_score_softmax_fwd
@@ -1328,8 +1346,8 @@ class NARModuleModel:
             Z2c, dZ2c = pl.Z2[BT:Rall], pl.dZ2[BT:Rall]
         h2 = use_p3 and rt.h2
         if h2:      # scale of the gradient at the CAR tanh from the Cauchy-Schwarz bound of dS1 Ws1^T: max row norm of dS1 x max row norm of Ws1
-            check(lib.cham_h2_scale_rownorm(ptr(pl.dS1), Rc, pl.dS1.shape[1], pl.dS1.shape[1], rt.sc_ws1n.data_ptr() + 8, ptr(pl.sc_dz2), s),
-                  "cham_h2_scale_rownorm")
+            check(lib.cham_h2_scale_rownorm2(ptr(pl.dS1), Rc, pl.dS1.shape[1], pl.dS1.shape[1], rt.sc_ws1n.data_ptr() + 8, ptr(pl.sc_dz2),
+                                             ptr(pl.sc_ds1), s), "cham_h2_scale_rownorm2")
         e_dS1 = mark()     # (starting the side lane only after the next GEMM, to pair its MFMA work with k_mulpred_bwd's HBM work,
         #                      measured 0.26 ms slower: 17.28-17.33 vs 17.01-17.07 ms, A/B in one gpurun call)
         # scorer layer-1 dgrad + cand (.) pred backward in one kernel (csrc/dm_fused.hip): dM never reaches HBM
@@ -1371,7 +1389,8 @@ class NARModuleModel:
                 rt.gemm_b16(pl.Mc, C, 1, pl.dS1, 128, 0, g('Ws1'), 128, 1, C, 128, Rc, splits=0)
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'), b16=True)
             else:
-                rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0)
+                rt.gemm(Z2c, pl.dS1, g('Ws1'), C, 128, Rc, C, 128, 128, transA=1, rowscale=pl.pred, ldrs=C, rs_div=NC, splits=0,
+                        h2scales=(rt.sc_unit, pl.sc_ds1) if (rt.s1_h2 and use_p3) else None)
                 rt.colsum(pl.dS1, 128, Rc, 128, g('bs1'))
         with side(e_start, e_dS1):
             ws1_wgrad()

@@ -147,6 +147,18 @@ int cham_gemm_f32x3(const float* A, int lda, int transA, const float* B, int ldb
 void cham_gemm_f32x3_set_variant(int variant);
 void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
 
+/* The same kernel over TWO fp16 planes per operand, split while staged (round 5): h = fp16(x * scale), l = fp16(x * scale - h), three plane
+ * products on v_mfma_f32_32x32x16_f16 instead of six, the result scaled back by 1 / (scale_a scale_b) (powers of two: exact) - the arithmetic
+ * of cham_gemm_h2 below for operands that exist in fp32 anyway.  sa_rec / sb_rec: the operands' H2Scale records (device memory, see
+ * cham_gemm_h2; A's covers A x rowscale when a row-broadcast scale is given); |element x scale| < 65 504 is the caller's contract.  Forms:
+ * NN (transA = transB = 0; bias + CHAM_ACT_NONE / LEAKY / TANH; rowscale on A) and TN (transA = 1; split-K as cham_gemm_f32; rowscale on
+ * A), N > 64; -EINVAL otherwise.  Replaces matching_dense_layer_1 over cand (.) pred (nar_model.py:447-451, 478-495; |tanh x tanh| <= 1:
+ * a constant record) and its weight gradient (autodiff under :718) when the runtime's default arithmetic is on.  Launches are counted in
+ * cham_gemm_f32x3_launch_counts out8[4] (128 x 128 tile) / out8[5] (256 x 128). */
+int cham_gemm_f32x2h(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
+                     const float* bias, int act, const float* rowscale, int ldrs, int rs_div, int accumulate, float* workspace,
+                     size_t workspace_bytes, int splits_hint, const float* sa_rec, const float* sb_rec, void* stream);
+
 /* fp32-grade GEMM over operands that already live in HBM as THREE bf16 PLANES (csrc/gemm_p3.hip, round 3): the same six plane products
  * as cham_gemm_f32x3, but the split is done once by the kernel that produces the matrix (cham_combine_fwd_p3, cham_mulpred_bwd_p3,
  * cham_split3 for weights) and the K loop is MFMAs + fragment reads + LDS-DMA only.  Replaces the CAR layer-2 matmul over the
@@ -200,6 +212,9 @@ int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plan
  *   round 4 (A/B arm; results are bit-identical: same products, same summation order); returns the previous setting. */
 int cham_h2_scale_absmax(const float* x0, size_t n0, const float* x1, size_t n1, void* rec, void* stream);
 int cham_h2_scale_rownorm(const float* X, long R, int K, int ld, const float* factor, void* rec, void* stream);
+/* ... and, from the same pass, a second record WITHOUT the factor (rec_plain, may be NULL): max row norm of X >= max |X| - the scale of X
+ * itself as a two-plane operand of cham_gemm_f32x2h */
+int cham_h2_scale_rownorm2(const float* X, long R, int K, int ld, const float* factor, void* rec, void* rec_plain, void* stream);
 int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,
                  int lddT, void* rec, int recompute, void* stream);
 int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride, int ldb,

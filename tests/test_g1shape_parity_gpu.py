@@ -176,7 +176,9 @@ def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, arith):
         assert car_gemm_counts(model) == (2, 1) and c[1] == 0 and c[2] == 0, (car_gemm_counts(model), x, c)
         assert (h2_counts(lib)[0] == 0) == (arith == "p3") and (p3_counts(lib)[0] == 0) == (arith == "h2")
         # (scorer layer 1 forward + its weight gradient; its dgrad lives in the fused kernel csrc/dm_fused.hip)
-        assert x[1] >= (2 if length_dist == "full" else 0) and x[0] + x[1] >= 2 and model.rt.dm_fused, x
+        assert x[1] + x[5] >= (2 if length_dist == "full" else 0) and x[0] + x[1] + x[4] + x[5] >= 2 and model.rt.dm_fused, x
+        # ... the default arithmetic runs those two on the two-fp16-plane form of that kernel (cham_gemm_f32x2h, round 5), the p3 arm does not
+        assert x[4] + x[5] == (2 if arith == "h2" else 0), x
     elif gemm_dtype == "f32":
         # CAR forward / dgrad / wgrad, scorer layer 1 (row scale) + its wgrad and dgrad on the 256x128 bf16x3 instance; nothing wide on
         # the native kernels
@@ -247,7 +249,7 @@ def test_step_parity_adressa_shape(gpu):
     reset_counts(lib)
     compare_step_large(model, orc, *batches[3], st)
     x = x3_counts(lib)
-    assert car_gemm_counts(model) == (2, 1) and x[1] >= 2, (car_gemm_counts(model), x)
+    assert car_gemm_counts(model) == (2, 1) and x[1] + x[5] >= 2 and x[4] + x[5] == 2, (car_gemm_counts(model), x)
 
 
 @pytest.mark.parametrize("dma", [True, False])

@@ -1,0 +1,222 @@
+"""fp32-grade GEMM over two fp16 planes per operand split WHILE STAGED (csrc/gemm_x3.hip NP = 2, cham_gemm_f32x2h, round 5): the arithmetic of
+cham_gemm_h2 (h = fp16(x s), l = fp16(x s - h), three plane products, result x 1 / (s_a s_b)) on operands that exist in fp32, with the
+operands' power-of-two scales taken from H2Scale records - the scorer's first layer over cand (.) pred (reference nar_model.py:447-451,
+478-495) and its weight gradient.  Against float64 with the tolerances of the bf16x3 tests, next to the native fp32 MFMA on the step's own
+shapes (the claim is fp32-GRADE error), with operands of wide dynamic range (the absolute-error contract of a per-matrix scale), and the
+device-side record cham_h2_scale_rownorm2 adds."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from tests.test_gemm_gpu import ROWS
+
+pytestmark = pytest.mark.gpu
+
+
+def _record(bound, gpu):
+    """H2Scale record as h2_finish_scale derives it: scale = 2^k with bound * scale in [2^14, 2^15)."""
+    _, e = math.frexp(bound)
+    k = 15 - e
+    return torch.tensor([2.0 ** k, 2.0 ** -k, bound, 0, 0, 0, 0, 0], dtype=torch.float32, device=gpu)
+
+
+def _counts(lib, reset=False):
+    out = (ctypes.c_longlong * 8)()
+    lib.cham_gemm_f32x3_launch_counts(out, 1 if reset else 0)
+    return list(out)
+
+
+@pytest.fixture(params=[-1, 0, 2], ids=["auto", "128x128", "256x128"])
+def variant(request):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    lib.cham_gemm_f32x3_set_variant(request.param)
+    yield request.param
+    lib.cham_gemm_f32x3_set_variant(-1)
+
+
+class _Case:
+    def __init__(self, gpu, M, N, K, transA=0, bias=False, act=0, rowscale=0, seed=0, wide=False, amp_a=1.0, amp_b=1.0):
+        g = torch.Generator().manual_seed(seed)
+        self.M, self.N, self.K, self.tA, self.act, self.rs_div, self.gpu = M, N, K, transA, act, (rowscale or 1), gpu
+        A = torch.randn((K, M) if transA else (M, K), generator=g) * amp_a
+        B = torch.randn(K, N, generator=g) * amp_b
+        if wide:          # rows of very different magnitude: what a gradient matrix looks like
+            A = A * torch.exp2(-20 * torch.rand(A.shape[0], 1, generator=g))
+            B = B * torch.exp2(-20 * torch.rand(B.shape[0], 1, generator=g))
+        self.A, self.B = A, B
+        self.bias = torch.randn(N, generator=g) * amp_a * amp_b if bias else None
+        self.rs = torch.tanh(torch.randn((A.shape[0] + self.rs_div - 1) // self.rs_div, A.shape[1], generator=g)) if rowscale else None
+        Ae = A.double()
+        if self.rs is not None:
+            Ae = Ae * self.rs.double()[torch.arange(A.shape[0]) // self.rs_div]
+        self.sa, self.sb = _record(float(Ae.abs().max()), gpu), _record(float(B.abs().max()), gpu)
+        R = (Ae.t() if transA else Ae) @ B.double()
+        if bias:
+            R = R + self.bias.double()
+        if act == 1:
+            R = torch.where(R > 0, R, 0.2 * R)
+        elif act == 2:
+            R = torch.tanh(R)
+        self.R = R
+        self.dev = {k: (v.to(gpu) if v is not None else None) for k, v in dict(A=A, B=B, bias=self.bias, rs=self.rs).items()}
+
+    def run(self, lib, splits=1, accumulate=0, native=False, sa=None, sb=None):
+        from chameleon_recsys_amd._lib import check, ptr
+        d = self.dev
+        C0 = torch.randn(self.M, self.N, generator=torch.Generator().manual_seed(99)) if accumulate else None
+        C = C0.to(self.gpu) if accumulate else torch.full((self.M, self.N), float('nan'), device=self.gpu)
+        ws = torch.empty(32 << 20, dtype=torch.float32, device=self.gpu) if splits != 1 else None
+        st = torch.cuda.current_stream().cuda_stream
+        if native:
+            rc = lib.cham_gemm_f32(ptr(d['A']), self.A.shape[1], self.tA, ptr(d['B']), self.N, 0, ptr(C), self.N, self.M, self.N, self.K, ptr(d['bias']),
+                                   self.act, None, 0, 0, ptr(d['rs']), self.A.shape[1], self.rs_div, accumulate, ptr(ws),
+                                   (32 << 20) * 4 if ws is not None else 0, splits, st)
+        else:
+            rc = lib.cham_gemm_f32x2h(ptr(d['A']), self.A.shape[1], self.tA, ptr(d['B']), self.N, 0, ptr(C), self.N, self.M, self.N, self.K,
+                                      ptr(d['bias']), self.act, ptr(d['rs']), self.A.shape[1], self.rs_div, accumulate, ptr(ws),
+                                      (32 << 20) * 4 if ws is not None else 0, splits, ptr(self.sa if sa is None else sa),
+                                      ptr(self.sb if sb is None else sb), st)
+        check(rc, "gemm")
+        torch.cuda.synchronize()
+        R = self.R + C0.double() if accumulate else self.R
+        return float((C.cpu().double() - R).abs().max()) / float(R.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 260, 96), (77, 1024, 408), (64, 72, 1024), (500, 128, 16), (130, 132, 4), (1000, 128, 20)])
+def test_x2h_nn(gpu, variant, M, N, K):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    for kw in (dict(), dict(bias=True, act=1), dict(bias=True, act=2), dict(bias=True)):
+        case = _Case(gpu, M, N, K, **kw)
+        e, e_nat = case.run(lib), case.run(lib, native=True)
+        # (a lost low plane would show as ~1e-5: far above the native error.  K < 64: so few roundings in the native kernel that the 22
+        # significand bits of two fp16 planes - |a b| 2^-22 per product - are what is left: the documented contract, gemm_h2.hip)
+        assert e < 5e-5 and e < 1.5 * e_nat + (2e-7 if K >= 64 else 4e-6), (kw, e, e_nat)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 5000), (72, 1024, 777), (408, 128, 3001), (1024, 128, 4099)])
+def test_x2h_tn_wgrad_splitk(gpu, variant, M, N, K):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    case = _Case(gpu, M, N, K, transA=1)
+    for splits in (1, 0, 7, 8):
+        e, e_nat = case.run(lib, splits=splits), case.run(lib, splits=splits, native=True)
+        assert e < 1e-4 and e < 1.5 * e_nat + 2e-7, (splits, e, e_nat)
+    assert case.run(lib, accumulate=1) < 1e-4
+    assert case.run(lib, splits=0, accumulate=1) < 1e-4
+
+
+def test_x2h_rowscale_is_the_scorers_first_layer(gpu, variant):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    for case, splits in ((_Case(gpu, 51 * 40, 128, 256, rowscale=51, bias=True, act=1), 1),          # scorer layer 1
+                         (_Case(gpu, 64 * 19 * 51, 128, 1024, rowscale=51, bias=True, act=1, amp_b=0.03), 1),          # ... at the loss-curve test's 64 sessions
+                         (_Case(gpu, 256, 128, 51 * 40, transA=1, rowscale=51), 0),                 # its weight gradient
+                         (_Case(gpu, 256, 128, 51 * 40, transA=1, rowscale=51), 1)):                # too short to split
+        e, e_nat = case.run(lib, splits=splits), case.run(lib, splits=splits, native=True)
+        assert e < 5e-5 and e < 1.5 * e_nat + 2e-7, (e, e_nat)
+
+
+@pytest.mark.parametrize("amp_a,amp_b", [(1e-12, 1.0), (1.0, 1e-9), (3e7, 1e-3), (1e-20, 1e12)])
+def test_x2h_scales_carry_the_dynamic_range(gpu, amp_a, amp_b):
+    """fp16 has five exponent bits: the records' power-of-two scales carry the operands' magnitude, the result comes back in true units."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    assert _Case(gpu, 300, 260, 96, amp_a=amp_a, amp_b=amp_b).run(lib) < 5e-5
+    assert _Case(gpu, 408, 128, 3001, transA=1, amp_a=amp_a, amp_b=amp_b).run(lib, splits=0) < 1e-4
+
+
+def test_x2h_wide_rows_keep_the_absolute_error_contract(gpu):
+    """One scale per MATRIX: elements far below the bound lose low bits (absolute error <= 2^-40 of the bound per element, DESIGN.md section 3,
+    'row-relative accuracy') - the error of the product stays fp32-grade relative to the largest entry of the result, next to the native fp32
+    MFMA on the same operands."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    for kw in (dict(M=1000, N=128, K=1024, rowscale=50, bias=True, act=1), dict(M=1024, N=128, K=20000, transA=1)):
+        tn = kw.get('transA', 0)
+        case = _Case(gpu, wide=True, seed=5, **kw)
+        e, e_nat = case.run(lib, splits=0 if tn else 1), case.run(lib, splits=0 if tn else 1, native=True)
+        assert e < 5e-5 and e < 1.5 * e_nat + 2e-7, (kw, e, e_nat)
+
+
+def test_x2h_step_shapes_next_to_the_native_fp32_mfma(gpu):
+    """The step's own shapes: [72 x 19 x 51 candidate rows, 1024] (.) pred -> 128 with bias + leaky-ReLU, and its weight gradient over the
+    rows.  fp32-grade: not measurably worse than v_mfma_f32_32x32x2_f32 on the same operands."""
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    _counts(lib, reset=True)
+    fwd = _Case(gpu, ROWS, 128, 1024, rowscale=51, bias=True, act=1, seed=1, amp_b=0.03)
+    e, e_nat = fwd.run(lib), fwd.run(lib, native=True)
+    assert e < 5e-5 and e < 1.5 * e_nat + 1e-7, (e, e_nat)
+    wg = _Case(gpu, 1024, 128, ROWS, transA=1, rowscale=51, seed=2, amp_b=1e-4)
+    e, e_nat = wg.run(lib, splits=0), wg.run(lib, splits=0, native=True)
+    assert e < 1e-4 and e < 1.5 * e_nat + 1e-7, (e, e_nat)
+    c = _counts(lib)
+    assert c[5] == 1 and c[4] == 1 and c[0] == c[1] == 0, c          # two-plane form: 256 x 128 tile (forward), 128 x 128 (the [1024, 128] weight gradient)
+    # a looser (larger) bound only costs low bits of small elements: the constant record of the runtime (|cand (.) pred| <= 1 -> 2^14)
+    unit = torch.tensor([16384.0, 1.0 / 16384.0, 1.0, 0, 0, 0, 0, 0], device=gpu)
+    tanh_rows = _Case(gpu, ROWS, 128, 1024, rowscale=51, bias=True, act=1, seed=3, amp_b=0.03)
+    tA = torch.tanh(tanh_rows.A)
+    tanh_rows.dev['A'] = tA.to(gpu)
+    Ae = tA.double() * tanh_rows.rs.double()[torch.arange(ROWS) // 51]
+    R = Ae @ tanh_rows.B.double() + tanh_rows.bias.double()
+    tanh_rows.R = torch.where(R > 0, R, 0.2 * R)
+    assert tanh_rows.run(lib, sa=unit) < 5e-5
+
+
+def test_x2h_is_deterministic(gpu):
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    case = _Case(gpu, 1024, 128, 30000, transA=1, rowscale=51, seed=7)
+    d, st = case.dev, torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=gpu)
+    outs = []
+    for _ in range(3):
+        C = torch.empty(1024, 128, device=gpu)
+        check(lib.cham_gemm_f32x2h(ptr(d['A']), 1024, 1, ptr(d['B']), 128, 0, ptr(C), 128, 1024, 128, 30000, None, 0, ptr(d['rs']), 1024, 51, 0, ptr(ws),
+                                   (32 << 20) * 4, 0, ptr(case.sa), ptr(case.sb), st), "gemm")
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_x2h_argument_errors(gpu):
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import ptr
+    lib = _lib.load()
+    A = torch.zeros(128, 128, device=gpu)
+    rec = _record(1.0, gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda tA, tB, N, sa, sb: lib.cham_gemm_f32x2h(ptr(A), 128, tA, ptr(A), 128, tB, ptr(A), 128, 128, N, 128, None, 0, None, 0, 1, 0, None, 0, 1,
+                                                         ptr(sa), ptr(sb), st)
+    assert call(0, 0, 128, rec, rec) == 0
+    assert call(0, 0, 128, None, rec) < 0 and call(0, 0, 128, rec, None) < 0          # no record
+    assert call(0, 1, 128, rec, rec) < 0 and call(1, 1, 128, rec, rec) < 0            # NT / TT: not taken
+    assert call(0, 0, 64, rec, rec) < 0                                               # narrow outputs stay on the native kernels
+    torch.cuda.synchronize()
+
+
+def test_rownorm2_adds_the_plain_record_from_the_same_pass(gpu):
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    X = (torch.randn(5000, 128, generator=g) * torch.exp2(-12 * torch.rand(5000, 1, generator=g))).to(gpu)
+    other = _record(7.25, gpu)
+    rec, plain, alone = (torch.zeros(8, device=gpu) for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.cham_h2_scale_rownorm2(ptr(X), 5000, 128, 128, other.data_ptr() + 8, ptr(rec), ptr(plain), st), "rownorm2")
+    check(lib.cham_h2_scale_rownorm(ptr(X), 5000, 128, 128, other.data_ptr() + 8, ptr(alone), st), "rownorm")
+    torch.cuda.synchronize()
+    assert torch.equal(rec, alone)                                                    # the first record is the one-record call's
+    norm = float(X.double().norm(dim=1).max())
+    s, inv, bound = (float(v) for v in plain[:3].cpu())
+    assert norm <= bound <= norm * 1.002 and bound >= float(X.abs().max())            # max row norm bounds max |x|
+    assert s * inv == 1.0 and math.log2(s) == int(math.log2(s)) and 2 ** 14 <= bound * s < 2 ** 15
+    assert abs(float(rec[2]) - bound * 7.25) <= 1e-6 * bound * 7.25
+    assert float(plain[4:7].abs().sum()) == 0.0 and float(rec[4:7].abs().sum()) == 0.0          # scratch words cleared for the next launch
+    assert lib.cham_h2_scale_rownorm2(ptr(X), 5000, 128, 128, None, ptr(rec), ptr(rec), st) < 0   # the two records must differ
