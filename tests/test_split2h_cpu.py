@@ -131,3 +131,28 @@ def test_plane_product_dot_product_error_is_fp32_class(K):
     r_planes, r_plain = np.sqrt(((got - exact) ** 2).mean()) / scale, np.sqrt(((plain - exact) ** 2).mean()) / scale
     print("K=%d: max err %.2e (native fp32 %.2e), rms %.2e (%.2e)" % (K, e_planes, e_plain, r_planes, r_plain))
     assert e_planes < 1.5 * e_plain + 1e-7 and r_planes < 1.5 * r_plain + 2e-8, (e_planes, e_plain, r_planes, r_plain)
+
+
+def test_constant_record_of_a_product_of_two_tanh_outputs():
+    """cham_gemm_f32x2h's A operand in the scorer's first layer (nar_model.py:478-495 of the reference): cand (.) pred, both tanh outputs, takes
+    the CONSTANT record {2^14, 2^-14} instead of a measured bound - |x| 2^14 <= 2^14 stays a factor of four inside fp16's range and the three
+    plane products of a K = 1024 dot product against a weight matrix scaled by its max ROW NORM (>= max |w|: what k_h2_scale_rownorm derives
+    without a second pass) err by less than one plain fp32 summation of the same dot product does."""
+    rng = np.random.default_rng(5)
+    M, K, N = 512, 1024, 128
+    cand = np.tanh(rng.standard_normal((M, K)) * 0.7).astype(np.float32)
+    pred = np.tanh(rng.standard_normal((M // 32, K)) * 0.7).astype(np.float32)
+    A = (cand * np.repeat(pred, 32, 0)).astype(np.float32)                  # the fp32 product the kernel forms while staging
+    W = (rng.standard_normal((K, N)) * 0.03).astype(np.float32)
+    sa = 2.0 ** 14
+    sw = h2_scale(float(np.sqrt((W.astype(np.float64) ** 2).sum(1)).max()) * 1.0009765625)
+    assert float(np.abs(A).max()) * sa <= 2.0 ** 14 and float(np.abs(W).max()) * sw < 2.0 ** 15
+    ah, al = (p.astype(np.float64) for p in split2h(A, sa))
+    wh, wl = (p.astype(np.float64) for p in split2h(W, sw))
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    planes = (ah @ wh + ah @ wl + al @ wh) / (sa * sw)                      # the three products, exactly accumulated: representation error only
+    plain = (A @ W).astype(np.float64)                                      # an fp32 summation of the exact operands
+    scale = float(np.abs(ref).max())
+    e_planes, e_plain = float(np.abs(planes - ref).max()) / scale, float(np.abs(plain - ref).max()) / scale
+    assert e_planes < 2.0 ** -21 and e_planes < e_plain, (e_planes, e_plain)
+    assert abs(float((planes - ref).mean())) / scale < 1e-9               # and no bias: round-to-nearest planes
