@@ -141,7 +141,7 @@ def gemm_symbol(r):
     if r.get('b1'):       # bf16-resident operands on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel)
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
-        return "void k_dm_mulpred_fused<%d>(DmfParams)" % (2 if r.get('bf16') else (1 if r.get('h2out') else 0))
+        return "void k_dm_mulpred_fused<%d>(DmfParams)" % (2 if r.get('bf16') else (3 if r.get('f16p') else (1 if r.get('h2out') else 0)))
     if r.get('h2w'):      # ... NT form on the 64-byte-source-piece kernel (round 5)
         return "void gemm_h2w_kernel<%d>(H2Params)" % epi
     if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
@@ -598,7 +598,7 @@ def main():
     def gemm_entry(sym, e):
         tf_s = e['flop'] / (e['ms'] * 1e-3) / 1e12
         gbs = e['bytes'] / (e['ms'] * 1e-3) / 1e9
-        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (H2_MATRIX_PEAK_TFLOPS if (e['r'].get('h2') or e['r'].get('x2h')) else
+        peak = BF16_MATRIX_PEAK_TFLOPS if e['r']['bf16'] else (H2_MATRIX_PEAK_TFLOPS if (e['r'].get('h2') or e['r'].get('x2h') or e['r'].get('f16p')) else
                                                                X3_MATRIX_PEAK_TFLOPS if (e['r'].get('x3') or e['r'].get('p3') or e['r'].get('dmf')) else FP32_MATRIX_PEAK_TFLOPS)
         return {"kernel": describe(sym, e), "launches_per_step": round(e['n'] / nprof, 2), "avg_launch_ms": round(e['ms'] / e['n'], 4),
                 "ms_per_step": round(e['ms'] / nprof, 3), "tflops": round(tf_s, 2), "frac_of_mfma_peak": round(tf_s / peak, 4),
@@ -710,8 +710,9 @@ def main():
                        "gemm": {"f32": ("fp32 accumulate / epilogues, fp32-grade error (float64-error bar next to the native fp32 MFMA: tests/test_gemm_h2_gpu.py, "
                                         "tests/test_gemm_x3_gpu.py): the three candidate-row CAR GEMMs as THREE fp16-plane products per fp32 product over "
                                         "(h, l) fp16 planes x a device-derived power-of-two scale that their producers wrote to HBM (csrc/gemm_h2.hip, "
-                                        "v_mfma_f32_32x32x16_f16; the NT forms stage 64-byte source pieces: gemm_h2w_kernel); the scorer's first layer over cand (.) pred and its weight gradient as three fp16-plane "
-                                        "products too, split while staged (cham_gemm_f32x2h = gemm_x3_kernel<..., 2>, tests/test_gemm_x2h_gpu.py); the other GEMMs "
+                                        "v_mfma_f32_32x32x16_f16; the NT forms stage 64-byte source pieces: gemm_h2w_kernel); the two backward kernels of the scorer's first layer - its weight gradient and the products inside its fused dgrad - "
+                                        "as three fp16-plane products too, split while staged (cham_gemm_f32x2h = gemm_x3_kernel<..., 2>, k_dm_mulpred_fused<3>; "
+                                        "tests/test_gemm_x2h_gpu.py, tests/test_dm_fused_gpu.py; CHAM_S1_H2); the other GEMMs - that layer's forward among them - "
                                         "with N > 64 as six bf16-plane products split while staged (csrc/gemm_x3.hip); N <= 64 on v_mfma_f32_32x32x2_f32.  Accuracy contract of the "
                                         "two-plane operands: relative to the MATRIX bound, not to each row - fp32 grade for rows within 2^-18 of the largest "
                                         "entry, an absolute error of 2^-40 of the bound below that (INTEGRATION.md)") if getattr(rt, 'h2', False) else

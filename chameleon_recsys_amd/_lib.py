@@ -60,6 +60,7 @@ _SIGNATURES = {
     "cham_combine_fwd_h2": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, P]),
     "cham_mulpred_bwd_h2": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P, P]),
     "cham_dm_mulpred_h2": (c_int, [P, c_int, c_int, P, c_int64, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
+    "cham_dm_mulpred_h2h": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
     "cham_dm_mulpred_b16": (c_int, [P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "cham_gemm_b16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                               P, c_size_t, c_int, P]),

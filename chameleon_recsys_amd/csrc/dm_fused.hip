@@ -38,6 +38,7 @@ struct DmfParams {
     const float* Z2c; const float* pred;        // [Rc, C] (MODE 2: bf16), [BT, C]
     __bf16* out; long long out_ps;              // planes of dZ2 [Rc, C]: three bf16 planes, or (H2) two fp16 planes x the scale of osc
     const H2Scale* osc;
+    const H2Scale* sa; const H2Scale* sw;       // MODE 3: the scales of dS1 and of Ws1's two fp16 planes
     float* dpred; float* b2part;                // [BT, C]
     int C, BT, NC, PW;
 };
@@ -57,10 +58,12 @@ __device__ __forceinline__ void dmf_dma_one(unsigned lds, unsigned voff, const u
 // out.  MODE 2: the bf16 configuration (BASELINE configs[2]) - dS1, Ws1 (its bf16 shadow), Z2c and the output are single bf16 matrices, ONE
 // product; dM is rounded to bf16 where the unfused pair (cham_gemm_b16 + cham_mulpred_bwd_b16) stores it, so the result is that pair's up
 // to the summation order of the per-position sums; col_part sums the ROUNDED gradient (what cham_colsum_b16 would read back).
+// MODE 3 (round 5): MODE 1 with the kernel's own products on TWO fp16 planes too - dS1 split with the scale of p.sa (its max row norm), Ws1's
+// planes (cham_split2h with the scale of p.sw) - THREE v_mfma_f32_32x32x16_f16 products instead of six, dM scaled back by 1 / (s_a s_w).
 template <int MODE>
 __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
-    constexpr bool H2 = MODE == 1, B16 = MODE == 2;
-    constexpr int NPL = B16 ? 1 : 3;                                      // planes of each operand
+    constexpr bool H2 = MODE == 1 || MODE == 3, B16 = MODE == 2, F16P = MODE == 3;
+    constexpr int NPL = B16 ? 1 : (F16P ? 2 : 3);                         // planes of each operand
     extern __shared__ __attribute__((aligned(1024))) unsigned char dmf_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     // (every global access of this kernel goes through a buffer descriptor sized to the workgroup's valid rows: rows beyond them read
     // zeros / drop their stores without a branch - a branch around a load makes hipcc wait for each load in turn, 16 dependent HBM round
     // trips per column tile in the first version of this epilogue: 1.25 ms for the kernel, profiles/r03_notes.md)
-    bf16x8 AH[8], AM[B16 ? 1 : 8], AL[B16 ? 1 : 8];
+    bf16x8 AH[8], AM[(B16 || F16P) ? 1 : 8], AL[B16 ? 1 : 8];          // (F16P: fp16 bit patterns in the same 16-bit containers)
+    float ginv = 1.f;
     if constexpr (B16) {
         const __bf16* a16 = reinterpret_cast<const __bf16*>(p.dS1);
         const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a16 + row0 * (size_t)p.lds1), 0,
@@ -98,8 +102,18 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
             const float v[8] = {__uint_as_float(x[2 * s].x), __uint_as_float(x[2 * s].y), __uint_as_float(x[2 * s].z), __uint_as_float(x[2 * s].w),
                                 __uint_as_float(x[2 * s + 1].x), __uint_as_float(x[2 * s + 1].y), __uint_as_float(x[2 * s + 1].z),
                                 __uint_as_float(x[2 * s + 1].w)};
+            if constexpr (F16P) {
+                const float sa = p.sa->scale;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 a, c;
+                    split2h(v[e] * sa, a, c);
+                    AH[s][e] = __builtin_bit_cast(__bf16, a); AL[s][e] = __builtin_bit_cast(__bf16, c);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); AH[s][e] = a; AM[s][e] = b; AL[s][e] = c; }
+            }
         }
     }
     const __amdgpu_buffer_rsrc_t zw = B16 ?
@@ -112,6 +126,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
         ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + ((H2 && q == 2) || B16 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
     float osc = 1.f;
     if constexpr (H2) osc = p.osc->scale;
+    if constexpr (F16P) ginv = p.sa->inv * p.sw->inv;
 
     // ---- B: LDS-DMA of Ws1's planes.  Half-stage image per plane: [slot 0..127][64 k] (128 B per slot), slot = j * 32 + n holds Ws1 row
     // n0 + 4 n + j; the eight 16-byte pieces of a slot are XOR-ed with (slot >> 1) & 7 (conflict-free ds_read_b128 fragments).  One
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     if constexpr (B16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // half-stage 0 landed (this wave's requests: NPL per half-stage)
+    else if constexpr (F16P) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -173,12 +189,25 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
             for (int j = 0; j < DMF_NT; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(S + fo[t] + j * 4096);
-                if constexpr (!B16) {
+                if constexpr (F16P) {
+                    bl[j] = *reinterpret_cast<const bf16x8*>(S + DMF_PLANE + fo[t] + j * 4096);
+                } else if constexpr (!B16) {
                     bm[j] = *reinterpret_cast<const bf16x8*>(S + DMF_PLANE + fo[t] + j * 4096);
                     bl[j] = *reinterpret_cast<const bf16x8*>(S + 2 * DMF_PLANE + fo[t] + j * 4096);
                 }
             }
-            if constexpr (B16) {
+            if constexpr (F16P) {
+                typedef _Float16 dmf_half8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int j = 0; j < DMF_NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dmf_half8, AL[s0 + t]), __builtin_bit_cast(dmf_half8, bh[j]), acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < DMF_NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dmf_half8, AH[s0 + t]), __builtin_bit_cast(dmf_half8, bl[j]), acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < DMF_NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dmf_half8, AH[s0 + t]), __builtin_bit_cast(dmf_half8, bh[j]), acc[j], 0, 0, 0);
+            } else if constexpr (B16) {
 #pragma unroll
                 for (int j = 0; j < DMF_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[s0 + t], bh[j], acc[j], 0, 0, 0);
             } else {
@@ -231,6 +260,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                 const bool second = rr >= bnd;
                 const float2 pr = second ? prb : pra;
                 float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
+                if constexpr (F16P) { g.x *= ginv; g.y *= ginv; }  // back to true units (a power of two)
                 if constexpr (B16) { g.x = (float)(__bf16)g.x; g.y = (float)(__bf16)g.y; }      // dM as the unfused pair stores it
                 float2 o;
                 o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);
@@ -311,8 +341,9 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 template <int MODE>
 static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
                              const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
-                             float* dpred_pre, float* col_part, void* stream) {
-    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || (MODE == 1 && !out_scale_rec)) return -CHAM_ERR_ARG;
+                             float* dpred_pre, float* col_part, void* stream, const void* a_scale_rec = nullptr, const void* w_scale_rec = nullptr) {
+    if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || ((MODE == 1 || MODE == 3) && !out_scale_rec)) return -CHAM_ERR_ARG;
+    if (MODE == 3 && (!a_scale_rec || !w_scale_rec || (((uintptr_t)a_scale_rec | (uintptr_t)w_scale_rec) & 3))) return -CHAM_ERR_ARG;
     const int NC = N + 1;
     if (K != 128 || (C % DMF_COLS) || C <= 0 || NC < 32 || NC > 256 || (lds1 & 3) || lds1 < K || (out_plane_stride & 3) || (w_plane_stride & 7))
         return -CHAM_ERR_ARG;
@@ -321,6 +352,7 @@ static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, 
     DmfParams p;
     p.dS1 = dS1; p.lds1 = lds1; p.W = reinterpret_cast<const __bf16*>(Wp); p.w_ps = w_plane_stride; p.Z2c = Z2c; p.pred = pred;
     p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.osc = reinterpret_cast<const H2Scale*>(out_scale_rec);
+    p.sa = reinterpret_cast<const H2Scale*>(a_scale_rec); p.sw = reinterpret_cast<const H2Scale*>(w_scale_rec);
     p.dpred = dpred_pre; p.b2part = col_part;
     p.C = C; p.BT = BT; p.NC = NC; p.PW = 256 / NC;
     constexpr int smem = 2 * DMF_HALF + DMF_RED_BYTES;
@@ -343,6 +375,15 @@ extern "C" int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void*
                                   const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
                                   float* dpred_pre, float* col_part, void* stream) {
     return dm_mulpred_launch<1>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream);
+}
+
+// ... and with the kernel's own products on two fp16 planes as well (MODE 3): Wh = plane 0 of cham_split2h(Ws1 [C, K]) under the scale of
+// w_scale_rec (planes w_plane_stride elements apart), ds1_scale_rec = a record whose scale covers max |dS1| (cham_h2_scale_rownorm2's second record)
+extern "C" int cham_dm_mulpred_h2h(const float* dS1, int lds1, int K, const void* Wh, long long w_plane_stride, const void* ds1_scale_rec,
+                                   const void* w_scale_rec, const float* Z2c, const float* pred, int C, int BT, int N, void* dZ2p,
+                                   long long out_plane_stride, const void* out_scale_rec, float* dpred_pre, float* col_part, void* stream) {
+    return dm_mulpred_launch<3>(dS1, lds1, K, Wh, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream,
+                                ds1_scale_rec, w_scale_rec);
 }
 
 // The bf16 configuration's twin (BASELINE configs[2]): dS1 [BT*(1+N), K = 128] bf16 (row stride lds1 elements), Ws1b = the bf16 shadow of Ws1

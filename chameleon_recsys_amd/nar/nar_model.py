@@ -202,10 +202,16 @@ class NARRuntime:
         # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
         # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A library-wide setting.
         self.lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
-        # the scorer's first layer over cand (.) pred and its weight gradient on two fp16 planes split while staged (csrc/gemm_x3.hip NP = 2,
-        # cham_gemm_f32x2h, round 5): three plane products instead of six for the 2 x 65 GFLOP that were left on the six-product kernel;
-        # |cand (.) pred| <= 1 (two tanh outputs: a constant scale record), Ws1 and dS1 by their max row norm.  CHAM_S1_H2=0: the bf16x3 arm
-        self.s1_h2 = self.h2 and os.environ.get("CHAM_S1_H2", "1") == "1"
+        # the scorer's first layer on two fp16 planes split while staged (round 5) - THREE plane products instead of six for the 3 x 65 GFLOP that were
+        # left on six-product kernels: its weight gradient (csrc/gemm_x3.hip NP = 2, cham_gemm_f32x2h; |cand (.) pred| <= 1: a constant scale record,
+        # dS1 by its max row norm) and the products inside its fused dgrad (csrc/dm_fused.hip MODE 3, cham_dm_mulpred_h2h; Ws1's planes by its max
+        # row norm).  CHAM_S1_H2=1 (default): those two BACKWARD kernels; =a: the forward GEMM as well (another 0.1 ms, but the 200-step loss curve
+        # then leaves the float64 trajectory earlier than every other fp32 arm - profiles/r05_notes.md section 9 - so the forward keeps its exact
+        # 24-bit operands); =0: six bf16 products in all three
+        mode = os.environ.get("CHAM_S1_H2", "1") if self.h2 else "0"
+        self.s1_h2 = mode in ("1", "a")          # the weight gradient
+        self.dm_f16 = self.s1_h2                  # the fused dgrad's own products
+        self.s1_h2_fwd = mode == "a"              # the forward GEMM
         self.tf_random_seed = int(params.get('tf_random_seed', 42))
         # resident article tables
         meta = params['articles_metadata']
@@ -307,6 +313,8 @@ class NARRuntime:
             # (and for 1 + N outside [32, 256]) the two separate kernels
             self.dm_fused = L.entries['Ws1'].shape == (C_, 128) and C_ % 64 == 0
             self.ws1p = torch.zeros(3, C_, 128, dtype=torch.bfloat16, device=dev)     # planes of Ws1 as stored
+            if self.h2:       # ... and its two fp16 planes under the scale of sc_ws1n (the fused dgrad's own products, CHAM_S1_H2)
+                self.ws1h = torch.zeros(2, C_, 128, dtype=torch.float16, device=dev)
         self._plans = {}
         self.max_plans = 24                       # padded lengths T seen in a run (seq_len - 1 = 19 at most for G1)
         self.plan_bytes_budget = 128 << 30        # of the 288 GB: activations of the cached shapes
@@ -365,6 +373,9 @@ class NARRuntime:
             C = self.layout.C
             if self.dm_fused:
                 check(self.lib.cham_split3(ptr(self.p('Ws1')), C, 128, 128, ptr(self.ws1p), C * 128, 128, None, 0, 0, _stream()), "cham_split3")
+                if self.dm_f16:     # (scale: the row-norm record derived just above - no second pass over the weight)
+                    check(self.lib.cham_split2h(ptr(self.p('Ws1')), C, 128, 128, ptr(self.ws1h), C * 128, 128, None, 0, 0, ptr(self.sc_ws1n), 0,
+                                                _stream()), "cham_split2h")
         if self.b16:
             for name in ('W2', 'Ws1', 'Ws2', 'Ws3'):
                 r, c = self.layout.entries[name].shape
@@ -1250,7 +1261,7 @@ class NARModuleModel:
             _roctx.pop(); _roctx.push("K5 scorer, softmax, loss")
             Z2c = pl.Z2[BT:Rall]
             rt.gemm(Z2c, p('Ws1'), pl.S1, Rc, 128, C, C, 128, 128, bias=p('bs1'), act=ACT_LEAKY, rowscale=pl.pred, ldrs=C, rs_div=NC,
-                    h2scales=(rt.sc_unit, rt.sc_ws1n) if rt.s1_h2 else None)
+                    h2scales=(rt.sc_unit, rt.sc_ws1n) if rt.s1_h2_fwd else None)
             rt.gemm(pl.S1, p('Ws2'), pl.S2, Rc, 64, 128, 128, 64, 64, bias=p('bs2'), act=ACT_LEAKY)
             rt.gemm(pl.S2, p('Ws3'), pl.S3, Rc, 32, 64, 64, 32, 32, bias=p('bs3'), act=ACT_LEAKY)
             softmax_fwd = lib.cham_score_softmax_fwd
@@ -1402,15 +1413,19 @@ class NARModuleModel:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if h2:
-                check(lib.cham_dm_mulpred_h2(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
-                                             ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2")
+                if rt.dm_f16:     # the kernel's own products on two fp16 planes too
+                    check(lib.cham_dm_mulpred_h2h(ptr(pl.dS1), 128, 128, ptr(rt.ws1h), C * 128, ptr(pl.sc_ds1), ptr(rt.sc_ws1n), ptr(Z2c), ptr(pl.pred),
+                                                  C, BT, N, ptr(pl.dZ2p), pl.p3_ps, ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2h")
+                else:
+                    check(lib.cham_dm_mulpred_h2(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
+                                                 ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2")
             else:
                 check(lib.cham_dm_mulpred_p3(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
                                              ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_p3")
             if prof is not None:
                 e1.record()
                 prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=False,
-                                 dmf=True, h2out=bool(h2), tile=0, epi=0, ev=(e0, e1)))
+                                 dmf=True, h2out=bool(h2), f16p=bool(h2 and rt.dm_f16), tile=0, epi=0, ev=(e0, e1)))
         elif dm_fused_b16:      # bf16 configuration: the same fusion over single bf16 matrices (dM rounded to bf16 where the pair stores it)
             prof = rt.profile
             if prof is not None:

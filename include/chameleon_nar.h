@@ -152,8 +152,9 @@ void cham_gemm_f32x3_launch_counts(long long* out8, int reset);
  * of cham_gemm_h2 below for operands that exist in fp32 anyway.  sa_rec / sb_rec: the operands' H2Scale records (device memory, see
  * cham_gemm_h2; A's covers A x rowscale when a row-broadcast scale is given); |element x scale| < 65 504 is the caller's contract.  Forms:
  * NN (transA = transB = 0; bias + CHAM_ACT_NONE / LEAKY / TANH; rowscale on A) and TN (transA = 1; split-K as cham_gemm_f32; rowscale on
- * A), N > 64; -EINVAL otherwise.  Replaces matching_dense_layer_1 over cand (.) pred (nar_model.py:447-451, 478-495; |tanh x tanh| <= 1:
- * a constant record) and its weight gradient (autodiff under :718) when the runtime's default arithmetic is on.  Launches are counted in
+ * A), N > 64; -EINVAL otherwise.  Replaces the weight gradient of matching_dense_layer_1 over cand (.) pred (nar_model.py:447-451, 478-495,
+ * autodiff under :718; |tanh x tanh| <= 1: a constant record) when the runtime's default arithmetic is on; the forward matmul of that layer
+ * only under CHAM_S1_H2=a (it keeps its exact operands by default: DESIGN.md section 3).  Launches are counted in
  * cham_gemm_f32x3_launch_counts out8[4] (128 x 128 tile) / out8[5] (256 x 128). */
 int cham_gemm_f32x2h(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
                      const float* bias, int act, const float* rowscale, int ldrs, int rs_div, int accumulate, float* workspace,
@@ -232,6 +233,13 @@ int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, in
 int cham_dm_mulpred_h2(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c, const float* pred,
                        int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec, float* dpred_pre,
                        float* col_part, void* stream);
+/* cham_dm_mulpred_h2 with the kernel's own products (dS1 Ws1^T, K = 128) on two fp16 planes as well (round 5): Wh = plane 0 of
+ * cham_split2h(Ws1 [C, K]) under the scale of w_scale_rec (planes w_plane_stride elements apart), dS1 split in registers with the scale of
+ * ds1_scale_rec (a record covering max |dS1|: cham_h2_scale_rownorm2's second record) - three v_mfma_f32_32x32x16_f16 products instead of
+ * six bf16 ones; same outputs, same shape limits. */
+int cham_dm_mulpred_h2h(const float* dS1, int lds1, int K, const void* Wh, long long w_plane_stride, const void* ds1_scale_rec,
+                        const void* w_scale_rec, const float* Z2c, const float* pred, int C, int BT, int N, void* dZ2p,
+                        long long out_plane_stride, const void* out_scale_rec, float* dpred_pre, float* col_part, void* stream);
 /* the bf16 configuration's twin (BASELINE configs[2]): every matrix a single bf16 array (dS1 [BT*(1+N), K] row stride lds1 ELEMENTS, Ws1b = the
  * bf16 shadow of Ws1 [C, K] as stored, Z2c and the output dZ2c [BT*(1+N), C]); replaces cham_gemm_b16(dS1, Ws1) + cham_mulpred_bwd_b16 and,
  * through col_part (sums of the STORED, bf16-rounded rows), the cham_colsum_b16 pass of the b2 gradient.  Same shape limits. */

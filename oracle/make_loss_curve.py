@@ -12,7 +12,8 @@ on the GPU box are gone.
   python oracle/make_loss_curve.py merge          # all arms -> tests/golden/loss_curve_200.npz
 
 Arms: f64 (float64 everything, the graph's own float32 quantisations kept), f32 (the oracle as every parity test uses it),
-f32_p1..p3 (fp32 with every contraction summed in a permuted order: NAROracle(sum_perm_seed=k)).
+f32_p1..p11 (fp32 with every contraction summed in a permuted order: NAROracle(sum_perm_seed=k)) - twelve fp32 realisations: four were
+too small a sample of a chaotic divergence (the level two of them reach at step 22 a HIP arm reached at step 19).
 Inputs / weights: tests/helpers.py loss_curve_setup() (seeded, host only) - exactly what the GPU test feeds the HIP path.
 Per step: total / cross-entropy / regularisation loss; SHA-1 of the drawn negatives (integer path: identical in every arm);
 after the last step: top-5 ranked ids of four held-out batches in EVAL mode (HitRate@5 / MRR@5 of the trained weights).
@@ -30,8 +31,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out")
 GOLD = os.path.join(ROOT, "tests", "golden", "loss_curve_200.npz")
-ARMS = {"f64": (torch.float64, None), "f32": (torch.float32, None), "f32_p1": (torch.float32, 1), "f32_p2": (torch.float32, 2),
-        "f32_p3": (torch.float32, 3)}
+ARMS = {"f64": (torch.float64, None), "f32": (torch.float32, None)}
+ARMS.update({"f32_p%d" % k: (torch.float32, k) for k in range(1, 12)})          # eleven permuted-summation realisations (p4..p11 added late in round 5)
 
 
 def run(arm, steps=None):

@@ -20,9 +20,9 @@ def test_rebuilt_gemm_symbols_are_the_names_rocprof_lists():
     names = _stats_names()
     base = dict(transA=0, transB=1, rowscale=False, bf16=False, tile=0)
     recs = [dict(base, h2=True, h2w=True, epi=3), dict(base, h2=True, h2w=True, epi=2), dict(base, h2=True, epi=6, transA=1, transB=0),      # h2w: the NT forms on the 64-byte-piece kernel
-            dict(base, dmf=True, h2out=True, epi=0),          # -> k_dm_mulpred_fused<1>
-            dict(base, x3=True, x2h=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue), two fp16 planes
-            dict(base, x3=True, x2h=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient
+            dict(base, dmf=True, h2out=True, f16p=True, epi=0),          # -> k_dm_mulpred_fused<3>
+            dict(base, x3=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue), six bf16 products
+            dict(base, x3=True, x2h=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient, two fp16 planes
             dict(base, x3=True, tile=0, epi=6, transA=1, transB=0)]                                   # bf16x3 (the other wide weight gradients)
     for r in recs:
         sym = bench.gemm_symbol(r)

@@ -126,3 +126,63 @@ def test_dm_fused_bf16_twin_matches_the_unfused_pair(gpu, BT, N, C):
     assert float((o.float() - dZ.float()).abs().max()) <= 2.0 ** -7 * float(dZ.float().abs().max())
     assert float((dp.double() - dpred_ref.double()).abs().max()) < 2e-3 * float(dpred_ref.abs().max())
     assert float((b2.double() - b2_ref).abs().max()) < 2e-3 * float(b2_ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("BT,N,C,wide", [(40, 50, 1024, False), (23, 100, 1024, True), (9, 200, 1024, False), (16, 31, 128, True), (5, 255, 64, False),
+                                         (256 * 19 // 4, 50, 1024, True)])
+def test_dm_fused_two_fp16_plane_products_match_float64_and_the_six_product_form(gpu, BT, N, C, wide):
+    """MODE 3 (cham_dm_mulpred_h2h, round 5): the kernel's own K = 128 products as THREE fp16-plane products (dS1 under the scale of its max row
+    norm - cham_h2_scale_rownorm2's second record - Ws1's planes under its row-norm record) next to MODE 1 (six bf16 products) on the same
+    operands and records: the two-plane outputs, dpred and the b2 partial sums against float64, not measurably worse than MODE 1; `wide`: the
+    rows of dS1 spread over 20 binary orders of magnitude (one scale per matrix: the absolute-error contract)."""
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    NC = N + 1
+    Rc = BT * NC
+    g = torch.Generator(device=gpu).manual_seed(11)
+    dS1 = torch.randn(Rc, 128, device=gpu, generator=g) * 1e-3
+    if wide:
+        dS1 = dS1 * torch.exp2(-20 * torch.rand(Rc, 1, device=gpu, generator=g))
+    Ws1 = torch.randn(C, 128, device=gpu, generator=g) * 0.05
+    Z2 = torch.tanh(torch.randn(Rc, C, device=gpu, generator=g))
+    pred = torch.tanh(torch.randn(BT, C, device=gpu, generator=g))
+    st = torch.cuda.current_stream().cuda_stream
+    Wp = split3(Ws1)
+    rw, rout, rds = (torch.zeros(8, device=gpu) for _ in range(3))
+    check(lib.cham_h2_scale_rownorm(ptr(Ws1), C, 128, 128, None, ptr(rw), st), "rownorm")
+    check(lib.cham_h2_scale_rownorm2(ptr(dS1), Rc, 128, 128, rw.data_ptr() + 8, ptr(rout), ptr(rds), st), "rownorm2")
+    Wh = torch.zeros(2, C, 128, dtype=torch.float16, device=gpu)
+    check(lib.cham_split2h(ptr(Ws1), C, 128, 128, ptr(Wh), C * 128, 128, None, 0, 0, ptr(rw), 0, st), "split2h")
+    outs = []
+    for mode in (1, 3, 3):
+        D = torch.full((2, Rc, C), float('nan'), dtype=torch.float16, device=gpu)
+        dp, b2 = torch.full((BT, C), float('nan'), device=gpu), torch.full((BT, C), float('nan'), device=gpu)
+        if mode == 1:
+            check(lib.cham_dm_mulpred_h2(ptr(dS1), 128, 128, ptr(Wp), C * 128, ptr(Z2), ptr(pred), C, BT, N, ptr(D), Rc * C, ptr(rout), ptr(dp), ptr(b2), st), "h2")
+        else:
+            check(lib.cham_dm_mulpred_h2h(ptr(dS1), 128, 128, ptr(Wh), C * 128, ptr(rds), ptr(rw), ptr(Z2), ptr(pred), C, BT, N, ptr(D), Rc * C, ptr(rout),
+                                          ptr(dp), ptr(b2), st), "h2h")
+        torch.cuda.synchronize()
+        outs.append((D, dp, b2))
+    assert all(torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+               for a, b in zip(outs[1], outs[2])), "not repeatable (race?)"
+    dM = dS1.double() @ Ws1.double().t()
+    pr = pred.double().repeat_interleave(NC, dim=0)
+    o_ref = dM * pr * (1 - Z2.double() ** 2)
+    dp_ref = (dM * Z2.double()).view(BT, NC, C).sum(1) * (1 - pred.double() ** 2)
+    b2_ref = o_ref.view(BT, NC, C).sum(1)
+    inv = float(rout[1])
+    errs = []
+    for D, dp, b2 in outs[:2]:
+        assert torch.isfinite(D.float()).all() and float(D[0].float().abs().max()) <= 2.0 ** 15
+        got = (D[0].double() + D[1].double()) * inv
+        errs.append((float((got - o_ref).abs().max()) / float(o_ref.abs().max()), float((dp.double() - dp_ref).abs().max()) / float(dp_ref.abs().max()),
+                     float((b2.double() - b2_ref).abs().max()) / float(b2_ref.abs().max())))
+    (e1_o, e1_dp, e1_b2), (e3_o, e3_dp, e3_b2) = errs
+    assert e3_o < 2e-6 and e3_dp < 5e-6 and e3_b2 < 5e-6, errs
+    assert e3_o < 1.5 * e1_o + 3e-7 and e3_dp < 1.5 * e1_dp + 5e-7 and e3_b2 < 1.5 * e1_b2 + 5e-7, errs
+    # the sign of the h plane is the sign of the value (the CAR dgrad reads leaky' from a plane like it; here: sanity of the plane format)
+    assert torch.equal(outs[1][0][0].view(torch.int16) > 0, ((outs[1][0][0].double() + outs[1][0][1].double()) > 0))
+    assert lib.cham_dm_mulpred_h2h(ptr(dS1), 128, 128, ptr(Wh), C * 128, None, ptr(rw), ptr(Z2), ptr(pred), C, BT, N, ptr(outs[0][0]), Rc * C, ptr(rout),
+                                   ptr(outs[0][1]), ptr(outs[0][2]), st) < 0

@@ -177,8 +177,9 @@ def test_step_parity_g1_shape(gpu, monkeypatch, length_dist, gemm_dtype, arith):
         assert (h2_counts(lib)[0] == 0) == (arith == "p3") and (p3_counts(lib)[0] == 0) == (arith == "h2")
         # (scorer layer 1 forward + its weight gradient; its dgrad lives in the fused kernel csrc/dm_fused.hip)
         assert x[1] + x[5] >= (2 if length_dist == "full" else 0) and x[0] + x[1] + x[4] + x[5] >= 2 and model.rt.dm_fused, x
-        # ... the default arithmetic runs those two on the two-fp16-plane form of that kernel (cham_gemm_f32x2h, round 5), the p3 arm does not
-        assert x[4] + x[5] == (2 if arith == "h2" else 0), x
+        # ... the default arithmetic runs the weight gradient on the two-fp16-plane form of that kernel (cham_gemm_f32x2h, round 5; the forward
+        # keeps its exact operands), the p3 arm does not
+        assert x[4] + x[5] == (1 if arith == "h2" else 0), x
     elif gemm_dtype == "f32":
         # CAR forward / dgrad / wgrad, scorer layer 1 (row scale) + its wgrad and dgrad on the 256x128 bf16x3 instance; nothing wide on
         # the native kernels
@@ -249,7 +250,7 @@ def test_step_parity_adressa_shape(gpu):
     reset_counts(lib)
     compare_step_large(model, orc, *batches[3], st)
     x = x3_counts(lib)
-    assert car_gemm_counts(model) == (2, 1) and x[1] + x[5] >= 2 and x[4] + x[5] == 2, (car_gemm_counts(model), x)
+    assert car_gemm_counts(model) == (2, 1) and x[1] + x[5] >= 2 and x[4] + x[5] == 1, (car_gemm_counts(model), x)
 
 
 @pytest.mark.parametrize("dma", [True, False])
@@ -337,28 +338,32 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     nar_trainer_gcom.py:511-525) from the same initial weights - adjudicated by a FLOAT64 trajectory.
 
     tests/golden/loss_curve_200.npz (oracle/make_loss_curve.py, generated in the build container: the CPU oracle no longer runs 200 steps
-    inside the GPU suite) holds the oracle's per-step loss in float64 and in FOUR float32 realisations (the oracle as every parity test
-    uses it + three with every contraction summed in a permuted order).  What it shows, before any HIP kernel is involved: every fp32
-    realisation of the ORACLE ITSELF leaves 1e-3 of the float64 curve after 37-42 steps and is 2.1e-2 ... 3.7e-2 away at its worst
-    (mean 2.7e-3 ... 4.7e-3) - under TF-Adam an entry whose gradient is roundoff moves by +-lr per step in either run, and the
+    inside the GPU suite) holds the oracle's per-step loss in float64 and in TWELVE float32 realisations (the oracle as every parity test
+    uses it + eleven with every contraction summed in a permuted order; four until late in round 5 - too small a sample of a chaotic
+    divergence).  What it shows, before any HIP kernel is involved: every fp32
+    realisation of the ORACLE ITSELF leaves 1e-3 of the float64 curve after 35-43 steps and is 1.0e-2 ... 4.8e-2 away at its worst
+    (mean 2.5e-3 ... 4.8e-3) - under TF-Adam an entry whose gradient is roundoff moves by +-lr per step in either run, and the
     difference is amplified chaotically.  "Within 1e-3 for 200 steps" is therefore not a property any fp32 implementation of this
     training loop can have (TensorFlow's own Eigen kernels included); the criterion that CAN fail is stated against the spread of the
     fp32 realisations:
       * every step i of the 200: |HIP - f64|_i <= 4 x E_i + 1e-4, E_i = running max over steps <= i of the largest |oracle_f32 - f64| of
-        the four realisations (leave-one-out among the oracle's own four arms: worst 2.78 x the other three's running max - the factor 2
-        of the round-4 verdict is exceeded by the oracle itself; 4 leaves ~1.4 x room), both HIP arms (default two-fp16-plane arithmetic
-        and every GEMM on the native fp32 MFMA);
+        the twelve realisations (leave-one-out among the oracle's own arms: worst 2.2 x the other eleven's running max, 2.78 among the first
+        four - the factor 2 of the round-4 verdict is exceeded by the oracle itself), both HIP arms (default two-fp16-plane arithmetic
+        and every GEMM on the native fp32 MFMA; measured on the final build: at most 0.23 / 0.30 of that bound, never above 0.94 / 1.23 x E_i
+        itself after step 25).  The bound has teeth: with the scorer's FORWARD layer-1 GEMM on two fp16 planes (CHAM_S1_H2=a) the default arm
+        is 4.4e-4 ... 6.7e-4 away at step 19 where all twelve realisations are <= 1.4e-4, and fails here - which is why that GEMM keeps its
+        exact operands (profiles/r05_notes.md section 9);
       * plain 1e-3 for the first 25 steps (the fp32 realisations: <= 2.0e-4 by step 20, 5.7e-4 by step 30) and the step up to which
         1e-3 holds printed for all six curves;
       * mean |HIP - f64| <= 2 x the worst realisation's mean + 1e-4;
-      * negatives bit-exact at every step (SHA-1 of the drawn ids against the fixture: the integer path of all five oracle arms);
+      * negatives bit-exact at every step (SHA-1 of the drawn ids against the fixture: the integer path of all thirteen oracle arms);
       * and, because a free-running comparison cannot see a systematic error below the drift, the TIGHT criterion at steps
         0, 50, 100, 150 and 199 of the default arm's own trajectory: the oracle (fp32) is loaded with the HIP weights of that step and
         both evaluate that step's batch - logits / loss within 1e-3 (measured ~1e-6), every gradient tensor within 1e-4 relative L2
         (compare_step_large, the per-step parity criterion) - the HIP step is as exact on trained weights as on the initial ones.
     Then HitRate@5 / MRR@5 of four held-out batches ranked against 50 sampled negatives (the other half of BASELINE.json's metric): the
     HIP-trained weights evaluated by the HIP path and by the oracle (the eval path alone: at most one tie broken differently), and
-    against the fixture's five oracle-trained values (0.3389 ... 0.3507: two trainings differ by the same drift)."""
+    against the fixture's thirteen oracle-trained values (0.3389 ... 0.3519: two trainings differ by the same drift)."""
     import hashlib
     from chameleon_recsys_amd.nar import metrics
     from chameleon_recsys_amd.nar.nar_model import ModeKeys, NARModuleModel
@@ -366,7 +371,7 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_curve_200.npz"))
     B, STEPS = H.LOSS_CURVE['B'], int(os.environ.get("CHAM_CURVE_STEPS", str(H.LOSS_CURVE['steps'])))
     f64, f32 = fx['loss_f64'], fx['loss_f32']
-    assert STEPS <= len(f64) and f32.shape == (4, len(f64))
+    assert STEPS <= len(f64) and f32.shape[0] >= 4 and f32.shape[1] == len(f64)
     env = np.maximum.accumulate(np.abs(f32 - f64[None]).max(0))
     p, batches, st, w = H.loss_curve_setup()
     model, _ = H.make_pair(p, seed=H.LOSS_CURVE['weight_seed'])
@@ -374,6 +379,7 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
     assert model.rt.h2 and not native.rt.x3
     assert all(np.array_equal(w[k], v) for k, v in model.rt.logical_weights().items())          # the fixture's initial weights
     dev = {"default": [], "native": []}
+    violations = []          # (checked after the curves have been written out: a failing run still leaves its 200 deviations behind)
     CHECK = (0, 50, 100, 150, STEPS - 1)
     t_start = time.time()
     for i, (f, l) in enumerate(batches[2:2 + STEPS]):
@@ -390,8 +396,10 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
             assert sha == str(fx['neg_sha1'][i]), "step %d (%s): negative samples differ from the oracle's" % (i, name)
             d = abs(float(loss[0]) - float(f64[i]))
             dev[name].append(d)
-            assert d <= 4.0 * env[i] + 1e-4, "step %d (%s): |loss - f64| %.3e, fp32 realisations of the oracle so far <= %.3e" % (i, name, d, env[i])
-            assert i >= 25 or d < LOGIT_TOL, "step %d (%s): loss %r vs float64 oracle %.6f" % (i, name, loss, float(f64[i]))
+            if d > 4.0 * env[i] + 1e-4:
+                violations.append("step %d (%s): |loss - f64| %.3e, fp32 realisations of the oracle so far <= %.3e" % (i, name, d, env[i]))
+            if i < 25 and d >= LOGIT_TOL:
+                violations.append("step %d (%s): loss %r vs float64 oracle %.6f" % (i, name, loss, float(f64[i])))
         H.update_state(st, f, l)
     within = lambda x: int(next((i for i, d in enumerate(x) if d >= LOGIT_TOL), len(x)))
     held = {"hip default": within(dev["default"]), "hip native fp32 MFMA": within(dev["native"])}
@@ -400,11 +408,13 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
           "mean default %.2e native %.2e, arms %s" % (STEPS, time.time() - t_start, held, max(dev["default"]), max(dev["native"]),
                                                       ["%.2e" % x for x in np.abs(f32 - f64[None])[:, :STEPS].max(1)], float(np.mean(dev["default"])),
                                                       float(np.mean(dev["native"])), ["%.2e" % x for x in np.abs(f32 - f64[None])[:, :STEPS].mean(1)]))
+    _dump_curve("loss_curve_%d.json" % STEPS, dict(batch=B, steps=STEPS, loss_f64=[float(x) for x in f64[:STEPS]], abs_dev_default=dev["default"],
+                                            abs_dev_native=dev["native"], envelope_fp32_oracle=[float(x) for x in env[:STEPS]], held_1e3=held,
+                                            violations=violations))
+    assert not violations, violations[:5]
     worst_mean = float(np.abs(f32 - f64[None])[:, :STEPS].mean(1).max())
     for name in dev:
         assert float(np.mean(dev[name])) <= 2.0 * worst_mean + 1e-4, (name, float(np.mean(dev[name])), worst_mean)
-    _dump_curve("loss_curve_%d.json" % STEPS, dict(batch=B, steps=STEPS, loss_f64=[float(x) for x in f64[:STEPS]], abs_dev_default=dev["default"],
-                                            abs_dev_native=dev["native"], envelope_fp32_oracle=[float(x) for x in env[:STEPS]], held_1e3=held))
     if STEPS != H.LOSS_CURVE['steps']:
         return
     ev = NARModuleModel(ModeKeys.EVAL, None, None, p['session_features_config'], p['articles_features_config'], B, p['lr'], 1.0,
