@@ -4,7 +4,8 @@ HIP kernel involved: the fp32 oracle with the two operands of matching_dense_lay
 cham_gemm_f32x2h rounds them - h = fp16(x s), l = fp16(x s - h), x' = (h + l) / s; s = 2^14 for cand (.) pred, the max-row-norm scale for the
 weight - in the FORWARD only (straight-through: gradients flow as if x' = x), trained for the first steps of the 200-step loss-curve setup and
 compared with the float64 trajectory of tests/golden/loss_curve_200.npz next to the twelve unrounded fp32 realisations.  Result (round 5, four
-arms per variant): 1.3-2.2 x the drift of sixteen unrounded arms for the scorer's layer, 0.8-1.0 x for the CAR layer-2 matmul.
+arms per variant): 1.3-2.2 x the drift of sixteen unrounded arms for the scorer's layer (nothing measurable with only one of its two operands
+rounded), 0.8-1.0 x for the CAR layer-2 matmul.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py); runs in the build container:
   python oracle/probe_forward_rounding.py [steps=45] [perm seeds ...]   -> gpurun_out/forward_rounding_probe.json
@@ -53,13 +54,15 @@ def run(steps, perm, rounded, where="scorer"):
             return self._store(torch.tanh(self._mm(two_plane(pre, sp), two_plane(k, sk)) + w['CAR/bias']))
 
         def _scorer(self, m):
-            if not (rounded and where == "scorer"):
+            if not (rounded and where.startswith("scorer")):
                 return super()._scorer(m)
             w = self.w
             k = w['match1/kernel']
             bound = float(k.detach().double().pow(2).sum(1).sqrt().max()) * 1.0009765625          # k_h2_scale_rownorm
             sw = 2.0 ** (15 - math.frexp(bound)[1])
-            s1 = self._leaky_site('S1', self._mm(two_plane(m, 2.0 ** 14), two_plane(k, sw)) + w['match1/bias'])
+            ma = m if where == "scorer_w" else two_plane(m, 2.0 ** 14)          # scorer_a / scorer_w: only one of the two operands rounded
+            kw = k if where == "scorer_a" else two_plane(k, sw)
+            s1 = self._leaky_site('S1', self._mm(ma, kw) + w['match1/bias'])
             s2 = self._leaky_site('S2', self._mm(s1, w['match2/kernel']) + w['match2/bias'])
             s3 = self._store(self._leaky_site('S3', self._mm(s2, w['match3/kernel']) + w['match3/bias']))
             self._tap('S1', s1); self._tap('S2', s2); self._tap('S3', s3)
@@ -78,7 +81,7 @@ def run(steps, perm, rounded, where="scorer"):
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", "4")))
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 45
-    where = os.environ.get("PROBE_WHERE", "scorer")          # scorer | car
+    where = os.environ.get("PROBE_WHERE", "scorer")          # scorer | car | scorer_a | scorer_w
     controls = os.environ.get("PROBE_CONTROLS", "1") == "1"
     perms = [None if a == "none" else int(a) for a in sys.argv[2:]] or [None, 1, 2]
     fx = np.load(os.path.join(ROOT, "tests", "golden", "loss_curve_200.npz"))
@@ -86,8 +89,9 @@ if __name__ == "__main__":
     res = dict(steps=steps, arms={})
     for perm in perms:
         for rounded in ((True, False) if controls else (True,)):
-            name = "%s, sum_perm_seed=%s" % (("forward operands on two fp16 planes" if where == "scorer" else "CAR layer-2 forward operands on two fp16 planes")
-                                             if rounded else "exact operands (control)", perm)
+            label = {"scorer": "forward operands on two fp16 planes", "car": "CAR layer-2 forward operands on two fp16 planes",
+                     "scorer_a": "only cand (.) pred on two fp16 planes", "scorer_w": "only Ws1 on two fp16 planes"}[where]
+            name = "%s, sum_perm_seed=%s" % (label if rounded else "exact operands (control)", perm)
             dev = np.abs(np.asarray(run(steps, perm, rounded, where)) - f64)
             res['arms'][name] = [float(x) for x in dev]
             print("%-70s |loss - f64| at steps 10 15 19 22 25 30 40: %s" % (name, " ".join("%.1e" % dev[s] for s in (10, 15, 19, 22, 25, 30, 40) if s < steps)), flush=True)
