@@ -206,7 +206,7 @@ class NARRuntime:
         # left on six-product kernels: its weight gradient (csrc/gemm_x3.hip NP = 2, cham_gemm_f32x2h; |cand (.) pred| <= 1: a constant scale record,
         # dS1 by its max row norm) and the products inside its fused dgrad (csrc/dm_fused.hip MODE 3, cham_dm_mulpred_h2h; Ws1's planes by its max
         # row norm).  CHAM_S1_H2=1 (default): those two BACKWARD kernels; =a: the forward GEMM as well (another 0.1 ms, but the 200-step loss
-        # curve then leaves the float64 curve earlier than every other fp32 arm, and the CPU oracle with the same rounding agrees in direction -
+        # curve then left the float64 curve earlier than every other fp32 arm - one trajectory; the CPU oracle with the same rounding: 1.1-1.4 x -
         # profiles/r05_notes.md section 9 - so the forward keeps its exact 24-bit operands); =0: six bf16 products in all three
         mode = os.environ.get("CHAM_S1_H2", "1") if self.h2 else "0"
         self.s1_h2 = mode in ("1", "a")          # the weight gradient

@@ -3,9 +3,9 @@
 HIP kernel involved: the fp32 oracle with the two operands of matching_dense_layer_1 (reference nar_model.py:447-451, 478-495) rounded the way
 cham_gemm_f32x2h rounds them - h = fp16(x s), l = fp16(x s - h), x' = (h + l) / s; s = 2^14 for cand (.) pred, the max-row-norm scale for the
 weight - in the FORWARD only (straight-through: gradients flow as if x' = x), trained for the first steps of the 200-step loss-curve setup and
-compared with the float64 trajectory of tests/golden/loss_curve_200.npz next to the twelve unrounded fp32 realisations.  Result (round 5, four
-arms per variant): 1.3-2.2 x the drift of sixteen unrounded arms for the scorer's layer (nothing measurable with only one of its two operands
-rounded), 0.8-1.0 x for the CAR layer-2 matmul.
+compared with the float64 trajectory of tests/golden/loss_curve_200.npz next to the twelve unrounded fp32 realisations.  Result (round 5): 1.1-1.4 x
+the drift of sixteen unrounded arms for the scorer's layer (twelve arms; nothing measurable with only one of its two operands rounded, four arms
+each), 0.8-1.0 x for the CAR layer-2 matmul (four arms).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py); runs in the build container:
   python oracle/probe_forward_rounding.py [steps=45] [perm seeds ...]   -> gpurun_out/forward_rounding_probe.json

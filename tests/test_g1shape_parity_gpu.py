@@ -352,7 +352,7 @@ def test_loss_curve_g1_shape_and_hitrate(gpu):
         and every GEMM on the native fp32 MFMA; measured on the final build: at most 0.23 / 0.30 of that bound, never above 0.94 / 1.23 x E_i
         itself after step 25).  The bound can fail: with the scorer's FORWARD layer-1 GEMM on two fp16 planes (CHAM_S1_H2=a) the default arm
         was 4.4e-4 ... 6.7e-4 away at step 19 where all twelve realisations are <= 1.4e-4, and failed here - which is why that GEMM keeps its
-        exact operands (the CPU oracle with the same operand rounding shows the same direction: profiles/r05_notes.md section 9);
+        exact operands (one trajectory; the CPU oracle with the same operand rounding shows the direction at 1.1-1.4 x: profiles/r05_notes.md section 9);
       * plain 1e-3 for the first 25 steps (the fp32 realisations: <= 2.0e-4 by step 20, 5.7e-4 by step 30) and the step up to which
         1e-3 holds printed for all six curves;
       * mean |HIP - f64| <= 2 x the worst realisation's mean + 1e-4;
