@@ -79,6 +79,9 @@ class DataParallelNAR:
         self.comm_bf16 = self.mode != "sharded" and (want == "bf16" or (want == "auto" and getattr(rt, 'gemm_dtype', 'f32') == 'bf16'))
         self._comm16, self._early16 = None, None
         self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
+        # how often each collective ran (tests assert the reduce-scatter / all-gather branches really executed with world > 1;
+        # bench.py's "dp" object reports them)
+        self.collective_calls = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0, "broadcast": 0}
         # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
         # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
         # (tests/test_dp_rccl_gpu.py; bench.py's dp_self_exchange_ms)
@@ -98,6 +101,9 @@ class DataParallelNAR:
                     self._early = (a, b)
                     rt.dp_early_bucket = self._issue_early_bucket
             rt.dp_gather_slots = self._gather_slots
+            self._via_host = False
+            if self.mode in ("sharded", "sparse_rs"):
+                self._probe_tensor_collectives(rt.flat.device)
             if self.mode == "sharded":
                 if rt.flat.numel() % self.world:
                     raise ValueError("flat parameter buffer (%d) does not split over %d ranks" % (rt.flat.numel(), self.world))
@@ -113,31 +119,85 @@ class DataParallelNAR:
             # identical initial weights on every rank (a write to rt.flat that bypasses load_logical_weights: bump the version the
             # bf16 / plane shadows of the weights are keyed on)
             dist.broadcast(rt.flat, src=0, group=self.pg)
+            self.collective_calls["broadcast"] += 1
             rt.weights_version = getattr(rt, 'weights_version', 0) + 1
 
     # ---- early bucket (see __init__)
-    def _comm_buffer(self, flat_grads, n=None):
-        """bf16 communication buffer (allocated once; slices of it go through the collectives): an image of the whole flat gradient
-        buffer in the dense mode, `n` elements - the dense remainder - in the sparse modes (at config 5 the flat buffer is 1.9 G entries,
-        the dense remainder 3 M)."""
-        need = flat_grads.numel() if n is None else int(n)
+    COMM16_CHUNK = 1 << 25          # elements of the bf16 communication buffer (64 MB): larger ranges go through it in pieces
+
+    def _comm_buffer(self, flat_grads, n):
+        """bf16 communication buffer of at most COMM16_CHUNK elements, allocated once (round 5 imaged the WHOLE flat gradient
+        buffer - 3.8 GB at configs[4] - where a bounded staging buffer does)."""
+        need = min(int(n), self.COMM16_CHUNK)
         if self._comm16 is None or self._comm16.numel() < need or self._comm16.device != flat_grads.device:
             self._comm16 = torch.empty(need, dtype=torch.bfloat16, device=flat_grads.device)
         return self._comm16
 
+    def _probe_tensor_collectives(self, device):
+        """reduce_scatter_tensor / all_gather_into_tensor on a 4-element tensor of the runtime's device, once, on every rank (a
+        collective): RCCL takes device tensors, gloo takes CPU tensors (torch 2.10) - whether a gloo group takes DEVICE tensors (the
+        two-ranks-on-one-GPU tests) is found out here rather than assumed.  When it does not, the same two collectives run on host
+        staging copies (self._via_host): the chunking / owner-slice arithmetic around them is the same code either way."""
+        self._via_host = False
+        try:
+            x = torch.ones(self.world * 2, dtype=torch.float32, device=device)
+            y = torch.empty(2, dtype=torch.float32, device=device)
+            dist.reduce_scatter_tensor(y, x, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_gather_into_tensor(x, y, group=self.pg)
+            ok = bool((x.cpu() == float(self.world)).all())
+        except (RuntimeError, NotImplementedError, ValueError):
+            ok = False
+        if not ok:
+            if torch.device(device).type == "cpu":
+                raise RuntimeError("backend %r of the data-parallel group runs neither reduce_scatter_tensor nor all_gather_into_tensor: "
+                                   "CHAM_DP_MODE=%s needs them" % (dist.get_backend(self.pg), self.mode))
+            self._via_host = True
+
+    def _reduce_scatter(self, out, inp):
+        self.collective_calls["reduce_scatter"] += 1
+        if self._via_host:
+            h_out, h_in = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+            dist.reduce_scatter_tensor(h_out, h_in, op=dist.ReduceOp.SUM, group=self.pg)
+            out.copy_(h_out)
+        else:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _all_gather(self, out, inp):
+        self.collective_calls["all_gather"] += 1
+        if self._via_host:
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h_out, inp.cpu(), group=self.pg)
+            out.copy_(h_out)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.pg)
+
+    def _all_reduce(self, t, async_op=False):
+        self.collective_calls["all_reduce"] += 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+
     def _reduce_range(self, flat_grads, a, b, async_op=False, buf16=None):
         """all-reduce(SUM) of flat_grads[a:b] in the exchange dtype; returns (work or None, bytes handed to the collective).  In bf16 the
-        range is rounded into `buf16` (default: its place in the whole-buffer image) and the caller widens it back with _widen_range once
-        the collective has finished."""
-        if self.comm_bf16:
-            buf = self._comm_buffer(flat_grads)[a:b] if buf16 is None else buf16
-            buf.copy_(flat_grads[a:b])           # fp32 -> bf16, round to nearest even
-            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 2 * (b - a)
-        return dist.all_reduce(flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), 4 * (b - a)
+        range is rounded (nearest even) into a bf16 buffer, summed there by the collective and widened back into the fp32 buffer Adam
+        reads.  With `buf16` (the early bucket's own buffer, async) the CALLER widens with _widen_range once the collective has finished;
+        without it the range goes through the bounded staging buffer piece by piece, synchronously, and is widened here."""
+        if not self.comm_bf16:
+            return self._all_reduce(flat_grads[a:b], async_op=async_op), 4 * (b - a)
+        if buf16 is not None:
+            buf16.copy_(flat_grads[a:b])           # fp32 -> bf16, round to nearest even
+            return self._all_reduce(buf16, async_op=async_op), 2 * (b - a)
+        assert not async_op
+        stage = self._comm_buffer(flat_grads, b - a)
+        for c in range(a, b, self.COMM16_CHUNK):
+            d = min(b, c + self.COMM16_CHUNK)
+            piece = stage[:d - c]
+            piece.copy_(flat_grads[c:d])
+            self._all_reduce(piece)
+            flat_grads[c:d].copy_(piece)
+        return None, 2 * (b - a)
 
-    def _widen_range(self, flat_grads, a, b, buf16=None):
+    def _widen_range(self, flat_grads, a, b, buf16):
         if self.comm_bf16:
-            flat_grads[a:b].copy_(self._comm16[a:b] if buf16 is None else buf16)
+            flat_grads[a:b].copy_(buf16)
 
     def _issue_early_bucket(self, flat_grads):
         """Called by the backward pass on the lane that produced the bucket, right after its last gradient was written."""
@@ -172,13 +232,27 @@ class DataParallelNAR:
         self.last_exchange_bytes = self._early_bytes if early else 0
         for a, b in self._ranges_without_early(0, flat_grads.numel(), early):
             _, nbytes = self._reduce_range(flat_grads, a, b)
-            self._widen_range(flat_grads, a, b)
             self.last_exchange_bytes += nbytes
+
+    # ---- the touched rows of the item table <-> the packed [L, dim] exchange buffer (HIP: cham_rows_gather / cham_rows_scatter on the
+    # ---- current stream).  There is no CPU form of the product path: the world-2/3 gloo tests install numpy stand-ins for these two.
+    def _rows_gather(self, table, ids, rows):
+        from .._lib import check, ptr
+        if not table.is_cuda:
+            raise RuntimeError("cham_rows_gather is a HIP kernel: the item-table gradient must live on a ROCm device")
+        L, dim = rows.shape
+        check(self.model.rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), torch.cuda.current_stream().cuda_stream), "cham_rows_gather")
+
+    def _rows_scatter(self, rows, ids, table):
+        from .._lib import check, ptr
+        if not table.is_cuda:
+            raise RuntimeError("cham_rows_scatter is a HIP kernel: the item-table gradient must live on a ROCm device")
+        L, dim = rows.shape
+        check(self.model.rt.lib.cham_rows_scatter(ptr(rows), ptr(ids), L, dim, ptr(table), torch.cuda.current_stream().cuda_stream), "cham_rows_scatter")
 
     def _sparse_allreduce(self, flat_grads):
         """ONE collective for everything but the early bucket: [flat buffer without the item table | touched item-table rows] packed
         into a contiguous communication buffer (round 1 issued three: prefix, suffix, rows)."""
-        from .._lib import check, ptr
         rt = self.model.rt
         off, n, dim = self._item
         # GLOBAL clicked ids + candidate pool + pad item of this step: int32 row indices in a buffer of the StepPlan, written by
@@ -195,43 +269,43 @@ class DataParallelNAR:
             self._compact = torch.empty(need, dtype=flat_grads.dtype, device=flat_grads.device)
         comm = self._compact[:need]
         table = flat_grads[off:off + n * dim]
-        st = torch.cuda.current_stream().cuda_stream
         o = 0
         for a, b in ranges:
             comm[o:o + b - a].copy_(flat_grads[a:b]); o += b - a
         rows = comm[n_dense:].view(L, dim)
-        check(rt.lib.cham_rows_gather(ptr(table), ptr(ids), L, dim, ptr(rows), st), "cham_rows_gather")
-        dense16 = None
-        if self.comm_bf16 and n_dense:          # dense remainder in bf16 (its own collective), the touched rows fp32
-            dense16 = self._comm_buffer(flat_grads, n_dense)[:n_dense]
-            dense16.copy_(comm[:n_dense])
-            dist.all_reduce(dense16, op=dist.ReduceOp.SUM, group=self.pg)
-            comm[:n_dense].copy_(dense16)
-        if self.mode == "sparse_rs" and dist.get_backend(self.pg) != "gloo":      # (gloo has no reduce_scatter: the all-reduce below)
-            if dense16 is None:
-                dist.all_reduce(comm[:n_dense], op=dist.ReduceOp.SUM, group=self.pg)
-            # the row list padded to a multiple of the world size (pad rows: zeros, never written back)
+        self._rows_gather(table, ids, rows)
+        dense_done = False
+        if self.comm_bf16 and n_dense:          # dense remainder in bf16 (its own collective(s)), the touched rows fp32
+            self._reduce_range(comm, 0, n_dense)
+            dense_done = True
+        if self.mode == "sparse_rs":
+            if not dense_done and n_dense:
+                self._all_reduce(comm[:n_dense])
+            # C2: the row list padded to a multiple of the world size (pad rows: zeros, never written back);
+            # rank r receives the sums of rows [r * per, (r + 1) * per) - the rows it owns this step - and the summed chunks are
+            # all-gathered.  Runs on RCCL and on gloo alike (round 5 substituted an all-reduce on gloo: these lines had only ever
+            # executed with a world of one).
             per = -(-L // self.world)
-            if self._rs is None or self._rs[0].numel() < per * self.world * dim:
+            if self._rs is None or self._rs[0].numel() < per * self.world * dim or self._rs[0].device != comm.device:
                 self._rs = (torch.zeros(per * self.world * dim, dtype=comm.dtype, device=comm.device),
                             torch.empty(per * dim, dtype=comm.dtype, device=comm.device))
             packed, mine = self._rs[0][:per * self.world * dim], self._rs[1][:per * dim]
             packed[:L * dim].copy_(rows.view(-1))
             packed[L * dim:].zero_()
-            dist.reduce_scatter_tensor(mine, packed, op=dist.ReduceOp.SUM, group=self.pg)       # C2: this rank's rows, summed
-            dist.all_gather_into_tensor(packed, mine, group=self.pg)
+            self._reduce_scatter(mine, packed)       # C2: this rank's rows, summed
+            self._all_gather(packed, mine)
             rows.view(-1).copy_(packed[:L * dim])
-        elif dense16 is not None:
-            dist.all_reduce(comm[n_dense:], op=dist.ReduceOp.SUM, group=self.pg)
+        elif dense_done:
+            self._all_reduce(comm[n_dense:])
         else:
-            dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self.pg)
-        self.last_exchange_bytes = (2 if dense16 is not None else 4) * n_dense + 4 * L * dim + (self._early_bytes if early else 0)
+            self._all_reduce(comm)
+        self.last_exchange_bytes = (2 if dense_done else 4) * n_dense + 4 * L * dim + (self._early_bytes if early else 0)
         self.last_touched_rows = L
         o = 0
         for a, b in ranges:
             flat_grads[a:b].copy_(comm[o:o + b - a]); o += b - a
         # duplicate ids carry identical sums: concurrent writes of the same value
-        check(rt.lib.cham_rows_scatter(ptr(rows), ptr(ids), L, dim, ptr(table), st), "cham_rows_scatter")
+        self._rows_scatter(rows, ids, table)
 
     # ---- checkpoints: in the sharded mode a rank's Adam slots are only valid on its own slice
     def _gather_slots(self, m, v):
@@ -244,29 +318,19 @@ class DataParallelNAR:
         for x in (m, v):
             full = x.clone()
             if n > 0:
-                parts = [torch.empty(n, dtype=x.dtype, device=x.device) for _ in range(self.world)]
-                dist.all_gather(parts, x[a:a + n].clone(), group=self.pg)
-                for r, t in enumerate(parts):
-                    full[r * n:(r + 1) * n].copy_(t)
+                self._all_gather(full[:n * self.world], x[a:a + n].clone())
             out.append(full)
         return out[0], out[1]
 
     def _sharded_step(self, flat_grads, flat_params, adam):
+        """reduce-scatter of the flat gradients -> Adam on this rank's contiguous 1/world slice -> all-gather of the updated slices
+        (RCCL and gloo alike)."""
         n = flat_params.numel() // self.world
         a = self.rank * n
-        if dist.get_backend(self.pg) == "gloo":      # gloo has no reduce_scatter: same arithmetic through all_reduce (tests)
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
-            self._grad_slice.copy_(flat_grads[a:a + n])
-        else:
-            dist.reduce_scatter_tensor(self._grad_slice, flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+        self._reduce_scatter(self._grad_slice, flat_grads)
         adam(a, a + n, self._grad_slice, 0)
-        if dist.get_backend(self.pg) == "gloo":
-            parts = [torch.empty_like(self._grad_slice) for _ in range(self.world)]
-            dist.all_gather(parts, flat_params[a:a + n].clone(), group=self.pg)
-            for r, t in enumerate(parts):
-                flat_params[r * n:(r + 1) * n].copy_(t)
-        else:
-            dist.all_gather_into_tensor(flat_params, flat_params[a:a + n].clone(), group=self.pg)
+        self._all_gather(flat_params, flat_params[a:a + n].clone())
+        self.last_exchange_bytes = 4 * flat_grads.numel() + 4 * flat_params.numel()
 
     def upload(self, global_features, global_labels):
         n = np.asarray(global_features['item_clicked']).shape[0]
@@ -280,7 +344,7 @@ class DataParallelNAR:
         loss = self.model.total_loss.clone()
         if self.active:
             xe = loss[1:2].clone()
-            dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=self.pg)
+            self._all_reduce(xe)
             loss[1] = xe[0]
             loss[0] = xe[0] + loss[2]
         return loss

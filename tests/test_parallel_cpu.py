@@ -97,8 +97,14 @@ def test_two_rank_gradients_equal_full_batch(tmp_path):
     assert abs(got['loss'][1] - float(out['xe_loss'])) < 1e-5 and abs(got['loss'][0] - float(out['total_loss'])) < 1e-5
 
 
-# ---- optimizer-step exchange modes (allreduce | sharded): same parameters on every rank as the single-process step --
-_N_TOTAL, _N_EMB = 4096, 1500            # flat parameter count, embedding-table region [0, _N_EMB) (not a multiple of world*64)
+# ---- optimizer-step exchange modes: same parameters on every rank as the single-process step ---------------------------------------
+# ---- Every collective of nar/parallel.py runs here with world 2 AND 3 on gloo - all_reduce, and the reduce_scatter_tensor /
+# ---- all_gather_into_tensor pair of "sharded" and "sparse_rs" (SURVEY.md 8e C2).  The reference is single-worker (README.md:252): this
+# ---- test is the specification.  The touched-row list of the sparse modes has duplicates and a length that no world size divides (the
+# ---- zero-padded tail of the reduce-scatter); cham_rows_gather / cham_rows_scatter (HIP) are replaced by numpy stand-ins.
+_N_TOTAL, _N_EMB = 4098, 1500            # flat parameter count (2 * 3 * 683: splits over 2 and 3 ranks), item table [0, _N_EMB)
+_ITEM_DIM = 6                            # item table = [250, 6]
+_TOUCHED = np.asarray([0, 7, 7, 19, 3, 249, 100, 101, 7, 55, 200, 19, 0], np.int32)      # 13 entries: not a multiple of 2 or 3
 
 
 def _toy_adam(flat, m, lr=0.1):
@@ -109,76 +115,129 @@ def _toy_adam(flat, m, lr=0.1):
     return adam
 
 
-def _mode_worker(rank, world, port, out_dir, mode):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _toy_grads(step, rank):
+    """A rank's flat gradient: dense everywhere, the item table non-zero only in the touched rows (as the data gradient is)."""
+    g = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(100 + 10 * step + rank))
+    table = g[:_N_EMB].view(-1, _ITEM_DIM)
+    keep = torch.zeros(table.shape[0], dtype=torch.bool)
+    keep[torch.from_numpy(_TOUCHED).long()] = True
+    table[~keep] = 0.0
+    return g
+
+
+def _mode_worker(rank, world, port, out_dir, mode, grad_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CHAM_DP_GRAD_DTYPE=grad_dtype)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     g0 = torch.Generator().manual_seed(0)
 
     class _E:
-        def __init__(self, name, offset, size):
-            self.name, self.offset, self.size = name, offset, size
+        def __init__(self, name, offset, size, shape=None):
+            self.name, self.offset, self.size, self.shape = name, offset, size, shape or (size,)
 
     class _Layout:
         emb_end = _N_EMB
         # the session-FC / scorer kernels are contiguous (the early all-reduce bucket of parallel.DataParallelNAR)
-        entries = {n: _E(n, o, sz) for n, o, sz in (('emb', 0, _N_EMB), ('W2', _N_EMB, 500), ('Wf1', 2000, 300), ('Wf2', 2300, 200),
-                                                    ('Ws1', 2500, 100), ('Ws2', 2600, 60), ('Ws3', 2660, 40), ('Ws4', 2700, 20),
-                                                    ('b1', 2720, _N_TOTAL - 2720))}
+        entries = {e.name: e for e in (_E('items_embedding', 0, _N_EMB, (_N_EMB // _ITEM_DIM, _ITEM_DIM)), _E('W2', _N_EMB, 500),
+                                       _E('Wf1', 2000, 300), _E('Wf2', 2300, 200), _E('Ws1', 2500, 100), _E('Ws2', 2600, 60),
+                                       _E('Ws3', 2660, 40), _E('Ws4', 2700, 20), _E('b1', 2720, _N_TOTAL - 2720))}
 
     class _RT:
         flat = torch.randn(_N_TOTAL, generator=g0) if rank == 0 else torch.zeros(_N_TOTAL)     # broadcast must replicate rank 0
         layout = _Layout()
         dp_rank = dp_world = dp_allreduce = dp_sharded = dp_early_bucket = dp_gather_slots = None
+        dp_touched = torch.from_numpy(_TOUCHED)
 
     class _Model:
         rt = _RT()
     dp = parallel.DataParallelNAR(_Model(), mode=mode)
+    # numpy stand-ins for the two HIP row kernels (the product methods refuse CPU tensors)
+    with pytest.raises(RuntimeError, match="HIP kernel"):
+        dp._rows_gather(torch.zeros(4), torch.zeros(1, dtype=torch.int32), torch.zeros(1, 4))
+
+    def rows_gather(table, ids, rows):
+        rows.numpy()[...] = table.view(-1, rows.shape[1]).numpy()[ids.numpy()]
+
+    def rows_scatter(rows, ids, table):
+        table.view(-1, rows.shape[1]).numpy()[ids.numpy()] = rows.numpy()
+    dp._rows_gather, dp._rows_scatter = rows_gather, rows_scatter
     rt = _Model.rt
     m = torch.zeros(_N_TOTAL)
     adam = _toy_adam(rt.flat, m)
+    summed = []
     for step in range(3):
-        grads = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(100 + 10 * step + rank))
+        grads = _toy_grads(step, rank)
         if rt.dp_sharded is not None:
             rt.dp_sharded(grads, rt.flat, adam)
         else:
-            if mode == "allreduce":
-                assert rt.dp_early_bucket is not None and dp._early == (2000, 2720)
-                if step != 1:                                  # (step 1: no early issue - the whole buffer goes in one collective)
-                    rt.dp_early_bucket(grads)                  # what the backward pass does once [Wf1 .. Ws4] are final
+            assert rt.dp_early_bucket is not None and dp._early == (2000, 2720)
+            if step != 1:                                  # (step 1: no early issue - the whole buffer goes in one collective)
+                rt.dp_early_bucket(grads)                  # what the backward pass does once [Wf1 .. Ws4] are final
             rt.dp_allreduce(grads)
+            summed.append(grads.numpy().copy())
             adam(0, _N_TOTAL, grads, 0)
     m_full, _ = rt.dp_gather_slots(m, m.clone())               # checkpoint path: full Adam slots on every rank
-    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), flat=rt.flat.numpy(), m=m.numpy(), m_full=m_full.numpy())
+    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), flat=rt.flat.numpy(), m=m.numpy(), m_full=m_full.numpy(),
+             summed=np.asarray(summed), calls=np.asarray([dp.collective_calls[k] for k in ("all_reduce", "reduce_scatter", "all_gather")]),
+             nbytes=dp.last_exchange_bytes, comm_bf16=dp.comm_bf16)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
-def test_exchange_modes_match_single_process_step(tmp_path, mode):
-    world = 2
-    mp.spawn(_mode_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode,grad_dtype", [("allreduce", "f32"), ("sharded", "f32"), ("sparse", "f32"), ("sparse_rs", "f32"),
+                                             ("sparse", "bf16"), ("sparse_rs", "bf16")])
+def test_exchange_modes_match_single_process_step(tmp_path, mode, grad_dtype, world):
+    mp.spawn(_mode_worker, args=(world, _free_port(), str(tmp_path), mode, grad_dtype), nprocs=world, join=True)
+    got = [np.load(str(tmp_path / ("%s_rank%d.npz" % (mode, r)))) for r in range(world)]
     flat = torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(0))
     m = torch.zeros(_N_TOTAL)
     adam = _toy_adam(flat, m)
+    bf16 = grad_dtype == "bf16"
+    assert all(bool(g['comm_bf16']) == bf16 for g in got)
+    n_item = _N_EMB
     for step in range(3):
-        g = sum(torch.randn(_N_TOTAL, generator=torch.Generator().manual_seed(100 + 10 * step + r)) for r in range(world))
-        adam(0, _N_TOTAL, g, 0)
-    got = [np.load(str(tmp_path / ("%s_rank%d.npz" % (mode, r)))) for r in range(world)]
+        gs = [_toy_grads(step, r) for r in range(world)]
+        g = gs[0].clone()
+        for x in gs[1:]:          # rank order: what gloo's ring / RCCL need not follow - fp32 sums of 2-3 terms are compared with a tolerance
+            g = g + x
+        if bf16:                   # the dense part (everything but the item table) travels in bf16; the touched rows stay fp32
+            d = gs[0][n_item:].bfloat16()
+            for x in gs[1:]:
+                d = d + x[n_item:].bfloat16()
+            g[n_item:] = d.float()
+        if mode != "sharded":      # the summed gradient buffer every rank hands to Adam
+            for r in range(world):
+                tol = (2.0 ** -7 if bf16 else 1e-6) * float(g.abs().max())
+                assert np.abs(got[r]['summed'][step] - g.numpy()).max() <= tol, (mode, r, step)
+                assert np.array_equal(got[r]['summed'][step], got[0]['summed'][step]), (mode, r, step)        # identical on every rank, bit for bit
+        adam(0, _N_TOTAL, torch.from_numpy(got[0]['summed'][step]) if (bf16 and mode != "sharded") else g, 0)
     for r in range(world):
-        assert np.allclose(got[r]['flat'], flat.numpy(), atol=1e-6), (mode, r)      # every rank ends with the full updated parameters
+        assert np.allclose(got[r]['flat'], flat.numpy(), atol=2e-6), (mode, r)      # every rank ends with the full updated parameters
+        assert np.array_equal(got[r]['flat'], got[0]['flat']), (mode, r)            # ... the same bits on every rank
     for r in range(world):      # NARRuntime.state_dict(): the gathered slots are complete on every rank in every mode
-        assert np.allclose(got[r]['m_full'], m.numpy(), atol=1e-6), (mode, r)
+        assert np.allclose(got[r]['m_full'], m.numpy(), atol=2e-6), (mode, r)
     owned = np.zeros(_N_TOTAL)
     for r in range(world):
-        owned += (got[r]['m'] != 0)
-        assert np.allclose(got[r]['m'][got[r]['m'] != 0], m.numpy()[got[r]['m'] != 0], atol=1e-6)
-    if mode == "allreduce":
-        assert (owned == world).all()
-    elif mode == "sharded":
-        assert (owned == 1).all()                                                   # every optimizer slot lives on exactly one rank
+        nz = got[r]['m'] != 0
+        owned += nz
+        assert np.allclose(got[r]['m'][nz], m.numpy()[nz], atol=2e-6)
+    touched = m.numpy() != 0
+    if mode == "sharded":
+        assert (owned[touched] == 1).all()                                          # every optimizer slot lives on exactly one rank
     else:
-        E = (_N_EMB // (world * 64)) * (world * 64)
-        assert (owned[:E] == 1).all() and (owned[E:] == world).all()                # tables sharded, dense replicated
+        assert (owned[touched] == world).all()
+    # the branch that ran: (all_reduce, reduce_scatter, all_gather) calls over the three steps (+ the gather of the checkpoint path)
+    calls = {k: int(v) for k, v in zip(("all_reduce", "reduce_scatter", "all_gather"), got[0]['calls'])}
+    if mode == "sharded":
+        assert calls == {"all_reduce": 0, "reduce_scatter": 3, "all_gather": 3 + 2}, calls
+    elif mode == "sparse_rs":
+        assert calls["reduce_scatter"] == 3 and calls["all_gather"] == 3 and calls["all_reduce"] >= 3, calls
+    else:
+        assert calls["reduce_scatter"] == 0 and calls["all_gather"] == 0 and calls["all_reduce"] >= 3, calls
+    if mode in ("sparse", "sparse_rs"):      # bytes of the last step (early bucket issued): dense remainder + touched rows, never the whole table
+        L, early = len(_TOUCHED), 2720 - 2000
+        n_dense = _N_TOTAL - _N_EMB - early
+        assert int(got[0]['nbytes']) == (2 if bf16 else 4) * (n_dense + early) + 4 * L * _ITEM_DIM
 
 
 # ---- the checkpoint decision under data parallelism (estimator._checkpoint_due): rank 0's wall clock, broadcast on the data-parallel
