@@ -130,6 +130,9 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    # library-wide kernel switches, set ONCE per process at load (not per runtime: a second NARRuntime must not flip the kernels of the
+    # first - ADVICE r05).  CHAM_H2_NT_WIDE=0: the 32-byte-piece NT kernels of round 4 (bit-identical results; A/B arm)
+    lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
     _lib = lib
     return lib
 

@@ -27,13 +27,35 @@ def enabled():
     return _lib is not None
 
 
+_depth = 0          # ranges this module has open (single host thread drives a step)
+
+
 def push(name):
     """Opens a nested range; returns its depth (>= 0) or -1 when tracing is off."""
-    return _lib.roctxRangePushA(name.encode()) if _lib is not None else -1
+    global _depth
+    if _lib is None:
+        return -1
+    _depth += 1
+    return _lib.roctxRangePushA(name.encode())
 
 
 def pop():
-    return _lib.roctxRangePop() if _lib is not None else -1
+    global _depth
+    if _lib is None or _depth == 0:
+        return -1
+    _depth -= 1
+    return _lib.roctxRangePop()
+
+
+def depth():
+    return _depth
+
+
+def unwind(to_depth):
+    """Closes every range opened since depth() returned `to_depth` - the `finally` of a function that pushes / pops stage ranges across many
+    calls that may raise (NARModuleModel.forward: an error mid-step must not leave the range stack unbalanced for the rest of the process)."""
+    while _depth > to_depth and _lib is not None:
+        pop()
 
 
 class range_:
@@ -44,10 +66,8 @@ class range_:
         self.name = name
 
     def __enter__(self):
-        if _lib is not None:
-            _lib.roctxRangePushA(self.name.encode())
+        push(self.name)
 
     def __exit__(self, *a):
-        if _lib is not None:
-            _lib.roctxRangePop()
+        pop()
         return False

@@ -4,7 +4,8 @@ import os
 from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_uint32, c_uint64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchameleon_tfrecord.so")
+# CHAM_TFRECORD_LIB: another build of the same codec (the ASAN / UBSAN one of build.build_host(sanitize=True), tests only)
+LIB_PATH = os.environ.get("CHAM_TFRECORD_LIB") or os.path.join(_HERE, "libchameleon_tfrecord.so")
 
 DT_INT64, DT_FLOAT, DT_BYTES = 0, 1, 2
 OK, EOF = 0, 1

@@ -31,19 +31,36 @@ def _stamp(files=None, flags=FLAGS):
     return h.hexdigest()
 
 
-def build_host(force=False, verbose=True):
-    """libchameleon_tfrecord.so: the host-side session TFRecord codec (plain C++17 + zlib, g++)."""
-    stamp_file = HOST_LIB + ".stamp"
-    stamp = _stamp(HOST_SOURCES, HOST_FLAGS)
-    if not force and os.path.exists(HOST_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return HOST_LIB
-    cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + HOST_SOURCES + ["-o", HOST_LIB, "-lz"]
+HOST_LIB_SANITIZED = os.path.join(HERE, "libchameleon_tfrecord_san.so")
+SANITIZE_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def build_host(force=False, verbose=True, sanitize=False):
+    """libchameleon_tfrecord.so: the host-side session TFRecord codec (plain C++17 + zlib, g++).
+    sanitize=True: the same sources as libchameleon_tfrecord_san.so under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only; test
+    infrastructure - tests/test_tfrecord_fuzz.py loads it through CHAM_TFRECORD_LIB in a child process with libasan preloaded)."""
+    lib = HOST_LIB_SANITIZED if sanitize else HOST_LIB
+    flags = [f for f in HOST_FLAGS if f != "-O2"] + SANITIZE_FLAGS if sanitize else HOST_FLAGS
+    stamp_file = lib + ".stamp"
+    stamp = _stamp(HOST_SOURCES, flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return lib
+    cmd = [os.environ.get("CXX", "g++")] + flags + HOST_SOURCES + ["-o", lib, "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(stamp_file, "w") as fh:
         fh.write(stamp)
-    return HOST_LIB
+    return lib
+
+
+def sanitizer_runtime():
+    """Path of libasan.so for LD_PRELOAD (python itself is not instrumented), or None."""
+    try:
+        out = subprocess.check_output([os.environ.get("CXX", "g++"), "-print-file-name=libasan.so"]).decode().strip()
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return os.path.realpath(out) if os.path.sep in out and os.path.exists(out) else None
 
 
 def _src_stamp(src):

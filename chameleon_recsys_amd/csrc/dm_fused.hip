@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
     // zeros / drop their stores without a branch - a branch around a load makes hipcc wait for each load in turn, 16 dependent HBM round
     // trips per column tile in the first version of this epilogue: 1.25 ms for the kernel, profiles/r03_notes.md)
     bf16x8 AH[8], AM[(B16 || F16P) ? 1 : 8], AL[B16 ? 1 : 8];          // (F16P: fp16 bit patterns in the same 16-bit containers)
-    float ginv = 1.f;
+    float ginv_a = 1.f, ginv_w = 1.f;      // the two inverse power-of-two scales, applied ONE AFTER THE OTHER: their product can leave the fp32 normal range (each exponent is clamped to +-110)
     if constexpr (B16) {
         const __bf16* a16 = reinterpret_cast<const __bf16*>(p.dS1);
         const __amdgpu_buffer_rsrc_t aw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a16 + row0 * (size_t)p.lds1), 0,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
         ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + ((H2 && q == 2) || B16 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
     float osc = 1.f;
     if constexpr (H2) osc = p.osc->scale;
-    if constexpr (F16P) ginv = p.sa->inv * p.sw->inv;
+    if constexpr (F16P) { ginv_a = p.sa->inv; ginv_w = p.sw->inv; }
 
     // ---- B: LDS-DMA of Ws1's planes.  Half-stage image per plane: [slot 0..127][64 k] (128 B per slot), slot = j * 32 + n holds Ws1 row
     // n0 + 4 n + j; the eight 16-byte pieces of a slot are XOR-ed with (slot >> 1) & 7 (conflict-free ds_read_b128 fragments).  One
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                 const bool second = rr >= bnd;
                 const float2 pr = second ? prb : pra;
                 float2 g = make_float2(acc[0][e], acc[1][e]);      // (zero on rows beyond the valid ones: their dS1 rows read as zeros)
-                if constexpr (F16P) { g.x *= ginv; g.y *= ginv; }  // back to true units (a power of two)
+                if constexpr (F16P) { g.x = (g.x * ginv_a) * ginv_w; g.y = (g.y * ginv_a) * ginv_w; }  // back to true units (powers of two)
                 if constexpr (B16) { g.x = (float)(__bf16)g.x; g.y = (float)(__bf16)g.y; }      // dM as the unfused pair stores it
                 float2 o;
                 o.x = g.x * pr.x * (1.f - z.x * z.x); o.y = g.y * pr.y * (1.f - z.y * z.y);

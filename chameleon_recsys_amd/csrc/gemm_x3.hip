@@ -275,8 +275,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsw = make_window(p.rs);
 
     LA la; LB lb;
-    float sa_inv = 1.f, sa = 1.f, sb = 1.f;
-    if constexpr (NP == 2) { sa = p.sa[0]; sb = p.sb[0]; sa_inv = p.sa[1] * p.sb[1]; }
+    float sa_inv = 1.f, sb_inv = 1.f, sa = 1.f, sb = 1.f;      // (the inverse scales are applied one after the other: their product can be denormal - ADVICE r05)
+    if constexpr (NP == 2) { sa = p.sa[0]; sb = p.sb[0]; sa_inv = p.sa[1]; sb_inv = p.sb[1]; }
     la.init(p.lda, p.M - m0, m0, p.ldrs, p.rs_div, RS, sa);
     lb.init(p.ldb, p.N - n0, n0, 0, 1, false, sb);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] *= sa_inv;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * sa_inv) * sb_inv;
     }
     gemm_epilogue<EPI, TM, TN>(p, acc, m0, n0, wm0, wn0, split, kl, fl);
 }

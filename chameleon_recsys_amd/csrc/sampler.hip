@@ -220,20 +220,12 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
     hipLaunchKernelGGL(k_rank_place, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, cat_vals, rank, ncat, pmax, pool, meta + 3,
                        sel + 4);
     {
-        static bool canon_attr = false;
-        if (!canon_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_canon), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            canon_attr = true;
-        }
+        CHAM_SET_DYNAMIC_LDS(k_canon, 150 * 1024);          // per DEVICE, not per process
         hipLaunchKernelGGL(k_canon, dim3((pmax + 255) / 256), dim3(256), (size_t)pmax * 8, st, pool, meta + 3, pmax, canon);
     }
     if (row_count > 0) {
         const size_t smem = (size_t)pp * 8 + (size_t)T1 * 8;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_click_select), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_done = true;
-        }
+        CHAM_SET_DYNAMIC_LDS(k_click_select, 150 * 1024);
         hipLaunchKernelGGL(k_click_select, dim3(T1 - 1, row_count), dim3(256), smem, st, aci, T1, row_begin, pool, canon,
                            meta + 3, pmax, pp, N, seed, step, neg_ids, neg_slot);
     }

@@ -155,18 +155,20 @@ class Estimator:
     _HEALTH_MSG = ("a cooperative recurrent kernel (csrc/rnn_coop.hip) gave up a bounded spin%s: the hidden states of at least one "
                    "step are invalid.  Is another process running cooperative kernels on this GPU?")
 
-    def _check_device_health(self):
+    def _check_device_health(self, collective=True):
         """The cooperative recurrent kernels (csrc/rnn_coop.hip) hand h_t from workgroup to workgroup with BOUNDED spins; a spin that gave
         up (a cooperating workgroup never became resident - e.g. several processes' cooperative kernels competing for one GPU) leaves a
         sticky word in their workspace and wrong hidden states behind.  Checked where the loop synchronises anyway (checkpoints, the end of
         train / evaluate, and the data-parallel checkpoint poll): fail loudly rather than train on.  The word is PER PROCESS: under data
         parallelism the flags are MAX-reduced over the data-parallel group first, so that every rank raises together - one rank raising
         alone would leave the others waiting in the next collective (state_dict() all-gathers the Adam slots in the sharded mode).
-        Every rank reaches this at the same steps (save_checkpoint is entered on rank 0's broadcast decision)."""
+        Every rank reaches the collective form at the same steps (save_checkpoint is entered on rank 0's broadcast decision; the end of
+        train()).  evaluate() passes collective=False: nothing makes every rank evaluate (chief-only or uneven evaluation is legal - the
+        evaluation forward issues no collective), so there the check is on the local word only."""
         bad = self._coop_timed_out_local()
         rt = self._store.get('runtime')
         where = ""
-        if rt is not None and getattr(rt, 'dp_active', False):
+        if collective and rt is not None and getattr(rt, 'dp_active', False):
             import torch.distributed as dist
             if dist.is_initialized():
                 pg = getattr(rt, 'dp_pg', None)
@@ -277,7 +279,9 @@ class Estimator:
                 self.steps_per_sec = n / dt
                 print("INFO:global_step/sec: %.4g (step %d)" % (n / dt, self.global_step), flush=True)
                 last_log = n
-            if self.config.save_checkpoints_secs and self._checkpoint_due():
+            # (called every step whatever save_checkpoints_secs says: under data parallelism it is also the cross-rank poll of the
+            # kernel time-out word, every CKPT_DECISION_EVERY steps - ADVICE r05; without a data-parallel group it reads the clock)
+            if self._checkpoint_due():
                 self.save_checkpoint()
         torch.cuda.synchronize()
         if n:
@@ -308,7 +312,7 @@ class Estimator:
         for h in all_hooks:
             h.end(None)
         ds.close()
-        self._check_device_health()
+        self._check_device_health(collective=False)
         out = {k: (v.result() if hasattr(v, 'result') else v) for k, v in spec.eval_metric_ops.items()}
         out['loss'] = loss_sum / max(1, n)
         out['global_step'] = self.global_step

@@ -200,8 +200,8 @@ class NARRuntime:
         # what moves them; same float64-error bar as the six-product form (tests/test_gemm_h2_gpu.py).  CHAM_GEMM_H2=0: the three-bf16-plane arm
         self.h2 = self.p3 and os.environ.get("CHAM_GEMM_H2", "1") == "1"
         # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
-        # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A library-wide setting.
-        self.lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
+        # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A LIBRARY-wide setting, made once per
+        # process when the library is loaded (chameleon_recsys_amd/_lib.py): constructing a second runtime never flips the kernels of the first
         # the scorer's first layer on two fp16 planes split while staged (round 5) - THREE plane products instead of six for the 3 x 65 GFLOP that were
         # left on six-product kernels: its weight gradient (csrc/gemm_x3.hip NP = 2, cham_gemm_f32x2h; |cand (.) pred| <= 1: a constant scale record,
         # dS1 by its max row norm) and the products inside its fused dgrad (csrc/dm_fused.hip MODE 3, cham_dm_mulpred_h2h; Ws1's planes by its max
@@ -1037,6 +1037,13 @@ class NARModuleModel:
 
     # ------------------------------------------------------------------ forward
     def forward(self, d, step=None):
+        depth = _roctx.depth()
+        try:
+            return self._forward(d, step)
+        finally:
+            _roctx.unwind(depth)          # (an error raised mid-step leaves no stage range open - ADVICE r05)
+
+    def _forward(self, d, step):
         rt, lib, L = self.rt, self.rt.lib, self.rt.layout
         st = self._dev_state
         if st is None:

@@ -282,12 +282,14 @@ def _health_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from chameleon_recsys_amd.nar.estimator import Estimator, RunConfig
-    est = Estimator(model_fn=None, config=RunConfig(save_checkpoints_secs=1000))
+    est = Estimator(model_fn=None, config=RunConfig(save_checkpoints_secs=None))      # (the poll does not depend on checkpointing being on)
     pg = dist.new_group(list(range(world)))
     bad = {"now": False}
     est._store['runtime'] = types.SimpleNamespace(dp_active=True, dp_pg=pg, device="cpu", _rnn_coop_ws={64: None},
                                                   rnn_coop_timed_out=lambda: bad["now"])
     res = []
+    if rank == 0:            # evaluate()'s form: local word only, no collective - a rank may evaluate alone; would hang otherwise
+        est._check_device_health(collective=False)
     est._check_device_health(); res.append("ok")                          # nobody timed out: no rank raises
     bad["now"] = rank == 1                                                # rank 1's kernels gave up a spin
     try:
