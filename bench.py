@@ -401,6 +401,44 @@ def hitrate_parity(seed):
                         "weights / inputs / negatives on both sides; cpu_oracle_on_hip_weights = the oracle evaluating the HIP-trained weights"}
 
 
+XGMI_LINKS, XGMI_LINK_GBPS = 7, 153.0          # MI355X: 7 point-to-point links x ~153 GB/s per GPU (MI355X_MICROARCH.md)
+
+
+def dp_exchange_report(dp, one_step, first_step, backend, n=5):
+    """The "dp" object of an N > 1 line: proof of what the process group is - backend, world, the PCI bus id and name of
+    every rank's device (all-gathered) - and what one step's gradient exchange moved and cost: payload bytes handed to the collectives, the
+    ring-equivalent bus bytes (all-reduce: 2 (N - 1) / N x payload), HIP-event time around the synchronous part of the exchange over `n`
+    extra steps (max over ranks of the per-rank mean; the early bucket's overlapped flight is not in it), and that as a fraction of the
+    7 x 153 GB/s of xGMI a GPU has.  Collective: every rank calls it."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = "%04x:%02x:%02x %s" % (getattr(prop, 'pci_domain_id', 0), getattr(prop, 'pci_bus_id', 0), getattr(prop, 'pci_device_id', 0), prop.name)
+    devices = [None] * world
+    dist.all_gather_object(devices, ident)
+    dp.time_exchange = True
+    for i in range(n):
+        one_step(first_step + i)
+    ms = dp.exchange_ms()
+    dp.time_exchange = False
+    mean_ms = sum(ms) / max(1, len(ms))
+    t = torch.tensor([mean_ms], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mean_ms = float(t.item())
+    payload = int(dp.last_exchange_bytes)
+    bus = payload * 2.0 * (world - 1) / world
+    return {"backend": "rccl" if backend == "nccl" else backend, "world": world, "devices": devices,
+            "distinct_devices": len(set(devices)), "mode": dp.mode, "grad_dtype": "bf16" if dp.comm_bf16 else "f32",
+            "early_bucket": dp._early is not None, "collective_calls_total": dict(dp.collective_calls),
+            "exchange_bytes_per_step": payload, "ring_bus_bytes_per_step": int(bus), "exchange_ms": round(mean_ms, 4), "exchange_steps_timed": len(ms),
+            "exchange_GBps": round(bus / (mean_ms * 1e-3) / 1e9, 2) if mean_ms > 0 else None,
+            "frac_of_xgmi": round(bus / (mean_ms * 1e-3) / 1e9 / (XGMI_LINKS * XGMI_LINK_GBPS), 4) if mean_ms > 0 else None,
+            "xgmi_peak_GBps": XGMI_LINKS * XGMI_LINK_GBPS,
+            "note": "exchange_ms = HIP events on the step's stream around the synchronous collectives (max over ranks of the mean); "
+                    "the early bucket [Wf1 .. Ws4] flies under the backward and only its wait is inside"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -692,6 +730,9 @@ def main():
         native_arm = {"gemm": "every GEMM on v_mfma_f32_32x32x2_f32 (--dtype f32_native), same runtime / weights / batches", "steps": n_arm,
                       "value": round(Bg * n_arm / adt, 2), "unit": "sessions/s", "ms_per_step": round(adt / n_arm * 1e3, 3)}
 
+    # ---- N > 1: what the exchange is and what it cost (every rank takes part: collectives - never under `if rank == 0`)
+    dp_info = dp_exchange_report(dp, one_step, args.warmup + args.steps + 200, backend) if world > 1 else None
+
     if rank == 0:
         L = rt.layout
         T = cfg['seq_len'] - 1
@@ -748,6 +789,8 @@ def main():
             else:
                 out["roofline"].update(bound="mfma", peak=BF16_MATRIX_PEAK_TFLOPS, frac=round(achieved / BF16_MATRIX_PEAK_TFLOPS, 4))
             out["roofline"].update(traffic=None, traffic_source=None)
+        if dp_info is not None:
+            out["dp"] = dp_info
         if ragged is not None:
             out["g1_like_session_lengths"] = ragged
         if native_arm is not None:

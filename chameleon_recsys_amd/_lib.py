@@ -55,6 +55,11 @@ _SIGNATURES = {
     "cham_split2h": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P, c_int, P]),
     "cham_gemm_h2": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
                              P, c_size_t, c_int, P]),
+    "cham_h2b_block_elements": (c_int, []),
+    "cham_gemm_h2b": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int,
+                              P, c_size_t, c_int, c_int, c_int, c_int, P]),
+    "cham_combine_fwd_h2b": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, c_int, P]),
+    "cham_dm_mulpred_h2_blk": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P]),
     "cham_gemm_h2_launch_counts": (None, [P, c_int]),
     "cham_gemm_h2_set_nt_wide": (c_int, [c_int]),
     "cham_combine_fwd_h2": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P, P]),

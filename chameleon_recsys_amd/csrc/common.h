@@ -151,6 +151,23 @@ __device__ __forceinline__ unsigned short h2_keep_sign(_Float16 h, float x) {
     const unsigned short b = __builtin_bit_cast(unsigned short, h);
     return (x > 0.f && b == 0) ? (unsigned short)1 : b;
 }
+// ---- TILE-BLOCKED plane layout (round 6; csrc/gemm_h2.hip "blocked operands"): a [rows, ld] matrix of 16-bit elements stored as
+//   [row tiles of 256][column blocks of 32][256 rows][32 columns]
+// i.e. a (256-row x 32-column) block is 16 KB contiguous, a row's 32 columns 64 bytes, 16 consecutive rows of a block 1 KB.  What the NT
+// plane GEMMs stage per request (16 rows x 32 k) is then 1 KB of whole 128-byte lines instead of sixteen half lines; the TN form's
+// request (2 k-rows x 256 m) is eight whole lines as before; the 16-byte pieces both kernels move are the same element sets, so their LDS
+// images, products and results are bit-identical to the row-major operands'.  ld % 32 == 0; the rows of the last tile beyond the
+// matrix are allocated and ZERO (the TN form contracts over rows).
+#define H2B_ROWS 256
+#define H2B_COLS 32
+#ifndef H2B_PAD
+#define H2B_PAD 0                                /* elements of padding behind each block (% 8 == 0): see profiles/r06_notes.md */
+#endif
+#define H2B_BLOCK (H2B_ROWS * H2B_COLS + H2B_PAD) /* elements from one block to the next */
+__host__ __device__ __forceinline__ size_t h2b_index(size_t row, unsigned col, unsigned col_blocks) {
+    return ((row >> 8) * col_blocks + (col >> 5)) * (size_t)H2B_BLOCK + (row & 255u) * H2B_COLS + (col & 31u);
+}
+
 // 4 consecutive elements of a row -> the two planes (planes `ps` elements apart): 8-byte stores
 __device__ __forceinline__ void st4_planes_h2(_Float16* p, long long ps, const float4& v, float s) {
     typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));

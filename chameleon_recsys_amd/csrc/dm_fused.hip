@@ -41,6 +41,7 @@ struct DmfParams {
     const H2Scale* sa; const H2Scale* sw;       // MODE 3: the scales of dS1 and of Ws1's two fp16 planes
     float* dpred; float* b2part;                // [BT, C]
     int C, BT, NC, PW;
+    int out_blocked;                            // H2: the planes of dZ2 are written tile-blocked (common.h h2b_index)
 };
 
 __device__ __forceinline__ void dmf_dma_one(unsigned lds, unsigned voff, const u32x4& r) {
@@ -124,6 +125,16 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)        // (H2: two planes of 16-bit elements, B16: one - the other descriptors are never used)
         ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + ((H2 && q == 2) || B16 ? 0 : q) * p.out_ps + row0 * (size_t)C, 0, (unsigned)((size_t)rows_valid * C * 2), 0x00020000);
+    // tile-blocked output (H2 only): the workgroup's <= 256 rows start `rin` rows into row tile row0 / 256 and reach at most into the next
+    // one; the windows start at that tile and span two (the allocation's last tile is followed by at least the other plane or the pad the
+    // caller allocates); rows beyond the valid ones get an out-of-range offset (their stores are dropped)
+    const bool oblk = H2 && p.out_blocked != 0;
+    const unsigned rin = (unsigned)(row0 & 255), tile_bytes = ((unsigned)C >> 5) * (unsigned)(H2B_BLOCK * 2);
+    if (oblk) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            ow[q] = __builtin_amdgcn_make_buffer_rsrc(p.out + q * p.out_ps + (row0 >> 8) * (size_t)((unsigned)C >> 5) * H2B_BLOCK, 0, 2u * tile_bytes, 0x00020000);
+    }
     float osc = 1.f;
     if constexpr (H2) osc = p.osc->scale;
     if constexpr (F16P) { ginv_a = p.sa->inv; ginv_w = p.sw->inv; }
@@ -274,7 +285,12 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
                     split2h(o.x * osc, h0, l0); split2h(o.y * osc, h1, l1);
                     const unsigned ph = (unsigned)h2_keep_sign(h0, o.x) | ((unsigned)h2_keep_sign(h1, o.y) << 16);
                     const unsigned pl = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-                    const unsigned oo = (r * (unsigned)C + (unsigned)col) * 2u;
+                    unsigned oo = (r * (unsigned)C + (unsigned)col) * 2u;
+                    if (oblk) {
+                        const unsigned lr = rin + r;              // row counted from the first row of the window's first tile
+                        oo = (int)r < rows_valid ? (lr >> 8) * tile_bytes + ((unsigned)col >> 5) * (unsigned)(H2B_BLOCK * 2) + (lr & 255u) * 64u + ((unsigned)col & 31u) * 2u
+                                                 : 0x80000000u;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(ph, ow[0], oo, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(pl, ow[1], oo, 0, 0);
                 } else {
@@ -341,15 +357,18 @@ __global__ __launch_bounds__(512) void k_dm_mulpred_fused(DmfParams p) {
 template <int MODE>
 static int dm_mulpred_launch(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const float* Z2c,
                              const float* pred, int C, int BT, int N, void* dZ2p, long long out_plane_stride, const void* out_scale_rec,
-                             float* dpred_pre, float* col_part, void* stream, const void* a_scale_rec = nullptr, const void* w_scale_rec = nullptr) {
+                             float* dpred_pre, float* col_part, void* stream, const void* a_scale_rec = nullptr, const void* w_scale_rec = nullptr,
+                             int out_blocked = 0) {
     if (!dS1 || !Wp || !Z2c || !pred || !dZ2p || !dpred_pre || BT < 0 || N < 0 || ((MODE == 1 || MODE == 3) && !out_scale_rec)) return -CHAM_ERR_ARG;
     if (MODE == 3 && (!a_scale_rec || !w_scale_rec || (((uintptr_t)a_scale_rec | (uintptr_t)w_scale_rec) & 3))) return -CHAM_ERR_ARG;
     const int NC = N + 1;
     if (K != 128 || (C % DMF_COLS) || C <= 0 || NC < 32 || NC > 256 || (lds1 & 3) || lds1 < K || (out_plane_stride & 3) || (w_plane_stride & 7))
         return -CHAM_ERR_ARG;
     if (((uintptr_t)dS1 | (uintptr_t)Wp | (uintptr_t)Z2c | (uintptr_t)pred | (uintptr_t)dZ2p) & 15) return -CHAM_ERR_ARG;
+    if (out_blocked && ((MODE != 1 && MODE != 3) || (C & 31) || out_plane_stride < (long long)(((size_t)BT * NC + 255) / 256) * (C >> 5) * H2B_BLOCK)) return -CHAM_ERR_ARG;
     if (BT == 0) return CHAM_OK;
     DmfParams p;
+    p.out_blocked = out_blocked ? 1 : 0;
     p.dS1 = dS1; p.lds1 = lds1; p.W = reinterpret_cast<const __bf16*>(Wp); p.w_ps = w_plane_stride; p.Z2c = Z2c; p.pred = pred;
     p.out = reinterpret_cast<__bf16*>(dZ2p); p.out_ps = out_plane_stride; p.osc = reinterpret_cast<const H2Scale*>(out_scale_rec);
     p.sa = reinterpret_cast<const H2Scale*>(a_scale_rec); p.sw = reinterpret_cast<const H2Scale*>(w_scale_rec);
@@ -384,6 +403,21 @@ extern "C" int cham_dm_mulpred_h2h(const float* dS1, int lds1, int K, const void
                                    long long out_plane_stride, const void* out_scale_rec, float* dpred_pre, float* col_part, void* stream) {
     return dm_mulpred_launch<3>(dS1, lds1, K, Wh, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream,
                                 ds1_scale_rec, w_scale_rec);
+}
+
+// the two H2 forms with the planes of dZ2 written TILE-BLOCKED (common.h h2b_index; round 6): ds1_scale_rec / w_scale_rec NULL = cham_dm_mulpred_h2's
+// arithmetic (six bf16 products inside, Wp = three bf16 planes), both given = cham_dm_mulpred_h2h's.  The caller allocates
+// ceil(BT (1 + N) / 256) row tiles per plane (+ the planes follow each other or a pad of one tile: a workgroup's window spans two tiles),
+// zero-initialised; rows beyond BT (1 + N) are never written.
+extern "C" int cham_dm_mulpred_h2_blk(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const void* ds1_scale_rec,
+                                      const void* w_scale_rec, const float* Z2c, const float* pred, int C, int BT, int N, void* dZ2p,
+                                      long long out_plane_stride, const void* out_scale_rec, float* dpred_pre, float* col_part, void* stream) {
+    if ((ds1_scale_rec == nullptr) != (w_scale_rec == nullptr)) return -CHAM_ERR_ARG;
+    if (ds1_scale_rec)
+        return dm_mulpred_launch<3>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream,
+                                    ds1_scale_rec, w_scale_rec, 1);
+    return dm_mulpred_launch<1>(dS1, lds1, K, Wp, w_plane_stride, Z2c, pred, C, BT, N, dZ2p, out_plane_stride, out_scale_rec, dpred_pre, col_part, stream,
+                                nullptr, nullptr, 1);
 }
 
 // The bf16 configuration's twin (BASELINE configs[2]): dS1 [BT*(1+N), K = 128] bf16 (row stride lds1 elements), Ws1b = the bf16 shadow of Ws1

@@ -46,6 +46,9 @@ struct H2Params {
     const unsigned short* dref; int ldr;       // h plane of the saved activation (dgrad)
     int kchunk, splits; float* partial;
     int nbm, nbn, xcd_split, accumulate;
+    // TILE-BLOCKED operands (common.h h2b_index; round 6): *_tiles > 0 = the operand's planes are stored [row tiles][ld / 32][256][32] with
+    // that many row tiles ALLOCATED (rows beyond the matrix: zeros); 0 = row-major.  NT: A only (B = the weight planes); TN: A and / or B.
+    int a_tiles, b_tiles, r_blk;               // r_blk: the dgrad's saved-activation h plane (dref) is tile-blocked
 };
 
 #define H2_SLAB 8192
@@ -79,14 +82,15 @@ __device__ __forceinline__ void h2_dma_stage(unsigned lds0, unsigned va, unsigne
         : "memory");
 }
 
+// (TN: `hi` = byte distance of k-row + 4 in the slab image: 4 * 512 for a row-major operand's image, 4 * 64 for a tile-blocked one's)
 template <bool TN>
-__device__ __forceinline__ half8 h2_frag(const unsigned char* __restrict__ s) {
+__device__ __forceinline__ half8 h2_frag(const unsigned char* __restrict__ s, unsigned hi_off = 4 * 512) {
     if constexpr (!TN) {
         return *reinterpret_cast<const half8*>(s);
     } else {
         typedef __attribute__((address_space(3))) h2_s16x4 lds_s4;
         const h2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(s));
-        const h2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(s + 4 * 512));
+        const h2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(s + hi_off));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -123,7 +127,12 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
         // (positive and non-zero <=> > 0; split2h keeps the sign of a value that underflows)
         const int limM = p.M - m0, limN = p.N - n0;
         const __amdgpu_buffer_rsrc_t cw = make_window(p.C + (size_t)m0 * p.ldc + n0);
-        const __amdgpu_buffer_rsrc_t dw = make_window(p.dref + (size_t)m0 * p.ldr + n0);
+        // saved activation: row-major [M, ldr], or tile-blocked (m0 is a multiple of 256: this tile's rows are ONE row tile; the window
+        // starts at its column block n0 / 32; element (row, column block cb, column c) sits at cb * 16 KB + row * 64 + c * 2)
+        const bool rb = p.r_blk != 0;
+        const __amdgpu_buffer_rsrc_t dw = make_window(rb ? p.dref + ((size_t)(m0 >> 8) * (size_t)(p.ldr >> 5) + (size_t)(n0 >> 5)) * H2B_BLOCK
+                                                         : p.dref + (size_t)m0 * p.ldr + n0);
+        const int rstride = rb ? 64 : p.ldr * 2;              // bytes from a row to the next inside the window
         if (limM >= wm0 + TM * 32 && limN >= wn0 + TNN * 32) {
             // interior wave tile (wave-uniform test; round 5): the row part of an element's address is uniform - c(e) * ld with
             // c(e) = (e & 3) + 8 (e >> 2) - and rides in the SGPR soffset of the buffer instructions, one VGPR offset per 32x32 block
@@ -134,12 +143,14 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
 #pragma unroll
                 for (int j = 0; j < TNN; ++j) {
                     const unsigned col = (unsigned)(wn0 + j * 32 + fl), rowb = (unsigned)(wm0 + i * 32 + 4 * kl);
-                    const unsigned voff = (rowb * (unsigned)p.ldc + col) * 4u, voffr = (rowb * (unsigned)p.ldr + col) * 2u;
+                    const unsigned voff = (rowb * (unsigned)p.ldc + col) * 4u;
+                    const unsigned voffr = rb ? (unsigned)((wn0 >> 5) + j) * (unsigned)(H2B_BLOCK * 2) + rowb * 64u + (unsigned)fl * 2u
+                                              : (rowb * (unsigned)p.ldr + col) * 2u;
                     unsigned short y[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ce = (e & 3) + 8 * (e >> 2);
-                        y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, voffr, ce * p.ldr * 2, 0);
+                        y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, voffr, ce * rstride, 0);
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -163,7 +174,9 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
                     const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
                     const bool ok = cok && row < limM;
                     offs[e] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
-                    y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u : OOB_OFF, 0, 0);
+                    const unsigned ro = rb ? (unsigned)((wn0 >> 5) + j) * (unsigned)(H2B_BLOCK * 2) + (unsigned)row * 64u + (unsigned)fl * 2u
+                                           : ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u;
+                    y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ro : OOB_OFF, 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -214,6 +227,8 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
     // ---- descriptors (one per plane: rows / k-rows beyond the operand arrive as zeros) and per-lane source offsets
     u32x4 ra[2], rb[2];
     unsigned va, vb, stepa, stepb;
+    unsigned tba = 0, tbb = 0;                 // TN, tile-blocked operand: bytes of a row tile (0: row-major)
+    int klim = 0;                              // TN, blocked operands: k-rows of this split from this lane's k-row on (see chunk_a)
     if constexpr (!TN) {
         // (the window starts kbeg elements into the first row: it ends that much earlier, so that requests past the reduction range
         // - issued, never consumed - cannot leave the operand's allocation)
@@ -231,17 +246,60 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
         stepa = stepb = BK * 2;
     } else {
         const size_t abytes = (size_t)max(kend - kbeg, 0) * p.lda * 2, bbytes = (size_t)max(kend - kbeg, 0) * p.ldb * 2;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {      // (M, N multiples of 256: the m / n extent of a tile never leaves its k-row)
-            ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)kbeg * p.lda + m0, (unsigned)min(abytes > (size_t)m0 * 2 ? abytes - (size_t)m0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
-            rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)kbeg * p.ldb + n0, (unsigned)min(bbytes > (size_t)n0 * 2 ? bbytes - (size_t)n0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
-        }
         // lane l of wave w fills LDS piece (k-row 2 w + l / 32, piece l & 31); its 64-byte group index is XOR-ed with k & 3
         const int k = 2 * wave + (lane >> 5), jp = lane & 31, j = ((((jp >> 2) ^ (k & 3)) << 2) | (jp & 3));
-        va = ((unsigned)k * (unsigned)p.lda + 8u * j) * 2u;
-        vb = ((unsigned)k * (unsigned)p.ldb + 8u * j) * 2u;
+        klim = kend - kbeg - (lane >> 2);       // (tile-blocked operands: lane l fetches k-row l / 4 of its wave's column block)
+        // Row-major operand: the window starts at (k-row kbeg, column m0) and ends with the split's last k-row.  Tile-blocked operand
+        // (common.h h2b_index): ANOTHER lane -> piece map, because there a (16 k-row x 32-column) block is 1 KB contiguous: wave w fetches
+        // column block w whole - lane l = (k-row l / 4, piece l & 3), source offset l * 16: one fully contiguous 1 KB request (the first
+        // version kept the row-major map - 2 k-rows x 32 pieces = sixteen 64-byte runs 16 KB apart - and the kernel was 6 % SLOWER than on
+        // row-major operands: profiles/r06_notes.md) - and the slab image becomes [column block][k-row][64 bytes] (fragment offsets below;
+        // k-rows 64 bytes apart: a half-wave's transposed read covers 256 contiguous bytes, no swizzle needed).
+        // The window starts at (row tile of kbeg, column block m0 / 32) and ends with the ALLOCATION; a k-row at or
+        // beyond the split's end is the next split's (or, past K, whatever an earlier and longer step left in the tile): those lanes
+        // request an out-of-range offset and receive zeros (chunk_a / chunk_b).  The piece (k-row, 8 m) of a lane is 16 contiguous
+        // bytes in either layout - the LDS image is the same.
+        if (p.a_tiles > 0) {
+            tba = (unsigned)(p.lda >> 5) * (unsigned)(H2B_BLOCK * 2);
+            const size_t t0 = (size_t)(kbeg >> 8), all = ((size_t)p.a_tiles - t0) * tba, skip = (size_t)(m0 >> 5) * (H2B_BLOCK * 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ra[q] = h2_rsrc(p.A + q * p.a_ps + (t0 * (size_t)(p.lda >> 5) + (size_t)(m0 >> 5)) * H2B_BLOCK, (unsigned)min(all > skip ? all - skip : (size_t)0, (size_t)0xFFFFFFF0u));
+            va = (unsigned)wave * (unsigned)(H2B_BLOCK * 2) + (unsigned)lane * 16u;       // wave w: column block w, 16 k-rows x 64 bytes = 1 KB CONTIGUOUS
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)      // (M, N multiples of 256: the m / n extent of a tile never leaves its k-row)
+                ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)kbeg * p.lda + m0, (unsigned)min(abytes > (size_t)m0 * 2 ? abytes - (size_t)m0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+            va = ((unsigned)k * (unsigned)p.lda + 8u * j) * 2u;
+        }
+        if (p.b_tiles > 0) {
+            tbb = (unsigned)(p.ldb >> 5) * (unsigned)(H2B_BLOCK * 2);
+            const size_t t0 = (size_t)(kbeg >> 8), all = ((size_t)p.b_tiles - t0) * tbb, skip = (size_t)(n0 >> 5) * (H2B_BLOCK * 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                rb[q] = h2_rsrc(p.B + q * p.b_ps + (t0 * (size_t)(p.ldb >> 5) + (size_t)(n0 >> 5)) * H2B_BLOCK, (unsigned)min(all > skip ? all - skip : (size_t)0, (size_t)0xFFFFFFF0u));
+            vb = (unsigned)wave * (unsigned)(H2B_BLOCK * 2) + (unsigned)lane * 16u;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)kbeg * p.ldb + n0, (unsigned)min(bbytes > (size_t)n0 * 2 ? bbytes - (size_t)n0 * 2 : (size_t)0, (size_t)0xFFFFFFF0u));
+            vb = ((unsigned)k * (unsigned)p.ldb + 8u * j) * 2u;
+        }
         stepa = (unsigned)BK * (unsigned)p.lda * 2u; stepb = (unsigned)BK * (unsigned)p.ldb * 2u;
     }
+    // source offset of 16-k chunk c of this split (wave-uniform): c * step, or - tile-blocked - (row tile) * tile bytes + (row in tile) * 64
+    // with the row counted from the first row of kbeg's row tile
+    const unsigned kin = (unsigned)(kbeg & 255);
+    auto chunk_a = [&](int c) -> unsigned {
+        if (!TN || tba == 0) return va + (unsigned)c * stepa;
+        const unsigned r = kin + 16u * (unsigned)c;
+        return 16 * c < klim ? va + (r >> 8) * tba + (r & 255u) * 64u : 0x80000000u;
+    };
+    auto chunk_b = [&](int c) -> unsigned {
+        if (!TN || tbb == 0) return vb + (unsigned)c * stepb;
+        const unsigned r = kin + 16u * (unsigned)c;
+        return 16 * c < klim ? vb + (r >> 8) * tbb + (r & 255u) * 64u : 0x80000000u;
+    };
 
     // ---- per-lane fragment offsets inside a slab (gemm_p3.hip's layouts: 16-bit elements, the element type does not matter)
     unsigned fa[TM], fb[TNN];
@@ -255,11 +313,18 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
     } else {
         const int i16 = lane & 15, kq = 8 * (lane >> 5) + (i16 >> 2);
         const unsigned within = 32u * ((lane >> 4) & 1) + 8u * (i16 & 3);
+        // row-major operand: slab = [k-row][column block ^ (k & 3)][64 B]; tile-blocked operand: slab = [column block][k-row][64 B]
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = (unsigned)kq * 512u + (unsigned)((((wm0 >> 5) + i) ^ (kq & 3))) * 64u + within;
+        for (int i = 0; i < TM; ++i)
+            fa[i] = tba ? (unsigned)((wm0 >> 5) + i) * 1024u + (unsigned)kq * 64u + within
+                        : (unsigned)kq * 512u + (unsigned)((((wm0 >> 5) + i) ^ (kq & 3))) * 64u + within;
 #pragma unroll
-        for (int j = 0; j < TNN; ++j) fb[j] = (unsigned)kq * 512u + (unsigned)((((wn0 >> 5) + j) ^ (kq & 3))) * 64u + within;
+        for (int j = 0; j < TNN; ++j)
+            fb[j] = tbb ? (unsigned)((wn0 >> 5) + j) * 1024u + (unsigned)kq * 64u + within
+                        : (unsigned)kq * 512u + (unsigned)((((wn0 >> 5) + j) ^ (kq & 3))) * 64u + within;
     }
+
+    const unsigned hia = tba ? 4u * 64u : 4u * 512u, hib = tbb ? 4u * 64u : 4u * 512u;
 
     floatx16 acc[TM][TNN];
 #pragma unroll
@@ -286,17 +351,15 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
         // prologue: chunks 0, 1, 2 (a chunk beyond the reduction range is requested all the same - it is never consumed, and the wait
         // counts stay the same in every step)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            h2_dma_stage(lds_base + (unsigned)s * H2_STAGE + wave_off, va, vb, ra[0], ra[1], rb[0], rb[1]);
-            va += stepa; vb += stepb;
-        }
+        for (int s = 0; s < 3; ++s)
+            h2_dma_stage(lds_base + (unsigned)s * H2_STAGE + wave_off, chunk_a(s), chunk_b(s), ra[0], ra[1], rb[0], rb[1]);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         h2_barrier();
         {   // early fragments of chunk 0
 #pragma unroll
-            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(h2_smem + 2 * H2_SLAB + fb[j]);
+            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(h2_smem + 2 * H2_SLAB + fb[j], hib);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) AL[i] = h2_frag<TN>(h2_smem + 1 * H2_SLAB + fa[i]);
+            for (int i = 0; i < TM; ++i) AL[i] = h2_frag<TN>(h2_smem + 1 * H2_SLAB + fa[i], hia);
         }
         int cur = 0;                                    // slot of chunk i
         for (int i = 0; i < nk; ++i) {
@@ -305,14 +368,13 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
             const unsigned char* Sn = h2_smem + nxt * H2_STAGE;
             __builtin_amdgcn_sched_barrier(0);
             // top: chunk i + 3
-            h2_dma_stage(lds_base + (unsigned)nx3 * H2_STAGE + wave_off, va, vb, ra[0], ra[1], rb[0], rb[1]);
-            va += stepa; vb += stepb;
+            h2_dma_stage(lds_base + (unsigned)nx3 * H2_STAGE + wave_off, chunk_a(i + 3), chunk_b(i + 3), ra[0], ra[1], rb[0], rb[1]);
             __builtin_amdgcn_sched_barrier(0);
             // P0: A_l x B_h; late fragments of this chunk
 #pragma unroll
-            for (int ii = 0; ii < TM; ++ii) AH[ii] = h2_frag<TN>(Sc + 0 * H2_SLAB + fa[ii]);
+            for (int ii = 0; ii < TM; ++ii) AH[ii] = h2_frag<TN>(Sc + 0 * H2_SLAB + fa[ii], hia);
 #pragma unroll
-            for (int j = 0; j < TNN; ++j) BL[j] = h2_frag<TN>(Sc + 3 * H2_SLAB + fb[j]);
+            for (int j = 0; j < TNN; ++j) BL[j] = h2_frag<TN>(Sc + 3 * H2_SLAB + fb[j], hib);
             mma(AL, BH);
             // P1: A_h x B_h
             mma(AH, BH);
@@ -322,9 +384,9 @@ __global__ __launch_bounds__(512) void gemm_h2_kernel(H2Params p) {
             h2_barrier();
             // P2: A_h x B_l; early fragments of chunk i + 1 into the registers that are dead
 #pragma unroll
-            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(Sn + 2 * H2_SLAB + fb[j]);
+            for (int j = 0; j < TNN; ++j) BH[j] = h2_frag<TN>(Sn + 2 * H2_SLAB + fb[j], hib);
 #pragma unroll
-            for (int ii = 0; ii < TM; ++ii) AL[ii] = h2_frag<TN>(Sn + 1 * H2_SLAB + fa[ii]);
+            for (int ii = 0; ii < TM; ++ii) AL[ii] = h2_frag<TN>(Sn + 1 * H2_SLAB + fa[ii], hia);
             mma(AH, BL);
             cur = nxt;
         }
@@ -375,7 +437,11 @@ __device__ __forceinline__ void h2w_dma4(unsigned l0, unsigned l1, unsigned v0, 
 }
 
 // EPI: 0 plain, 2 bias + tanh, 3 x leaky'(dref h plane), 5 bias
-template <int EPI>
+// ABLK (round 6): A is TILE-BLOCKED (common.h h2b_index) - the 256 rows of this workgroup are one row tile, double chunk D_j is its column
+// block j: 16 KB contiguous per plane, a request (16 rows x 64 bytes) is 1 KB of eight WHOLE 128-byte lines where the row-major operand
+// gives sixteen half lines (the 1.24-1.29 x over-fetch and the L1 line-fill limit of profiles/r05_h2_sq_counters.txt).  Same 16-byte
+// pieces into the same LDS slots: bit-identical results.
+template <int EPI, bool ABLK>
 __global__ __launch_bounds__(512) void gemm_h2w_kernel(H2Params p) {
     constexpr int BM = 256, BN = 256, TM = 4, TNN = 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char h2_smem[];
@@ -395,13 +461,17 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(H2Params p) {
     const size_t aall = (size_t)max(p.M - m0, 0) * p.lda * 2, ball = (size_t)max(p.N - n0, 0) * p.ldb * 2;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda, (unsigned)min(aall, (size_t)0xFFFFFFF0u));
+        if constexpr (ABLK) ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)tile_m * (size_t)(p.lda >> 5) * H2B_BLOCK,
+                                            (unsigned)min((size_t)(p.lda >> 5) * (H2B_BLOCK * 2), (size_t)0xFFFFFFF0u));      // this row tile (allocated whole)
+        else ra[q] = h2_rsrc(p.A + q * p.a_ps + (size_t)m0 * p.lda, (unsigned)min(aall, (size_t)0xFFFFFFF0u));
         rb[q] = h2_rsrc(p.B + q * p.b_ps + (size_t)n0 * p.ldb, (unsigned)min(ball, (size_t)0xFFFFFFF0u));
     }
     // lane l of wave w, request half r: LDS piece (row 32 w + 16 r + l / 4, piece l & 3) <- source piece (l & 3) ^ ((row >> 2) & 3),
     // and (row >> 2) & 3 == (l >> 4) & 3 for every w, r
     const unsigned row = 32u * (unsigned)wave + (unsigned)(lane >> 2), sp = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
-    unsigned va0 = (row * (unsigned)p.lda + 8u * sp) * 2u, va1 = va0 + 16u * (unsigned)p.lda * 2u;
+    unsigned va0 = ABLK ? row * 64u + 16u * sp : (row * (unsigned)p.lda + 8u * sp) * 2u;
+    unsigned va1 = va0 + (ABLK ? 16u * 64u : 16u * (unsigned)p.lda * 2u);
+    constexpr unsigned stepA = ABLK ? (unsigned)(H2B_BLOCK * 2) : 64u;          // bytes from a double chunk to the next
     unsigned vb0 = (row * (unsigned)p.ldb + 8u * sp) * 2u, vb1 = vb0 + 16u * (unsigned)p.ldb * 2u;
 
     // ---- per-lane fragment offsets inside a slab, k-half 0 (half 1: ^ 32)
@@ -437,7 +507,7 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(H2Params p) {
     };
     auto dma_a = [&](unsigned buf) {          // (A_h, A_l) of the next double chunk of A
         h2w_dma4(lds_base + buf + 0 * H2W_SLAB + wave_off, lds_base + buf + 1 * H2W_SLAB + wave_off, va0, va1, ra[0], ra[1]);
-        va0 += 64u; va1 += 64u;
+        va0 += stepA; va1 += stepA;
     };
     auto dma_b = [&](unsigned buf) {          // (B_h, B_l)
         h2w_dma4(lds_base + buf + 2 * H2W_SLAB + wave_off, lds_base + buf + 3 * H2W_SLAB + wave_off, vb0, vb1, rb[0], rb[1]);
@@ -672,7 +742,12 @@ extern "C" int cham_split2h(const float* X, int R, int Cc, int ld, void* dst, lo
     return CHAM_OK;
 }
 
-// launch counters: [0] NT launches, [1] TN launches, [2] NT launches on the 64-byte-piece kernel, [6] epilogue and [7] K-splits of the last launch
+// elements from one (256-row x 32-column) block of a tile-blocked plane to the next (8192 + the build's padding): a plane of `tiles` row
+// tiles and leading dimension ld occupies tiles * (ld / 32) * this many elements
+extern "C" int cham_h2b_block_elements(void) { return H2B_BLOCK; }
+
+// launch counters: [0] NT launches, [1] TN launches, [2] NT launches on the 64-byte-piece kernel, [3] NT launches with a tile-blocked A,
+// [4] TN launches with a tile-blocked operand, [6] epilogue and [7] K-splits of the last launch
 static long long g_h2_launches[8];
 extern "C" void cham_gemm_h2_launch_counts(long long* out8, int reset) {
     for (int i = 0; i < 8; ++i) { if (out8) out8[i] = g_h2_launches[i]; if (reset) g_h2_launches[i] = 0; }
@@ -682,15 +757,20 @@ extern "C" void cham_gemm_h2_launch_counts(long long* out8, int reset) {
 static int g_h2_nt_wide = 1;
 extern "C" int cham_gemm_h2_set_nt_wide(int on) { const int was = g_h2_nt_wide; g_h2_nt_wide = on ? 1 : 0; return was; }
 
-template <int EPI>
-static int h2w_launch(H2Params& p, hipStream_t st) {
+template <int EPI, bool ABLK>
+static int h2w_launch_l(H2Params& p, hipStream_t st) {
     g_h2_launches[6] = EPI; g_h2_launches[7] = 1; ++g_h2_launches[2];
+    if (ABLK) ++g_h2_launches[3];
     constexpr int smem = 2 * H2W_BUF;
-    auto k = gemm_h2w_kernel<EPI>;
+    auto k = gemm_h2w_kernel<EPI, ABLK>;
     CHAM_SET_DYNAMIC_LDS(k, smem);
     hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+template <int EPI>
+static int h2w_launch(H2Params& p, hipStream_t st) {
+    return p.a_tiles > 0 ? h2w_launch_l<EPI, true>(p, st) : h2w_launch_l<EPI, false>(p, st);
 }
 
 template <bool TN, int EPI>
@@ -710,11 +790,23 @@ static int h2_launch(H2Params& p, hipStream_t st) {
 //   tn = 1 (TN): A stored [K, lda >= M], B stored [K, ldb >= N]; M % 256 == 0, N % 256 == 0, any K; split-K through `workspace`
 //     (splits_hint: 1 none, 0 automatic, n at most n; fixed-order reduction), accumulate adds to C.
 // Returns -CHAM_ERR_ARG for shapes it does not take (the caller keeps cham_gemm_p3 / cham_gemm_f32x3 for those).
-extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
-                            int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
-                            const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
-                            void* stream) {
-    if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0) return -CHAM_ERR_ARG;
+// cham_gemm_h2b: the same with TILE-BLOCKED operands (common.h h2b_index: [row tiles of 256][ld / 32][256][32]; round 6).  a_tiles /
+// b_tiles > 0: that operand's planes are tile-blocked with that many row tiles allocated per plane (>= ceil(rows / 256), the rows beyond
+// the matrix ZERO; plane stride >= tiles * 256 * ld); 0: row-major.  dref_blocked: the dgrad's saved-activation plane likewise.
+//   NT: A may be blocked (needs K % 32 == 0 and the 64-byte-piece kernel, ld == K); B (the weight planes) is row-major.
+//   TN: A and B independently.  Results are bit-identical to the row-major operands' (tests/test_gemm_h2_gpu.py).
+extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                             int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                             const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                             int a_tiles, int b_tiles, int dref_blocked, void* stream) {
+    if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0 || a_tiles < 0 || b_tiles < 0) return -CHAM_ERR_ARG;
+    {   // tile-blocked operands: whole column blocks, enough row tiles, planes that do not overlap
+        const long a_rows = tn ? K : M, b_rows = tn ? K : N;
+        if (a_tiles && ((lda & 31) || (long)a_tiles * 256 < a_rows || a_plane_stride < (long long)a_tiles * (lda >> 5) * H2B_BLOCK)) return -CHAM_ERR_ARG;
+        if (b_tiles && ((ldb & 31) || (long)b_tiles * 256 < b_rows || b_plane_stride < (long long)b_tiles * (ldb >> 5) * H2B_BLOCK)) return -CHAM_ERR_ARG;
+        if (!tn && (b_tiles || (a_tiles && (lda != K || (K & 31) || !g_h2_nt_wide)))) return -CHAM_ERR_ARG;
+        if (dref_blocked && (!dref_h || (ldr & 31) || tn)) return -CHAM_ERR_ARG;      // (the caller allocates ceil(M / 256) row tiles of it)
+    }
     if ((lda & 7) || (ldb & 7) || (a_plane_stride & 7) || (b_plane_stride & 7) || (N & 3) || (ldc & 3)) return -CHAM_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return -CHAM_ERR_ARG;
     if ((size_t)ldc * 4 * 256 >= WINDOW_BYTES || (size_t)ldr * 2 * 256 >= WINDOW_BYTES) return -CHAM_ERR_ARG;
@@ -723,6 +815,7 @@ extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, co
     p.lda = lda; p.ldb = ldb; p.sa = a_scale; p.sb = b_scale; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.dref = reinterpret_cast<const unsigned short*>(dref_h); p.ldr = ldr; p.partial = workspace; p.xcd_split = 0; p.accumulate = 0;
     p.nbm = (M + 255) / 256; p.nbn = (N + 255) / 256;
+    p.a_tiles = a_tiles; p.b_tiles = b_tiles; p.r_blk = dref_blocked ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (!tn) {
         if ((K & 15) || accumulate) return -CHAM_ERR_ARG;
@@ -758,7 +851,9 @@ extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, co
     p.kchunk = kchunk;
     p.splits = (K + kchunk - 1) / kchunk;
     if ((size_t)kchunk * (lda > ldb ? lda : ldb) * 2 >= 0xFFFFFFF0ull) return -CHAM_ERR_ARG;
+    if ((a_tiles || b_tiles) && ((size_t)kchunk + 512 + 64) * (size_t)(lda > ldb ? lda : ldb) * 2 >= 0xFFFFFFF0ull) return -CHAM_ERR_ARG;      // offsets from kbeg's row tile
     ++g_h2_launches[1];
+    if (a_tiles || b_tiles) ++g_h2_launches[4];
     if (p.splits > 1) {
         p.xcd_split = (p.splits % 8 == 0) ? 1 : 0;
         const int rc = h2_launch<true, 6>(p, st);
@@ -773,4 +868,12 @@ extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, co
     }
     p.accumulate = accumulate;
     return h2_launch<true, 0>(p, st);
+}
+
+extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                            int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                            const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                            void* stream) {
+    return cham_gemm_h2b(A, a_plane_stride, lda, a_scale, B, b_plane_stride, ldb, b_scale, tn, C, ldc, M, N, K, bias, act, dref_h, ldr, dact, accumulate,
+                         workspace, workspace_bytes, splits_hint, 0, 0, 0, stream);
 }

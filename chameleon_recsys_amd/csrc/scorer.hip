@@ -108,11 +108,13 @@ __global__ __launch_bounds__(256) void k_combine_fwd_cand_p3(const float* __rest
 __global__ __launch_bounds__(256) void k_combine_fwd_cand_h2(const float* __restrict__ U, const float* __restrict__ V, int C,
                                                              int BT, int N, int pmax, const int* __restrict__ neg_slot,
                                                              _Float16* __restrict__ Z1p /* plane 0, candidate rows */, long long ps,
-                                                             const H2Scale* __restrict__ rec) {
+                                                             const H2Scale* __restrict__ rec, int blocked) {
     const int bt = blockIdx.x, NC = N + 1;
     const float sc = rec->scale;
     const float4* pu = reinterpret_cast<const float4*>(U + (size_t)bt * C);
     _Float16* po = Z1p + (size_t)bt * NC * C;
+    const size_t grow0 = (size_t)bt * NC;              // first candidate row of this position
+    const unsigned ncb = (unsigned)C >> 5;
     for (int k = threadIdx.x; k < C / 4; k += 256) {
         const float4 a = pu[k];
         for (int c0 = 0; c0 < NC; c0 += 4) {
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void k_combine_fwd_cand_h2(const float* __rest
                 float4 o;
                 o.x = act_fwd(a.x + b[i].x, ACT_LEAKY); o.y = act_fwd(a.y + b[i].y, ACT_LEAKY);
                 o.z = act_fwd(a.z + b[i].z, ACT_LEAKY); o.w = act_fwd(a.w + b[i].w, ACT_LEAKY);
-                st4_planes_h2(po + (size_t)(c0 + i) * C + 4 * k, ps, o, sc);
+                // row-major [rows, C], or tile-blocked (common.h h2b_index: four consecutive columns never leave a 32-column block)
+                st4_planes_h2(blocked ? Z1p + h2b_index(grow0 + (size_t)(c0 + i), 4u * (unsigned)k, ncb) : po + (size_t)(c0 + i) * C + 4 * k, ps, o, sc);
             }
         }
     }
@@ -701,14 +704,21 @@ extern "C" int cham_mulpred_bwd_p3(const float* dM, const float* Z2c, const floa
     return CHAM_OK;
 }
 
-extern "C" int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
-                                   long long plane_stride, const void* scale_rec, void* stream) {
+// blocked != 0: the planes are written TILE-BLOCKED (common.h h2b_index; C % 32 == 0; the caller allocates ceil(rows / 256) row tiles per
+// plane, zero-initialised: rows beyond BT * (1 + N) are never written)
+extern "C" int cham_combine_fwd_h2b(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                                    long long plane_stride, const void* scale_rec, int blocked, void* stream) {
     if (!U || !V || !neg_slot || !Z1p || !scale_rec || C <= 0 || (C & 3) || BT < 0 || N < 0 || (plane_stride & 3)) return -CHAM_ERR_ARG;
+    if (blocked && ((C & 31) || plane_stride < (long long)(((size_t)BT * (N + 1) + 255) / 256) * (C >> 5) * H2B_BLOCK)) return -CHAM_ERR_ARG;
     if (BT == 0) return CHAM_OK;
     hipLaunchKernelGGL(k_combine_fwd_cand_h2, dim3(BT), dim3(256), 0, (hipStream_t)stream, U, V, C, BT, N, pmax, neg_slot,
-                       reinterpret_cast<_Float16*>(Z1p), plane_stride, reinterpret_cast<const H2Scale*>(scale_rec));
+                       reinterpret_cast<_Float16*>(Z1p), plane_stride, reinterpret_cast<const H2Scale*>(scale_rec), blocked ? 1 : 0);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_combine_fwd_h2(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                                   long long plane_stride, const void* scale_rec, void* stream) {
+    return cham_combine_fwd_h2b(U, V, C, BT, N, pmax, neg_slot, Z1p, plane_stride, scale_rec, 0, stream);
 }
 
 extern "C" int cham_mulpred_bwd_h2(const float* dM, const float* Z2c, const float* pred, int C, int BT, int N, float* dpred_pre, void* dZ2p,

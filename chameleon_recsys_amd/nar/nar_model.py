@@ -199,6 +199,14 @@ class NARRuntime:
         # from a bound of the matrix, THREE plane products instead of six - the kernels were power-limited, so halving the MFMA count is
         # what moves them; same float64-error bar as the six-product form (tests/test_gemm_h2_gpu.py).  CHAM_GEMM_H2=0: the three-bf16-plane arm
         self.h2 = self.p3 and os.environ.get("CHAM_GEMM_H2", "1") == "1"
+        # ... optionally with the candidate-row planes TILE-BLOCKED (round 6; [row tiles of 256][C / 32][256][32], csrc/common.h h2b_index): an
+        # LDS-DMA request of the NT forms (16 rows x 32 k) is then 1 KB of whole 128-byte lines instead of sixteen half lines.  Bit-identical
+        # results (same pieces, same products).  MEASURED (profiles/r06_notes.md section 2): the NT forms gain 4-5 % (stand-alone 1.41 -> 1.36 and
+        # 1.44 -> 1.375 ms), the TN weight gradient loses 2.5 % stand-alone and 6-19 % in the step, the plane-writing combine 0.09 ms: the step is
+        # 0.05 ms SLOWER (7.89 vs 7.84 ms) - the NT forms were power-limited, not line-fill-limited.  Hence OFF by default; CHAM_H2_BLOCKED=1 is
+        # the arm (needs the 64-byte-piece NT kernel, CHAM_H2_NT_WIDE=1).
+        self.h2_blocked = (self.h2 and os.environ.get("CHAM_H2_BLOCKED", "0") == "1" and os.environ.get("CHAM_H2_NT_WIDE", "1") == "1"
+                           and self.layout.C % 32 == 0)
         # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
         # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A LIBRARY-wide setting, made once per
         # process when the library is loaded (chameleon_recsys_amd/_lib.py): constructing a second runtime never flips the kernels of the first
@@ -557,8 +565,9 @@ class NARRuntime:
                              bias=bias is not None, rowscale=False, bf16=False, p3=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
 
     def gemm_h2(self, A, a_ps, lda, a_sc, B, b_ps, ldb, b_sc, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
-                accumulate=0, splits=1):
-        """Plane-product GEMM over two fp16 planes + scale records (csrc/gemm_h2.hip): NT (tn=0) or TN (tn=1, split-K)."""
+                accumulate=0, splits=1, a_tiles=0, b_tiles=0, dref_blocked=0):
+        """Plane-product GEMM over two fp16 planes + scale records (csrc/gemm_h2.hip): NT (tn=0) or TN (tn=1, split-K).  a_tiles / b_tiles > 0:
+        that operand is TILE-BLOCKED with this many row tiles per plane (include/chameleon_nar.h cham_gemm_h2b), dref_blocked: dref_h likewise."""
         ws = None
         if splits != 1:
             ws = self._lane_ws('gemm_ws')
@@ -569,8 +578,9 @@ class NARRuntime:
             self.lib.cham_gemm_h2_launch_counts(c0, 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(self.lib.cham_gemm_h2(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
-                                    ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_h2")
+        check(self.lib.cham_gemm_h2b(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
+                                     ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, a_tiles, b_tiles, dref_blocked,
+                                     _stream()), "cham_gemm_h2b")
         if prof is not None:
             e1.record()
             c = (ctypes.c_longlong * 8)()
@@ -601,6 +611,38 @@ class NARRuntime:
     def join(self):
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.side_stream)
+
+
+def _h2b_block():
+    from .. import _lib
+    return int(_lib.load().cham_h2b_block_elements())
+
+
+def blocked_plane_elements(tiles, C):
+    """Elements of ONE tile-blocked plane of `tiles` row tiles and leading dimension C (csrc/common.h h2b_index)."""
+    return tiles * (C // 32) * _h2b_block()
+
+
+def planes_from_blocked(t, tiles, C=None):
+    """[planes, >= tiles * (C / 32) * block] memory in the TILE-BLOCKED layout ([row tile][C / 32][256][32] (+ padding), csrc/common.h
+    h2b_index) -> the row-major [planes, tiles * 256, C] matrix (a copy; tests and debugging)."""
+    npl = t.shape[0]
+    C = t.shape[2] if C is None else C
+    blk = _h2b_block()
+    flat = t.reshape(npl, -1)[:, :tiles * (C // 32) * blk]
+    return flat.reshape(npl, tiles, C // 32, blk)[..., :8192].reshape(npl, tiles, C // 32, 256, 32).permute(0, 1, 3, 2, 4).reshape(npl, tiles * 256, C)
+
+
+def planes_to_blocked(t):
+    """Row-major [planes, R, C] (C % 32 == 0) -> (tile-blocked [planes, tiles * (C / 32) * block] with the rows beyond R zero, tiles)."""
+    npl, R, C = t.shape
+    tiles = -(-R // 256)
+    blk = _h2b_block()
+    pad = torch.zeros(npl, tiles * 256, C, dtype=t.dtype, device=t.device)
+    pad[:, :R] = t
+    out = torch.zeros(npl, tiles, C // 32, blk, dtype=t.dtype, device=t.device)
+    out[..., :8192] = pad.reshape(npl, tiles, 256, C // 32, 32).permute(0, 1, 3, 2, 4).reshape(npl, tiles, C // 32, 8192)
+    return out.reshape(npl, -1), tiles
 
 
 class StepPlan:
@@ -650,6 +692,7 @@ class StepPlan:
         self.pmax = pmax = 20 * N
         self.RV = RV = 2 * BT + pmax + 1
         C, Hp, Fc, Fi = L.C, L.Hp, L.Fc, L.Fi
+        self.C = C
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         i64 = lambda *s: torch.zeros(*s, dtype=torch.int64, device=dev)
         # sampler
@@ -700,14 +743,28 @@ class StepPlan:
         self.p3 = rt.p3
         self.h2 = rt.h2
         if rt.p3:     # plane-resident operands of the three candidate-row CAR GEMMs (planes Rc * C elements apart) + b2 partial sums
+            self.z1_tiles = self.dz2_tiles = 0
             if rt.h2:      # two fp16 planes + the scale records of the two matrices
-                self.Z1p, self.dZ2p = (torch.empty(2, Rc, C, dtype=torch.float16, device=dev) for _ in range(2))
+                # TILE-BLOCKED planes (round 6; csrc/common.h h2b_index): [row tiles of 256][C / 32][256][32] - what the NT GEMMs fetch per
+                # request is whole 128-byte lines.  Z1's planes always (cham_combine_fwd_h2b writes them); dZ2's when the fused scorer dgrad
+                # is their producer (cham_dm_mulpred_h2_blk; the unfused cham_mulpred_bwd_h2 writes row-major).  Row tiles are allocated
+                # whole (+ one: a workgroup of the fused dgrad addresses two tiles from its first row's), zero-initialised.
+                tiles = -(-Rc // 256) + 1
+                if rt.h2_blocked:
+                    self.z1_tiles = tiles
+                    self.dz2_tiles = tiles if (rt.dm_fused and 32 <= NC <= 256) else 0
+                self.Z1p = (torch.zeros(2, blocked_plane_elements(self.z1_tiles, C), dtype=torch.float16, device=dev) if self.z1_tiles
+                            else torch.zeros(2, Rc, C, dtype=torch.float16, device=dev))
+                self.dZ2p = (torch.zeros(2, blocked_plane_elements(self.dz2_tiles, C), dtype=torch.float16, device=dev) if self.dz2_tiles
+                             else torch.zeros(2, Rc, C, dtype=torch.float16, device=dev))
                 self.sc_z1 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_dz2 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_ds1 = torch.zeros(8, dtype=torch.float32, device=dev)          # dS1 itself (operand of the Ws1 weight gradient)
             else:
                 self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
-            self.p3_ps = Rc * C
+            self.p3_ps = Rc * C                                   # plane stride of a row-major operand ...
+            self.z1_ps = self.Z1p[0].numel()                      # ... and of each operand as allocated
+            self.dz2_ps = self.dZ2p[0].numel()
             self.b2part = f32(BT, C)
         # RNN
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -783,7 +840,10 @@ class StepPlan:
         P = self.P if P is None else P
         n = P * self.NC
         if getattr(self, 'used_p3', False):
-            z = self.Z1p[:, :n].float()
+            if getattr(self, 'z1_tiles', 0):       # tile-blocked planes -> row-major
+                z = planes_from_blocked(self.Z1p, self.z1_tiles, self.C)[:, :n].float()
+            else:
+                z = self.Z1p[:, :n].float()
             if self.h2:
                 return (z[0] + z[1]) * self.sc_z1[1]
             return z[0] + z[1] + z[2]
@@ -1251,14 +1311,14 @@ class NARModuleModel:
                 rt.gemm(pl.Xd[BT:], self._drop['W1'], pl.Z1[BT:], Rc, C, Fc + Fi, Fc + Fi, C, C, bias=p('b1'), act=ACT_LEAKY)
             elif use_p3 and rt.h2:      # candidate rows straight into two fp16 planes x 2^k, k from the bound max|U| + max|V| (no fp32 copy)
                 check(lib.cham_h2_scale_absmax(ptr(pl.U), BT * C, ptr(pl.V), RV * C, ptr(pl.sc_z1), s), "cham_h2_scale_absmax")
-                check(lib.cham_combine_fwd_h2(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, ptr(pl.sc_z1), s),
+                check(lib.cham_combine_fwd_h2b(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.z1_ps, ptr(pl.sc_z1), 1 if pl.z1_tiles else 0, s),
                       "cham_combine_fwd_h2")
             elif use_p3:      # candidate rows straight into three bf16 planes (no fp32 copy)
                 check(lib.cham_combine_fwd_p3(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1p), pl.p3_ps, s), "cham_combine_fwd_p3")
             else:
                 check(lib.cham_combine_fwd(ptr(pl.U), ptr(pl.V), C, BT, N, pmax, ptr(neg_slot), ptr(pl.Z1), BT, Rc, s), "cham_combine_fwd")
             if use_p3 and rt.h2:
-                rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
+                rt.gemm_h2(pl.Z1p, pl.z1_ps, C, pl.sc_z1, rt.w2tp, C * C, C, rt.sc_w2, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH, a_tiles=pl.z1_tiles)
             elif use_p3:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, rt.w2tp, C * C, C, 0, pl.Z2[BT:], C, Rc, C, C, bias=p('b2'), act=ACT_TANH)
             else:
@@ -1419,12 +1479,17 @@ class NARModuleModel:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if h2:
+            if h2 and pl.dz2_tiles:      # ... with the planes of dZ2 written tile-blocked (ds1 / w scale records: the kernel's own products on two fp16 planes too)
+                f16 = rt.dm_f16
+                check(lib.cham_dm_mulpred_h2_blk(ptr(pl.dS1), 128, 128, ptr(rt.ws1h if f16 else rt.ws1p), C * 128, ptr(pl.sc_ds1) if f16 else None,
+                                                 ptr(rt.sc_ws1n) if f16 else None, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.dz2_ps, ptr(pl.sc_dz2),
+                                                 ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2_blk")
+            elif h2:
                 if rt.dm_f16:     # the kernel's own products on two fp16 planes too
                     check(lib.cham_dm_mulpred_h2h(ptr(pl.dS1), 128, 128, ptr(rt.ws1h), C * 128, ptr(pl.sc_ds1), ptr(rt.sc_ws1n), ptr(Z2c), ptr(pl.pred),
-                                                  C, BT, N, ptr(pl.dZ2p), pl.p3_ps, ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2h")
+                                                  C, BT, N, ptr(pl.dZ2p), pl.dz2_ps, ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2h")
                 else:
-                    check(lib.cham_dm_mulpred_h2(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
+                    check(lib.cham_dm_mulpred_h2(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.dz2_ps,
                                                  ptr(pl.sc_dz2), ptr(pl.dpred), ptr(pl.b2part), s), "cham_dm_mulpred_h2")
             else:
                 check(lib.cham_dm_mulpred_p3(ptr(pl.dS1), 128, 128, ptr(rt.ws1p), C * 128, ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dZ2p), pl.p3_ps,
@@ -1445,7 +1510,7 @@ class NARModuleModel:
                 prof.append(dict(M=Rc, N=C, K=128, transA=0, transB=1, splits=1, act=0, dref=False, dact=0, bias=False, rowscale=False, bf16=True,
                                  dmf=True, tile=0, epi=0, ev=(e0, e1)))
         elif h2:          # gradient at the CAR tanh straight into two fp16 planes + this position's share of the b2 gradient
-            check(lib.cham_mulpred_bwd_h2(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part),
+            check(lib.cham_mulpred_bwd_h2(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.dz2_ps, ptr(pl.b2part),
                                           ptr(pl.sc_dz2), s), "cham_mulpred_bwd_h2")
         elif use_p3:      # gradient at the CAR tanh straight into three bf16 planes + this position's share of the b2 gradient
             check(lib.cham_mulpred_bwd_p3(ptr(dZ2c), ptr(Z2c), ptr(pl.pred), C, BT, N, ptr(pl.dpred), ptr(pl.dZ2p), pl.p3_ps, ptr(pl.b2part), s),
@@ -1462,11 +1527,13 @@ class NARModuleModel:
             rt.gemm_b16(dZ2c, C, 0, sh['W2'], C, 1, pl.dZ1c, C, 0, Rc, C, C, dref=pl.Z1c, ldr=C, dact=ACT_LEAKY, dma=rt.b16_dma)
         def w2_wgrad_planes(splits):      # candidate rows' share of the W2 weight gradient from the planes (TN, split-K)
             if h2:
-                rt.gemm_h2(pl.Z1p, pl.p3_ps, C, pl.sc_z1, pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, 1, g('W2'), C, C, C, Rc, splits=splits)
+                rt.gemm_h2(pl.Z1p, pl.z1_ps, C, pl.sc_z1, pl.dZ2p, pl.dz2_ps, C, pl.sc_dz2, 1, g('W2'), C, C, C, Rc, splits=splits,
+                           a_tiles=pl.z1_tiles, b_tiles=pl.dz2_tiles)
             else:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=splits)
         if h2:          # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
-            rt.gemm_h2(pl.dZ2p, pl.p3_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
+            rt.gemm_h2(pl.dZ2p, pl.dz2_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY,
+                       a_tiles=pl.dz2_tiles, dref_blocked=1 if pl.z1_tiles else 0)
         elif use_p3:
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         elif not b16 and Rc > 0:

@@ -82,6 +82,11 @@ class DataParallelNAR:
         # how often each collective ran (tests assert the reduce-scatter / all-gather branches really executed with world > 1;
         # bench.py's "dp" object reports them)
         self.collective_calls = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0, "broadcast": 0}
+        # time_exchange = True: HIP events on the step's stream around the synchronous part of the exchange (everything but the early
+        # bucket's overlapped flight) - the collectives make the current stream wait for RCCL's, so the pair brackets them; read with
+        # exchange_ms() (bench.py's "dp" object).  Off by default: no events, no synchronisation.
+        self.time_exchange = False
+        self._exchange_events = []
         # CHAM_DP_FORCE=1: install the exchange hooks for a process group of ONE rank too - every collective of every mode then runs
         # (on RCCL when the group's backend is "nccl") and must leave the step bit-identical to the plain single-process one
         # (tests/test_dp_rccl_gpu.py; bench.py's dp_self_exchange_ms)
@@ -227,6 +232,27 @@ class DataParallelNAR:
             out.append((max(a, eb), b))
         return out
 
+    def _timed(fn):
+        def wrapped(self, *a, **k):
+            if not self.time_exchange or not torch.cuda.is_available():
+                return fn(self, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(self, *a, **k)
+            e1.record()
+            self._exchange_events.append((e0, e1))
+            return out
+        return wrapped
+
+    def exchange_ms(self, reset=True):
+        """Per-step durations (ms) of the exchange recorded while time_exchange was set (synchronises the device)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._exchange_events]
+        if reset:
+            self._exchange_events = []
+        return out
+
+    @_timed
     def _allreduce(self, flat_grads):
         early = self._wait_early_bucket()
         self.last_exchange_bytes = self._early_bytes if early else 0
@@ -250,6 +276,7 @@ class DataParallelNAR:
         L, dim = rows.shape
         check(self.model.rt.lib.cham_rows_scatter(ptr(rows), ptr(ids), L, dim, ptr(table), torch.cuda.current_stream().cuda_stream), "cham_rows_scatter")
 
+    @_timed
     def _sparse_allreduce(self, flat_grads):
         """ONE collective for everything but the early bucket: [flat buffer without the item table | touched item-table rows] packed
         into a contiguous communication buffer (round 1 issued three: prefix, suffix, rows)."""
@@ -322,6 +349,7 @@ class DataParallelNAR:
             out.append(full)
         return out[0], out[1]
 
+    @_timed
     def _sharded_step(self, flat_grads, flat_params, adam):
         """reduce-scatter of the flat gradients -> Adam on this rank's contiguous 1/world slice -> all-gather of the updated slices
         (RCCL and gloo alike)."""

@@ -223,6 +223,28 @@ int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* 
                  int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, void* stream);
 void cham_gemm_h2_launch_counts(long long* out8, int reset);
 int cham_gemm_h2_set_nt_wide(int on);
+/* TILE-BLOCKED planes (round 6).  A two-plane matrix [rows, ld] may be stored as [row tiles of 256][ld / 32 column blocks][256 rows][32
+ * columns] (element (r, c) of a plane at ((r / 256) * (ld / 32) + c / 32) * 8192 + (r % 256) * 32 + c % 32; ld % 32 == 0), with
+ * ceil(rows / 256) row tiles allocated per plane and the rows beyond the matrix ZERO: a (256-row x 32-column) block is then 16 KB contiguous,
+ * and what the NT plane GEMMs (CAR forward / dgrad over the candidate rows, nar_model.py:384-388) fetch per LDS-DMA request - 16 rows x 32 k -
+ * is 1 KB of whole 128-byte lines where the row-major operand gives sixteen half lines (HBM over-fetch 1.24-1.29 x and an L1 line-fill
+ * limit in round 5).  The 16-byte pieces the kernels move are the same element sets in both layouts, so results are BIT-IDENTICAL.
+ *   cham_gemm_h2b = cham_gemm_h2 + a_tiles / b_tiles (> 0: that operand is tile-blocked with this many row tiles allocated per plane, plane
+ *   stride >= tiles * 256 * ld; 0: row-major) + dref_blocked (the saved activation's h plane likewise).  NT: A only (ld == K, K % 32 == 0,
+ *   the 64-byte-piece kernel); TN: A and B independently.  cham_gemm_h2_launch_counts out8[3] / out8[4]: NT / TN launches with a blocked operand.
+ *   cham_combine_fwd_h2b = cham_combine_fwd_h2 + blocked (the planes of the PreCAR output are written tile-blocked);
+ *   cham_dm_mulpred_h2_blk = cham_dm_mulpred_h2 (ds1_scale_rec = w_scale_rec = NULL) / cham_dm_mulpred_h2h (both given) with the planes of
+ *   the gradient at the CAR tanh written tile-blocked. */
+int cham_h2b_block_elements(void);      /* elements from one block to the next: 8192 (+ the build's padding, 0 by default) */
+int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride, int ldb,
+                  const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act, const void* dref_h, int ldr,
+                  int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint, int a_tiles, int b_tiles,
+                  int dref_blocked, void* stream);
+int cham_combine_fwd_h2b(const float* U, const float* V, int C, int BT, int N, int pmax, const int32_t* neg_slot, void* Z1p,
+                         long long plane_stride, const void* scale_rec, int blocked, void* stream);
+int cham_dm_mulpred_h2_blk(const float* dS1, int lds1, int K, const void* Wp, long long w_plane_stride, const void* ds1_scale_rec,
+                           const void* w_scale_rec, const float* Z2c, const float* pred, int C, int BT, int N, void* dZ2p,
+                           long long out_plane_stride, const void* out_scale_rec, float* dpred_pre, float* col_part, void* stream);
 /* producers of two-plane matrices (csrc/scorer.hip, csrc/dm_fused.hip): cham_combine_fwd_p3 / cham_mulpred_bwd_p3 / cham_dm_mulpred_p3
  * with the output written as (h, l) fp16 planes x the scale of `scale_rec` (filled BEFORE the call: max|U| + max|V| for the PreCAR output,
  * rownorm(dS1) x rownorm(Ws1) for the gradient at the CAR tanh) */

@@ -421,3 +421,166 @@ def test_h2_producers_match_the_three_plane_ones(gpu):
     torch.cuda.synchronize()
     d2u = D2u.double().sum(0) * float(rd[1])
     assert float((d2u - d3).abs().max()) <= 1e-5 * float(d3.abs().max())
+
+
+# ---- TILE-BLOCKED operands (round 6; common.h h2b_index, include/chameleon_nar.h cham_gemm_h2b): the 16-byte pieces the kernels move are the
+# ---- same element sets in both layouts - same LDS images, same products in the same order: BIT-IDENTICAL to the row-major operands
+def _gemm_b(lib, Ap, a_ps, lda, ra, Bp, b_ps, ldb, rb, tn, C, ldc, M, N, K, bias=None, act=0, dref=None, ldr=0, dact=0, accumulate=0, ws=None, splits=1,
+            a_tiles=0, b_tiles=0, dref_blocked=0, expect=0):
+    from chameleon_recsys_amd._lib import ptr
+    rc = lib.cham_gemm_h2b(ptr(Ap), a_ps, lda, ptr(ra), ptr(Bp), b_ps, ldb, ptr(rb), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref), ldr, dact,
+                           accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, a_tiles, b_tiles, dref_blocked,
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == expect, rc
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (700, 320, 64), (1024, 1024, 1024), (5 * 256 + 51, 1024, 1024), (255, 96, 128), (12 * 51, 256, 512)])
+@pytest.mark.parametrize("epi", ["plain", "bias", "tanh", "dgrad"])
+def test_h2_nt_blocked_a_bit_identical_to_row_major(gpu, M, N, K, epi):
+    from chameleon_recsys_amd.nar.nar_model import planes_from_blocked, planes_to_blocked
+    lib = _lib_()
+    g = torch.Generator(device=gpu).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu, generator=g)
+    B = torch.randn(N, K, device=gpu, generator=g) * (K ** -0.5)
+    bias_t = torch.randn(N, device=gpu, generator=g) if epi in ("bias", "tanh") else None
+    (Ap, ra), (Bp, rb) = split2h_dev(A), split2h_dev(B)
+    Ab, tiles = planes_to_blocked(Ap)
+    assert torch.equal(planes_from_blocked(Ab, tiles, K)[:, :M], Ap)
+    # garbage in the rows beyond M of the last tile must not matter (NT: rows are independent, those outputs are never stored)
+    junk = planes_from_blocked(Ab, tiles, K).clone(); junk[:, M:] = float('nan'); Ab = planes_to_blocked(junk)[0]
+    a_ps = Ab[0].numel()
+    Yh = Yb = None
+    if epi == "dgrad":      # the saved activation's h plane, [M, N]: row-major and tile-blocked (N % 32 == 0)
+        Yh = split2h_dev(torch.randn(M, N, device=gpu, generator=g))[0][0].contiguous()
+        Yb = planes_to_blocked(Yh[None])[0][0].contiguous()
+    ref, got = (torch.full((M, N), float('nan'), device=gpu) for _ in range(2))
+    kw = dict(bias=bias_t, act=2 if epi == "tanh" else 0, ldr=N, dact=1 if epi == "dgrad" else 0)
+    _gemm_b(lib, Ap, M * K, K, ra, Bp, N * K, K, rb, 0, ref, N, M, N, K, dref=Yh, **kw)
+    c0 = _counts(lib)
+    _gemm_b(lib, Ab, a_ps, K, ra, Bp, N * K, K, rb, 0, got, N, M, N, K, dref=Yb, a_tiles=tiles, dref_blocked=1 if epi == "dgrad" else 0, **kw)
+    c1 = _counts(lib)
+    torch.cuda.synchronize()
+    assert c1[3] == c0[3] + 1 and c1[2] == c0[2] + 1            # the blocked-A instance of the 64-byte-piece kernel ran
+    assert not torch.isnan(ref).any() and torch.equal(ref, got)
+    if epi == "dgrad":      # blocked A with a row-major activation plane, and the other way round
+        got2, got3 = (torch.full((M, N), float('nan'), device=gpu) for _ in range(2))
+        _gemm_b(lib, Ab, a_ps, K, ra, Bp, N * K, K, rb, 0, got2, N, M, N, K, dref=Yh, a_tiles=tiles, **kw)
+        _gemm_b(lib, Ap, M * K, K, ra, Bp, N * K, K, rb, 0, got3, N, M, N, K, dref=Yb, dref_blocked=1, **kw)
+        assert torch.equal(ref, got2) and torch.equal(ref, got3)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 256, 16, 1), (256, 512, 700, 1), (512, 256, 5000, 0), (1024, 1024, 9 * 256 * 4 + 51 * 3, 32),
+                                          (256, 256, 1000, 3), (1024, 1024, 255 * 51, 7)])
+@pytest.mark.parametrize("which", ["ab", "a", "b"])
+def test_h2_tn_blocked_operands_bit_identical_to_row_major(gpu, M, N, K, splits, which):
+    """TN contracts over the ROWS: split boundaries inside a row tile (k-chunks that are no multiple of 256), a reduction length that
+    is no multiple of 16, and STALE non-zero data in the tile's rows beyond K (an earlier, longer step) - masked by the kernel."""
+    from chameleon_recsys_amd.nar.nar_model import planes_from_blocked, planes_to_blocked
+    lib = _lib_()
+    g = torch.Generator(device=gpu).manual_seed(K + splits)
+    A = torch.randn(K, M, device=gpu, generator=g)
+    B = torch.randn(K, N, device=gpu, generator=g)
+    (Ap, ra), (Bp, rb) = split2h_dev(A), split2h_dev(B)
+    def blocked(P, ld):
+        Pb, tiles = planes_to_blocked(P)
+        rm = planes_from_blocked(Pb, tiles, ld).clone()
+        rm[:, K:] = torch.randn(rm[:, K:].shape, device=gpu, generator=g).half() * 100      # stale rows: finite, non-zero
+        return planes_to_blocked(rm)[0], tiles
+    Ab, ta = blocked(Ap, M)
+    Bb, tb = blocked(Bp, N)
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=gpu) if splits != 1 else None
+    ref, got = (torch.full((M, N), float('nan'), device=gpu) for _ in range(2))
+    _gemm_b(lib, Ap, K * M, M, ra, Bp, K * N, N, rb, 1, ref, N, M, N, K, ws=ws, splits=splits)
+    ua, ub = "a" in which, "b" in which
+    c0 = _counts(lib)
+    _gemm_b(lib, Ab if ua else Ap, Ab[0].numel() if ua else K * M, M, ra, Bb if ub else Bp, Bb[0].numel() if ub else K * N, N, rb, 1, got, N, M, N, K, ws=ws,
+            splits=splits, a_tiles=ta if ua else 0, b_tiles=tb if ub else 0)
+    torch.cuda.synchronize()
+    assert _counts(lib)[4] == c0[4] + 1
+    assert not torch.isnan(ref).any() and torch.equal(ref, got)
+    err = float((got.double() - A.double().t() @ B.double()).abs().max()) / float((A.double().t() @ B.double()).abs().max())
+    assert err < 2e-6, err
+
+
+def test_h2_blocked_argument_checks(gpu):
+    lib = _lib_()
+    blk = lib.cham_h2b_block_elements()
+    assert blk >= 8192 and blk % 8 == 0
+    ps = 2 * 2 * blk                                  # two row tiles x two column blocks (ld = 64)
+    P = torch.zeros(2, ps, dtype=torch.float16, device=gpu)
+    W = torch.zeros(2, 256, 64, dtype=torch.float16, device=gpu)
+    r = new_rec(gpu)
+    C = torch.zeros(300, 256, device=gpu)
+    ok = dict(expect=0)
+    _gemm_b(lib, P, ps, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 64, a_tiles=2, **ok)
+    bad = dict(expect=-22)
+    _gemm_b(lib, P, ps, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 64, a_tiles=1, **bad)            # too few row tiles for M = 300
+    _gemm_b(lib, P, ps // 2, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 64, a_tiles=2, **bad)       # planes overlap
+    _gemm_b(lib, P, ps, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 64, b_tiles=1, **bad)            # NT: B (weights) is row-major
+    _gemm_b(lib, P, ps, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 48, a_tiles=2, **bad)            # ld != K / K % 32
+    was = lib.cham_gemm_h2_set_nt_wide(0)
+    try:
+        _gemm_b(lib, P, ps, 64, r, W, 256 * 64, 64, r, 0, C, 256, 300, 256, 64, a_tiles=2, **bad)        # needs the 64-byte-piece kernel
+    finally:
+        lib.cham_gemm_h2_set_nt_wide(was)
+
+
+@pytest.mark.parametrize("BT,N,C", [(7, 50, 1024), (64, 50, 256), (33, 31, 128), (5, 100, 512)])
+def test_blocked_plane_producers_write_the_row_major_planes_bit_for_bit(gpu, BT, N, C):
+    """cham_combine_fwd_h2b (PreCAR output) and cham_dm_mulpred_h2_blk (gradient at the CAR tanh, both arithmetics) in the tile-blocked
+    layout against their row-major forms: same bits after un-blocking, rows beyond BT (1 + N) untouched (zero), every other output equal."""
+    from chameleon_recsys_amd._lib import check, ptr
+    from chameleon_recsys_amd.nar.nar_model import blocked_plane_elements, planes_from_blocked
+    lib = _lib_()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=gpu).manual_seed(BT * N + C)
+    NC, pmax = N + 1, 40
+    R = BT * NC
+    tiles = -(-R // 256) + 1
+    U = torch.randn(BT, C, device=gpu, generator=g)
+    V = torch.randn(2 * BT + pmax + 1, C, device=gpu, generator=g)
+    neg_slot = torch.randint(0, pmax + 1, (BT, N), device=gpu, generator=g, dtype=torch.int32)
+    rec = new_rec(gpu)
+    check(lib.cham_h2_scale_absmax(ptr(U), U.numel(), ptr(V), V.numel(), ptr(rec), st), "absmax")
+    Zr = torch.zeros(2, R, C, dtype=torch.float16, device=gpu)
+    bps = blocked_plane_elements(tiles, C)
+    Zb = torch.zeros(2, bps, dtype=torch.float16, device=gpu)
+    check(lib.cham_combine_fwd_h2b(ptr(U), ptr(V), C, BT, N, pmax, ptr(neg_slot), ptr(Zr), R * C, ptr(rec), 0, st), "row-major")
+    check(lib.cham_combine_fwd_h2b(ptr(U), ptr(V), C, BT, N, pmax, ptr(neg_slot), ptr(Zb), bps, ptr(rec), 1, st), "blocked")
+    un = planes_from_blocked(Zb, tiles, C)
+    assert torch.equal(un[:, :R].view(torch.int16), Zr.view(torch.int16)) and not un[:, R:].any()
+    assert lib.cham_combine_fwd_h2b(ptr(U), ptr(V), C, BT, N, pmax, ptr(neg_slot), ptr(Zb), R * C - 8, ptr(rec), 1, st) == -22      # plane stride < whole tiles
+    if not (32 <= NC <= 256 and C % 64 == 0):
+        return
+    # ---- the fused scorer dgrad
+    dS1 = torch.randn(R, 128, device=gpu, generator=g) * 1e-3
+    Ws1 = torch.randn(C, 128, device=gpu, generator=g) * 0.05
+    Z2c = torch.tanh(torch.randn(R, C, device=gpu, generator=g))
+    pred = torch.tanh(torch.randn(BT, C, device=gpu, generator=g))
+    sc_ws1n, sc_out, sc_ds1 = new_rec(gpu), new_rec(gpu), new_rec(gpu)
+    check(lib.cham_h2_scale_rownorm(ptr(Ws1), C, 128, 128, None, ptr(sc_ws1n), st), "rownorm w")
+    check(lib.cham_h2_scale_rownorm2(ptr(dS1), R, 128, 128, ptr(sc_ws1n[2:]), ptr(sc_out), ptr(sc_ds1), st), "rownorm ds1")
+    Wh = torch.zeros(2, C, 128, dtype=torch.float16, device=gpu)
+    check(lib.cham_split2h(ptr(Ws1), C, 128, 128, ptr(Wh), C * 128, 128, None, 0, 0, ptr(sc_ws1n), 0, st), "split2h")
+    W3 = torch.zeros(3, C, 128, dtype=torch.bfloat16, device=gpu)
+    check(lib.cham_split3(ptr(Ws1), C, 128, 128, ptr(W3), C * 128, 128, None, 0, 0, st), "split3")
+    for f16 in (True, False):
+        outs = []
+        for blk in (0, 1):
+            D = torch.zeros(2, bps, dtype=torch.float16, device=gpu) if blk else torch.zeros(2, R, C, dtype=torch.float16, device=gpu)
+            dpred, b2 = torch.zeros(BT, C, device=gpu), torch.zeros(BT, C, device=gpu)
+            ps = D[0].numel()
+            if blk:
+                check(lib.cham_dm_mulpred_h2_blk(ptr(dS1), 128, 128, ptr(Wh if f16 else W3), C * 128, ptr(sc_ds1) if f16 else None, ptr(sc_ws1n) if f16 else None,
+                                                 ptr(Z2c), ptr(pred), C, BT, N, ptr(D), ps, ptr(sc_out), ptr(dpred), ptr(b2), st), "blk")
+            elif f16:
+                check(lib.cham_dm_mulpred_h2h(ptr(dS1), 128, 128, ptr(Wh), C * 128, ptr(sc_ds1), ptr(sc_ws1n), ptr(Z2c), ptr(pred), C, BT, N, ptr(D), ps,
+                                              ptr(sc_out), ptr(dpred), ptr(b2), st), "h2h")
+            else:
+                check(lib.cham_dm_mulpred_h2(ptr(dS1), 128, 128, ptr(W3), C * 128, ptr(Z2c), ptr(pred), C, BT, N, ptr(D), ps, ptr(sc_out), ptr(dpred), ptr(b2), st), "h2")
+            outs.append((D, dpred, b2))
+        (Dr, dpr, b2r), (Db, dpb, b2b) = outs
+        un = planes_from_blocked(Db, tiles, C)
+        assert Dr.abs().max() > 0
+        assert torch.equal(un[:, :R].view(torch.int16), Dr.view(torch.int16)) and not un[:, R:].any(), f16
+        assert torch.equal(dpr, dpb) and torch.equal(b2r, b2b)

@@ -46,3 +46,15 @@ def test_two_ranks_through_the_drivers_launch_line(gpu, scaling, mode, dtype):
     assert 0.5 < loss[1] < 8.0 and abs(loss[0] - loss[1] - loss[2]) < 1e-3, loss       # a finite, plausible loss assembled from both ranks' shares
     assert d["config"]["rnn_coop_spin_timeouts"] == 0
     assert "roofline" in d and d["roofline"]["frac"] > 0.0
+    # the N > 1 evidence: what the process group was and what the exchange moved / cost
+    dp = d["dp"]
+    assert dp["backend"] == "gloo" and dp["world"] == 2 and len(dp["devices"]) == 2 and dp["mode"] == mode
+    assert dp["distinct_devices"] == 1                              # (this test: two ranks share the box's one GPU; the driver's run must show N)
+    assert dp["grad_dtype"] == ("bf16" if dtype == "bf16" else "f32")
+    assert dp["exchange_bytes_per_step"] > 1_000_000 and dp["exchange_ms"] > 0.0 and dp["exchange_steps_timed"] == 5
+    assert dp["ring_bus_bytes_per_step"] == dp["exchange_bytes_per_step"]          # 2 (N - 1) / N = 1 at N = 2
+    calls = dp["collective_calls_total"]
+    if mode == "sparse_rs":        # the C2 pair really ran, once per step (2 warm-up + 3 timed + roofline / host legs + 5 exchange-timing steps)
+        assert calls["reduce_scatter"] >= 10 and calls["reduce_scatter"] == calls["all_gather"], calls
+    else:
+        assert calls["reduce_scatter"] == 0 and calls["all_reduce"] >= 10, calls

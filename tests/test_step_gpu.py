@@ -517,3 +517,37 @@ def test_step_parity_bf16_with_dropout(gpu):
             assert e_hip < 3.0 * e_emu + 2e-2 * scale + 2e-5, (k, e_hip, e_emu, scale)
         H.update_state(st, f, l)
         model.rt.global_step += 1
+
+
+def test_training_with_tile_blocked_planes_is_bit_identical(gpu, monkeypatch):
+    """CHAM_H2_BLOCKED=1 (round 6: the candidate rows' fp16 planes stored [row tiles of 256][C / 32][256][32]; both producers and the three
+    plane GEMMs in that layout) against the default row-major planes: the SAME four optimizer steps, ragged G1-like batches (valid
+    positions vary from step to step: a row tile keeps rows of an earlier, longer step beyond the current ones - the TN form masks them),
+    bit-identical losses, weights and Adam slots; the launch counters prove the blocked kernels ran."""
+    import ctypes
+    from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
+    p = H.tiny_params(C=256, neg=40)
+    batches = synthetic.make_batches(5, 64, 8, 1000, p['session_features_config'], length_dist='g1')
+    runs, counts = [], []
+    for blocked in ("0", "1"):
+        monkeypatch.setenv("CHAM_H2_BLOCKED", blocked)
+        model, _o = H.make_pair(p)
+        assert model.rt.h2 and model.rt.h2_blocked == (blocked == "1")
+        c = (ctypes.c_longlong * 8)()
+        model.rt.lib.cham_gemm_h2_launch_counts(c, 1)
+        st = DeviceClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'], p['recent_clicks_for_normalization'], 1000)
+        dev = [model.upload_batch(f, l) for f, l in batches]
+        losses = []
+        for i, d in enumerate(dev):
+            model.feed_state(st, st)
+            losses.append(model.train_step(d).clone())
+            st.update_from_device_batch(d['aci'], d['g_event_ts'])
+        torch.cuda.synchronize()
+        model.rt.lib.cham_gemm_h2_launch_counts(c, 0)
+        counts.append(list(c))
+        z1 = model._plan.cand_Z1().cpu()
+        runs.append((torch.stack(losses).cpu(), model.rt.flat.cpu().clone(), model.rt.m.cpu().clone(), model.rt.v.cpu().clone(), z1))
+    assert counts[0][3] == 0 and counts[0][4] == 0
+    assert counts[1][3] == 2 * len(batches) and counts[1][4] == len(batches), counts      # NT forward + dgrad, TN weight gradient per step
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
