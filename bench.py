@@ -469,6 +469,9 @@ def main():
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="timed steps replayed from a hipGraph (nar_model.GraphedTrainStep; bit-identical to the eager step): auto = when the step is "
+                         "capturable (one GPU, full-length sessions, device state) and the capture succeeds, else eager with the reason recorded")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: until it is printed, file descriptor 1 points at stderr, so that nothing a library
@@ -534,8 +537,14 @@ def main():
     dev_batches = [dp.upload(f, l) for f, l in batches]          # inputs resident in HBM before the timed region
     host_clicks = [batch_clicks_for_state(f['item_clicked'], l['label_last_item'], f['event_timestamp']) for f, l in batches]
 
+    graph = {"requested": args.graph, "used": False, "reason": None}
+    gstep = [None]
+
     def one_step(i):
         k = i % n_distinct
+        if gstep[0] is not None:
+            gstep[0].step(dev_batches[k], dev_batches[(k + 1) % n_distinct])
+            return
         if args.state == "device":
             model.feed_state(state, state)                                                              # hook.before_run
             model.train_step(dev_batches[k])
@@ -553,6 +562,28 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    # ---- the timed steps as replays of ONE captured hipGraph (the reference: one session.run per step) when the step is capturable
+    if args.graph != "off":
+        from chameleon_recsys_amd.nar.nar_model import GraphedTrainStep
+        gs = GraphedTrainStep(model, state)
+        k0 = args.warmup % n_distinct
+        why = ("%d ranks (collectives inside the step)" % world) if world > 1 else (gs.supports(dev_batches[k0]) if args.warmup > 0 else "no eager warm-up step")
+        if why is None:
+            try:
+                torch.cuda.synchronize()
+                gstep[0] = gs
+                for i in range(3):               # capture + first replays, untimed (n_distinct more warm-up steps keep the timed loop on the same batches)
+                    one_step(args.warmup + i)
+                for i in range(3, n_distinct):
+                    one_step(args.warmup + i)
+                torch.cuda.synchronize()
+                graph.update(used=True, replays_before_the_clock=gs.replays)
+            except Exception as ex:          # (a failed capture has executed nothing: the eager step carries on)
+                gstep[0], why = None, "capture failed: %s: %s" % (type(ex).__name__, str(ex)[:300])
+        if why is not None:
+            graph["reason"] = why
+            if args.graph == "on":
+                raise SystemExit("--graph on: " + why)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -573,6 +604,15 @@ def main():
         one_step(args.warmup + args.steps + 100 + i)
     host_enqueue_ms = (time.perf_counter() - t_h) / 3 * 1e3
     torch.cuda.synchronize()
+    host_enqueue_eager_ms = host_enqueue_ms
+    if gstep[0] is not None:         # the legs below (per-launch HIP events, arms) drive the EAGER step; its host cost beside the replay's
+        graph["graph_replays_timed"] = gstep[0].replays
+        gstep[0] = None
+        t_h = time.perf_counter()
+        for i in range(3):
+            one_step(args.warmup + args.steps + 103 + i)
+        host_enqueue_eager_ms = (time.perf_counter() - t_h) / 3 * 1e3
+        torch.cuda.synchronize()
 
     # ---- roofline leg: HIP-event timing of every GEMM launch over a few extra steps -------------------------
     rt.profile = []
@@ -764,6 +804,8 @@ def main():
                                 "f32_native": "every GEMM on v_mfma_f32_32x32x2_f32",
                                 "bf16": "bf16-resident candidate-row matrices, fp32 accumulate"}[args.dtype],
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+                       "host_enqueue_ms_per_step_eager": round(host_enqueue_eager_ms, 3),
+                       "hip_graph": graph,
                        "rnn_coop_spin_timeouts": int(rt.rnn_coop_timed_out()),       # bounded spins of the cooperative recurrent kernels (ragged leg): must be 0
                        "final_loss": [round(float(x), 5) for x in loss]},
             "roofline": {"bound": "mfma", "kernel": describe(DOM_SYMBOL, dom) + " - the GEMM symbol with the largest total time in the step",

@@ -105,6 +105,15 @@ _SIGNATURES = {
     "cham_sumsq_partial": (c_int, [P, c_size_t, P, P]),
     "cham_loss_finalize": (c_int, [P, c_int, c_float, P, c_float, P, P]),
     "cham_adam_tf": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    "cham_step_scalars_bytes": (c_int, []),
+    "cham_step_scalars_set": (c_int, [P, c_uint32, c_uint32, c_int64, c_float, c_float, c_int, P]),
+    "cham_neg_sample_dev": (c_int, [P, c_int, c_int, P, c_int, c_uint32, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "cham_step_ints_dev": (c_int, [P, P, P, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P]),
+    "cham_norm_stats_from_buffer_dev": (c_int, [P, c_int, P, P, P, P, P, P]),
+    "cham_score_softmax_bwd_dev": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, P, P, P, c_float, P, P, P, P, P]),
+    "cham_score_softmax_bwd_b16_dev": (c_int, [P, c_int, P, P, P, c_int, c_int, c_float, P, P, P, c_float, P, P, P, P, P]),
+    "cham_loss_finalize_dev": (c_int, [P, c_int, P, P, c_float, P, P]),
+    "cham_adam_tf_dev": (c_int, [P, P, P, P, c_size_t, c_size_t, c_float, P, c_float, c_float, c_float, P]),
     "cham_accumulate": (c_int, [P, P, c_size_t, c_int, P]),
     "cham_loss_accumulate": (c_int, [P, P, c_int, P]),
     "cham_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -33,6 +33,21 @@ static inline int cham_set_dynamic_lds(const void* kernel, int bytes, std::atomi
             return -CHAM_ERR_LAUNCH;                                                                         \
     } while (0)
 
+// ---- STEP SCALARS in device memory (round 6).  The launch parameters of a step that change from one optimizer step to the next - the
+// sampler key, the batch's max time stamp, sum(mask), Adam's bias-corrected learning rate - live in ONE 32-byte device record written by
+// cham_step_scalars_set (a one-thread kernel taking them by value).  The `*_dev` entry points read them from the record instead of taking
+// them by value, so that a step's launches carry no per-step host value: the step can be captured in a hipGraph once and replayed
+// (reference: one session.run per step, nar_model.py:1434-1470).  Same arithmetic on the same values: results are bit-identical to the
+// by-value entry points.
+struct ChamStepScalars {
+    uint32_t step;            // sampler key of this step (global_step, or the evaluation key)
+    uint32_t step_next;       // ... of the NEXT step (presampling of the next batch's negatives)
+    int64_t max_ts;           // max event time stamp of the (global) batch, nar_model.py:235
+    int64_t max_ts_next;      // reserved
+    float sum_mask;           // sum(mask) of the (global) batch: the loss denominator, nar_model.py:664
+    float lr_t;               // lr * sqrt(1 - b2^t) / (1 - b1^t), tf.train.AdamOptimizer
+};
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

@@ -86,9 +86,11 @@ __global__ __launch_bounds__(256) void k_item_dynamic_raw(const int64_t* __restr
 // same, for the "last N recent clicks" used as normalisation population (nar_model.py:1066-1071, 1156-1158)
 __global__ __launch_bounds__(256) void k_last_dynamic_raw(const int64_t* __restrict__ last_ids, int n, int64_t max_ts,
                                                           const int64_t* __restrict__ created, const float* __restrict__ pop_norm,
-                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw, float ln_e, float ln_p) {
+                                                          float* __restrict__ rec_raw, float* __restrict__ nov_raw, float ln_e, float ln_p,
+                                                          const ChamStepScalars* __restrict__ sc) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
+    if (sc) max_ts = sc->max_ts;
     const int64_t id = last_ids[r];
     rec_raw[r] = recency_raw(max_ts, created[id], ln_e);
     nov_raw[r] = novelty_raw(pop_norm[id], ln_p);
@@ -594,7 +596,7 @@ extern "C" int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, 
     if (!last_ids || n_last <= 0 || !created || !pop_norm || !scratch || !stats) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_last + 255) / 256), dim3(256), 0, st, last_ids, n_last, max_ts, created,
-                       pop_norm, scratch, scratch + n_last, g_cham_ln_elapsed_base, g_cham_ln_pop_base);
+                       pop_norm, scratch, scratch + n_last, g_cham_ln_elapsed_base, g_cham_ln_pop_base, (const ChamStepScalars*)nullptr);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)nullptr, n_last, stats, 3);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_last, (const float*)nullptr, n_last, stats + 4, 3);
     CHAM_CHECK_LAUNCH();
@@ -603,18 +605,28 @@ extern "C" int cham_norm_stats_from_recent(const int64_t* last_ids, int n_last, 
 
 // same statistics straight from the device-resident recent-clicks buffer (csrc/state.hip): population = the first
 // min(n_prefix, #valid) entries (valid entries are a zero-padded prefix; nar_model.py:1041-1044).  scratch: 3 * n_prefix floats.
-extern "C" int cham_norm_stats_from_buffer(const int64_t* buffer_ids, int n_prefix, int64_t max_ts, const int64_t* created,
-                                           const float* pop_norm, float* scratch, float* stats /*[3][8]*/, void* stream) {
+static int norm_stats_from_buffer_impl(const int64_t* buffer_ids, int n_prefix, int64_t max_ts, const int64_t* created,
+                                       const float* pop_norm, float* scratch, float* stats /*[3][8]*/, const void* scalars, void* stream) {
     if (!buffer_ids || n_prefix <= 0 || !created || !pop_norm || !scratch || !stats) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     float* w = scratch + 2 * (size_t)n_prefix;
     hipLaunchKernelGGL(k_nonzero_weights, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, w);
     hipLaunchKernelGGL(k_last_dynamic_raw, dim3((n_prefix + 255) / 256), dim3(256), 0, st, buffer_ids, n_prefix, max_ts, created,
-                       pop_norm, scratch, scratch + n_prefix, g_cham_ln_elapsed_base, g_cham_ln_pop_base);
+                       pop_norm, scratch, scratch + n_prefix, g_cham_ln_elapsed_base, g_cham_ln_pop_base, reinterpret_cast<const ChamStepScalars*>(scalars));
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch, (const float*)w, n_prefix, stats, 3);
     hipLaunchKernelGGL(k_norm_stats, dim3(1), dim3(1024), 0, st, scratch + n_prefix, (const float*)w, n_prefix, stats + 4, 3);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_norm_stats_from_buffer(const int64_t* buffer_ids, int n_prefix, int64_t max_ts, const int64_t* created,
+                                           const float* pop_norm, float* scratch, float* stats /*[3][8]*/, void* stream) {
+    return norm_stats_from_buffer_impl(buffer_ids, n_prefix, max_ts, created, pop_norm, scratch, stats, nullptr, stream);
+}
+// max_ts from the ChamStepScalars record (device; common.h)
+extern "C" int cham_norm_stats_from_buffer_dev(const int64_t* buffer_ids, int n_prefix, const void* scalars, const int64_t* created,
+                                               const float* pop_norm, float* scratch, float* stats /*[3][8]*/, void* stream) {
+    if (!scalars) return -CHAM_ERR_ARG;
+    return norm_stats_from_buffer_impl(buffer_ids, n_prefix, 0, created, pop_norm, scratch, stats, scalars, stream);
 }
 
 // stats from the call's own rows (empty buffer = very first batch): one group at a time
@@ -816,8 +828,9 @@ __global__ __launch_bounds__(256) void k_step_ints(const int64_t* __restrict__ i
                                                    const int64_t* __restrict__ ets, int64_t max_ts, int BT, int pmax,
                                                    const int32_t* __restrict__ seq_len_in, int B, const unsigned char* __restrict__ mask_in,
                                                    int64_t* __restrict__ ids_all, int64_t* __restrict__ ref_ts, int32_t* __restrict__ seq_len,
-                                                   unsigned char* __restrict__ mask) {
+                                                   unsigned char* __restrict__ mask, const ChamStepScalars* __restrict__ sc) {
     const int i = blockIdx.x * 256 + threadIdx.x, RV = 2 * BT + pmax + 1;
+    if (sc) max_ts = sc->max_ts;
     if (i < RV) {
         int64_t id;
         if (i < BT) id = ic[i];
@@ -831,14 +844,26 @@ __global__ __launch_bounds__(256) void k_step_ints(const int64_t* __restrict__ i
     if (i < BT) mask[i] = mask_in[i];
 }
 
-extern "C" int cham_step_ints(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, int64_t max_ts, int BT,
-                              int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts,
-                              int32_t* seq_len, uint8_t* mask, void* stream) {
+static int step_ints_impl(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, int64_t max_ts, int BT,
+                          int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts,
+                          int32_t* seq_len, uint8_t* mask, const void* scalars, void* stream) {
     if (!ic_rows || !ln_rows || !pool || !ets_rows || !seq_len_in || !mask_in || !ids_all || !ref_ts || !seq_len || !mask || BT < 0 || pmax < 0 || B < 0)
         return -CHAM_ERR_ARG;
     const int n = 2 * BT + pmax + 1 > B ? 2 * BT + pmax + 1 : B;
     hipLaunchKernelGGL(k_step_ints, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ic_rows, ln_rows, pool, ets_rows, max_ts, BT, pmax,
-                       seq_len_in, B, mask_in, ids_all, ref_ts, seq_len, mask);
+                       seq_len_in, B, mask_in, ids_all, ref_ts, seq_len, mask, reinterpret_cast<const ChamStepScalars*>(scalars));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_step_ints(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, int64_t max_ts, int BT,
+                              int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts,
+                              int32_t* seq_len, uint8_t* mask, void* stream) {
+    return step_ints_impl(ic_rows, ln_rows, pool, ets_rows, max_ts, BT, pmax, seq_len_in, B, mask_in, ids_all, ref_ts, seq_len, mask, nullptr, stream);
+}
+// max_ts from the ChamStepScalars record (device; common.h)
+extern "C" int cham_step_ints_dev(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, const void* scalars, int BT,
+                                  int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts,
+                                  int32_t* seq_len, uint8_t* mask, void* stream) {
+    if (!scalars) return -CHAM_ERR_ARG;
+    return step_ints_impl(ic_rows, ln_rows, pool, ets_rows, 0, BT, pmax, seq_len_in, B, mask_in, ids_all, ref_ts, seq_len, mask, scalars, stream);
 }

@@ -10,7 +10,8 @@
 
 __global__ __launch_bounds__(256) void k_adam_tf(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, size_t n4, size_t n_reg4, float lambda, float lr_t,
-                                                 float b1, float b2, float eps) {
+                                                 float b1, float b2, float eps, const ChamStepScalars* __restrict__ sc) {
+    if (sc) lr_t = sc->lr_t;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -46,8 +47,9 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__
 // loss[0] = xe + reg, loss[1] = xe = sum(nll)/sum_mask, loss[2] = reg = lambda/2 * sum(w^2)
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ nll, int BT, float inv_sum_mask,
                                                        const float* __restrict__ sumsq_partial, int n_partial, float lambda,
-                                                       float* __restrict__ loss) {
+                                                       float* __restrict__ loss, const ChamStepScalars* __restrict__ sc) {
     __shared__ float red[4];
+    if (sc) inv_sum_mask = 1.0f / sc->sum_mask;       // (the by-value entry point computes the same fp32 quotient on the host)
     float s = 0.f;
     for (int i = threadIdx.x; i < BT; i += 256) s += nll[i];
     s = block_sum(s, red);
@@ -131,18 +133,46 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
     }
 }
 
-extern "C" int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
-                            float lr_t, float beta1, float beta2, float eps, void* stream) {
+// scalars != NULL: lr_t is read from the ChamStepScalars record (device) instead of the argument
+static int adam_tf_impl(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
+                        float lr_t, float beta1, float beta2, float eps, const void* scalars, void* stream) {
     if (!params || !grads || !m || !v || (n & 3) || (n_reg & 3) || n_reg > n) return -CHAM_ERR_ARG;
     const size_t n4 = n / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks == 0) return CHAM_OK;
     hipLaunchKernelGGL(k_adam_tf, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n4, n_reg / 4,
-                       lambda, lr_t, beta1, beta2, eps);
+                       lambda, lr_t, beta1, beta2, eps, reinterpret_cast<const ChamStepScalars*>(scalars));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }
+extern "C" int cham_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
+                            float lr_t, float beta1, float beta2, float eps, void* stream) {
+    return adam_tf_impl(params, grads, m, v, n, n_reg, lambda, lr_t, beta1, beta2, eps, nullptr, stream);
+}
+extern "C" int cham_adam_tf_dev(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda,
+                                const void* scalars, float beta1, float beta2, float eps, void* stream) {
+    if (!scalars) return -CHAM_ERR_ARG;
+    return adam_tf_impl(params, grads, m, v, n, n_reg, lambda, 0.f, beta1, beta2, eps, scalars, stream);
+}
+
+// ---- the step-scalar record (common.h ChamStepScalars): written by a one-thread kernel that takes the values BY VALUE (a kernel's
+// parameters are copied at launch: no host staging buffer to keep alive), stream-ordered in front of the step that reads them
+__global__ void k_step_scalars_set(ChamStepScalars* __restrict__ rec, uint32_t step, uint32_t step_next, int64_t max_ts, float sum_mask, float lr_t,
+                                   int fields) {
+    if (fields & 1) { rec->step = step; rec->step_next = step_next; }
+    if (fields & 2) { rec->max_ts = max_ts; rec->sum_mask = sum_mask; }
+    if (fields & 4) rec->lr_t = lr_t;
+}
+// fields: bit 0 = the sampler keys, bit 1 = the batch scalars (max_ts, sum_mask), bit 2 = lr_t (the others are left as they are)
+extern "C" int cham_step_scalars_set(void* rec, uint32_t step, uint32_t step_next, int64_t max_ts, float sum_mask, float lr_t, int fields, void* stream) {
+    if (!rec || ((uintptr_t)rec & 7) || !(fields & 7)) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_step_scalars_set, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<ChamStepScalars*>(rec), step, step_next, max_ts,
+                       sum_mask, lr_t, fields);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" int cham_step_scalars_bytes(void) { return (int)sizeof(ChamStepScalars); }
 
 extern "C" int cham_sumsq_partial(const float* params, size_t n_reg, float* partial /*[1024]*/, void* stream) {
     if (!params || !partial || (n_reg & 3)) return -CHAM_ERR_ARG;
@@ -155,7 +185,16 @@ extern "C" int cham_loss_finalize(const float* nll, int BT, float sum_mask, cons
                                   float* loss /*[3]*/, void* stream) {
     if (!nll || !sumsq_partial || !loss || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, BT, 1.0f / sum_mask, sumsq_partial,
-                       SUMSQ_BLOCKS, lambda, loss);
+                       SUMSQ_BLOCKS, lambda, loss, (const ChamStepScalars*)nullptr);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+// sum(mask) from the ChamStepScalars record (device)
+extern "C" int cham_loss_finalize_dev(const float* nll, int BT, const void* scalars, const float* sumsq_partial, float lambda,
+                                      float* loss /*[3]*/, void* stream) {
+    if (!nll || !sumsq_partial || !loss || BT <= 0 || !scalars) return -CHAM_ERR_ARG;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, BT, 0.f, sumsq_partial,
+                       SUMSQ_BLOCKS, lambda, loss, reinterpret_cast<const ChamStepScalars*>(scalars));
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

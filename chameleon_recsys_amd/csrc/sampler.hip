@@ -15,10 +15,12 @@
 // n <= buffer size (20 000): ~40 us, deterministic, no global sort needed.
 #include "common.h"
 
+// (step_dev != NULL: the key of the step is read from device memory - a ChamStepScalars field, common.h - instead of the argument)
 __global__ __launch_bounds__(256) void k_keys_buffer(const int64_t* __restrict__ buf, int n, uint64_t* __restrict__ keys,
-                                                     uint32_t seed, uint32_t step) {
+                                                     uint32_t seed, uint32_t step, const uint32_t* __restrict__ step_dev) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (step_dev) step = *step_dev;
     keys[i] = buf[i] != 0 ? philox_sort_key((uint32_t)i, 0u, 0u, 0u, seed, step) : CHAM_INF_KEY;
 }
 
@@ -26,9 +28,10 @@ __global__ __launch_bounds__(256) void k_keys_buffer(const int64_t* __restrict__
 __global__ __launch_bounds__(256) void k_keys_pool(const int64_t* __restrict__ aci, int n_aci,
                                                    const int64_t* __restrict__ buf_sample, int n_slots,
                                                    int64_t* __restrict__ cat_vals, uint64_t* __restrict__ keys,
-                                                   uint32_t seed, uint32_t step) {
+                                                   uint32_t seed, uint32_t step, const uint32_t* __restrict__ step_dev) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_aci + n_slots) return;
+    if (step_dev) step = *step_dev;
     const int64_t v = i < n_aci ? aci[i] : buf_sample[i - n_aci];
     cat_vals[i] = v;
     keys[i] = v != 0 ? philox_sort_key((uint32_t)i, 0u, 0u, 1u, seed, step) : CHAM_INF_KEY;
@@ -115,8 +118,9 @@ __global__ __launch_bounds__(256) void k_click_select(const int64_t* __restrict_
                                                       const int64_t* __restrict__ pool, const int* __restrict__ canon,
                                                       const int* __restrict__ pcount, int pmax, int pp /*pow2 >= pmax*/,
                                                       int N, uint32_t seed, uint32_t step,
-                                                      int64_t* __restrict__ neg_ids, int* __restrict__ neg_slot) {
+                                                      int64_t* __restrict__ neg_ids, int* __restrict__ neg_slot, const uint32_t* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (step_dev) step = *step_dev;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);            // [pp]
     int64_t* sess = reinterpret_cast<int64_t*>(keys + pp);             // [T1]
     const int j = blockIdx.x, bl = blockIdx.y, b = row_begin + bl;
@@ -174,10 +178,10 @@ extern "C" size_t cham_neg_sample_workspace_bytes(int n_aci, int buf_size, int n
     return align256((size_t)buf_size * 8) + align256((size_t)n_from_buffer * 8) + align256(ncat * 8) * 2 + align256(nmax * 4) + 256;
 }
 
-extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size,
-                               uint32_t seed, uint32_t step, int row_begin, int row_count, int N, int n_from_buffer,
-                               int64_t* neg_ids, int32_t* neg_slot, int64_t* pool, int32_t* canon, int32_t* meta,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+static int neg_sample_impl(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size,
+                           uint32_t seed, uint32_t step, const uint32_t* step_dev, int row_begin, int row_count, int N, int n_from_buffer,
+                           int64_t* neg_ids, int32_t* neg_slot, int64_t* pool, int32_t* canon, int32_t* meta,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!aci || !buffer || !neg_ids || !neg_slot || !pool || !canon || !meta || !workspace) return -CHAM_ERR_ARG;
     if (Bg <= 0 || T1 < 2 || N <= 0 || n_from_buffer < 0 || row_begin < 0 || row_begin + row_count > Bg) return -CHAM_ERR_ARG;
     const int n_aci = Bg * T1;
@@ -200,7 +204,7 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
     if (n_from_buffer > 0 && hipMemsetAsync(buf_sample, 0, (size_t)n_from_buffer * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (hipMemsetAsync(pool, 0, (size_t)pmax * 8, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     if (buf_size > 0 && n_from_buffer > 0) {
-        hipLaunchKernelGGL(k_keys_buffer, dim3((buf_size + 255) / 256), dim3(256), 0, st, buffer, buf_size, keys0, seed, step);
+        hipLaunchKernelGGL(k_keys_buffer, dim3((buf_size + 255) / 256), dim3(256), 0, st, buffer, buf_size, keys0, seed, step, step_dev);
         if (hipMemsetAsync(rank, 0, (size_t)buf_size * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
         hipLaunchKernelGGL(k_sel_count_valid, dim3((buf_size + 255) / 256), dim3(256), 0, st, keys0, buf_size, sel);
         hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(64), 0, st, sel, n_from_buffer);
@@ -211,7 +215,7 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
                            n_from_buffer, buf_sample, meta + 1, sel);
     }
     hipLaunchKernelGGL(k_keys_pool, dim3((ncat + 255) / 256), dim3(256), 0, st, aci, n_aci, buf_sample, n_from_buffer,
-                       cat_vals, keys1, seed, step);
+                       cat_vals, keys1, seed, step, step_dev);
     if (hipMemsetAsync(rank, 0, (size_t)ncat * 4, st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_sel_count_valid, dim3((ncat + 255) / 256), dim3(256), 0, st, keys1, ncat, sel + 4);
     hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(64), 0, st, sel + 4, pmax);
@@ -227,8 +231,26 @@ extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t
         const size_t smem = (size_t)pp * 8 + (size_t)T1 * 8;
         CHAM_SET_DYNAMIC_LDS(k_click_select, 150 * 1024);
         hipLaunchKernelGGL(k_click_select, dim3(T1 - 1, row_count), dim3(256), smem, st, aci, T1, row_begin, pool, canon,
-                           meta + 3, pmax, pp, N, seed, step, neg_ids, neg_slot);
+                           meta + 3, pmax, pp, N, seed, step, neg_ids, neg_slot, step_dev);
     }
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+extern "C" int cham_neg_sample(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size,
+                               uint32_t seed, uint32_t step, int row_begin, int row_count, int N, int n_from_buffer,
+                               int64_t* neg_ids, int32_t* neg_slot, int64_t* pool, int32_t* canon, int32_t* meta,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return neg_sample_impl(aci, Bg, T1, buffer, buf_size, seed, step, nullptr, row_begin, row_count, N, n_from_buffer, neg_ids, neg_slot, pool, canon, meta,
+                           workspace, workspace_bytes, stream);
+}
+// the step's key from the ChamStepScalars record `scalars` (device; common.h): which = 0 -> .step, 1 -> .step_next (the NEXT step's negatives,
+// drawn behind the current step: NARModuleModel.presample)
+extern "C" int cham_neg_sample_dev(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size,
+                                   uint32_t seed, const void* scalars, int which, int row_begin, int row_count, int N, int n_from_buffer,
+                                   int64_t* neg_ids, int32_t* neg_slot, int64_t* pool, int32_t* canon, int32_t* meta,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!scalars || (which != 0 && which != 1)) return -CHAM_ERR_ARG;
+    const ChamStepScalars* sc = reinterpret_cast<const ChamStepScalars*>(scalars);
+    return neg_sample_impl(aci, Bg, T1, buffer, buf_size, seed, 0u, which ? &sc->step_next : &sc->step, row_begin, row_count, N, n_from_buffer, neg_ids,
+                           neg_slot, pool, canon, meta, workspace, workspace_bytes, stream);
 }

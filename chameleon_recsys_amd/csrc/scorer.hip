@@ -537,10 +537,12 @@ __global__ __launch_bounds__(256) void k_score_softmax_bwd(const T* __restrict__
                                                            float* __restrict__ ds, T* __restrict__ dS3, float nov_factor,
                                                            const int64_t* __restrict__ neg_ids, const float* __restrict__ pop_norm,
                                                            const float* __restrict__ logits, float inv_tau,
-                                                           const float* __restrict__ nov_aux, float inv_log2_base) {
+                                                           const float* __restrict__ nov_aux, float inv_log2_base,
+                                                           const ChamStepScalars* __restrict__ sc, float tau) {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int NC = N + 1;
     if (row >= (size_t)BT * NC) return;
+    if (sc) scale = 1.0f / (tau * sc->sum_mask);       // (the by-value entry points compute the same fp32 expression on the host)
     const int bt = (int)(row / NC), c = (int)(row % NC);
     float g = mask[bt] ? (probs[row] - (c == 0 ? 1.f : 0.f)) * scale : 0.f;
     if (nov_factor > 0.f && c > 0 && mask[bt]) {
@@ -767,15 +769,32 @@ template <typename T>
 static int score_softmax_bwd_impl(const T* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
                                   int BT, int N, float tau, float sum_mask, float* ds, T* dS3, float novelty_reg_factor,
                                   const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
-                                  void* stream) {
-    if (!S3 || !w4 || !probs || !mask || !ds || !dS3 || K3 != 32 || BT <= 0 || sum_mask <= 0.f) return -CHAM_ERR_ARG;
+                                  void* stream, const void* scalars = nullptr) {
+    if (!S3 || !w4 || !probs || !mask || !ds || !dS3 || K3 != 32 || BT <= 0 || (!scalars && sum_mask <= 0.f)) return -CHAM_ERR_ARG;
     if (novelty_reg_factor > 0.f && (!neg_ids || !pop_norm || !logits || !nov_aux)) return -CHAM_ERR_ARG;
     const size_t rows = (size_t)BT * (N + 1);
     hipLaunchKernelGGL((k_score_softmax_bwd<32, T>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S3, w4,
-                       probs, mask, BT, N, 1.0f / (tau * sum_mask), ds, dS3, novelty_reg_factor, neg_ids, pop_norm, logits,
-                       1.0f / tau, nov_aux, g_cham_inv_log2_pop_base);
+                       probs, mask, BT, N, scalars ? 0.f : 1.0f / (tau * sum_mask), ds, dS3, novelty_reg_factor, neg_ids, pop_norm, logits,
+                       1.0f / tau, nov_aux, g_cham_inv_log2_pop_base, reinterpret_cast<const ChamStepScalars*>(scalars), tau);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
+}
+// sum(mask) from the ChamStepScalars record (device; common.h)
+extern "C" int cham_score_softmax_bwd_dev(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                          int BT, int N, float tau, const void* scalars, float* ds, float* dS3, float novelty_reg_factor,
+                                          const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                          void* stream) {
+    if (!scalars) return -CHAM_ERR_ARG;
+    return score_softmax_bwd_impl<float>(S3, K3, w4, probs, mask, BT, N, tau, 0.f, ds, dS3, novelty_reg_factor, neg_ids, pop_norm,
+                                         logits, nov_aux, stream, scalars);
+}
+extern "C" int cham_score_softmax_bwd_b16_dev(const void* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
+                                              int BT, int N, float tau, const void* scalars, float* ds, void* dS3, float novelty_reg_factor,
+                                              const int64_t* neg_ids, const float* pop_norm, const float* logits, const float* nov_aux,
+                                              void* stream) {
+    if (!scalars) return -CHAM_ERR_ARG;
+    return score_softmax_bwd_impl<__bf16>(reinterpret_cast<const __bf16*>(S3), K3, w4, probs, mask, BT, N, tau, 0.f, ds,
+                                          reinterpret_cast<__bf16*>(dS3), novelty_reg_factor, neg_ids, pop_norm, logits, nov_aux, stream, scalars);
 }
 extern "C" int cham_score_softmax_bwd(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask,
                                       int BT, int N, float tau, float sum_mask, float* ds, float* dS3, float novelty_reg_factor,

@@ -179,6 +179,14 @@ class NARRuntime:
         self.v = torch.zeros_like(self.flat)
         self.grads = torch.zeros_like(self.flat)
         self.global_step = 0
+        # The launch parameters that change from step to step (sampler key, the batch's max time stamp, sum(mask), Adam's lr_t) live in a
+        # 32-byte DEVICE record (csrc/common.h ChamStepScalars, include/chameleon_nar.h "STEP SCALARS"), written by set_step_scalars() in
+        # front of the step: the step's launches then carry no per-step host value and can be captured in a hipGraph (GraphedTrainStep).
+        # CHAM_DEV_SCALARS=0: the by-value entry points (A/B arm; bit-identical results).  capturing: a graph capture is in progress - the
+        # record is NOT written by the step's code (the replay writes it in front of every launch of the graph).
+        self.dev_scalars = os.environ.get("CHAM_DEV_SCALARS", "1") == "1"
+        self.capturing = False
+        self.scalars = None
         # 'f32': exact fp32 MFMA (BASELINE config 2, the default); 'bf16': operands of every Dense / matmul rounded to bf16 on
         # the fly, fp32 accumulation, fp32 storage / softmax / loss / Adam (BASELINE config 3)
         self.gemm_dtype = params.get('gemm_dtype', 'f32')
@@ -598,6 +606,16 @@ class NARRuntime:
         ws = self._lane_ws('colsum_ws')
         check((self.lib.cham_colsum_b16 if b16 else self.lib.cham_colsum)(ptr(X), ld, R, F, ptr(w), ptr(out), accumulate, ptr(ws),
                                                                            ws.numel() * 4, _stream()), "cham_colsum")
+
+    def set_step_scalars(self, step=0, max_ts=0, sum_mask=1.0, lr_t=0.0, fields=7, stream=None):
+        """Writes the selected fields of the step-scalar record (fields: 1 = sampler keys (step, step + 1), 2 = max_ts + sum_mask, 4 = lr_t) on
+        `stream` (default: the current one), in stream order in front of the launches that read it.  No-op during a graph capture."""
+        if self.capturing:
+            return
+        if self.scalars is None:
+            self.scalars = torch.zeros(max(8, self.lib.cham_step_scalars_bytes() // 4), dtype=torch.int32, device=self.device)
+        check(self.lib.cham_step_scalars_set(ptr(self.scalars), int(step) & 0xFFFFFFFF, (int(step) + 1) & 0xFFFFFFFF, int(max_ts), float(sum_mask),
+                                             float(lr_t), fields, _stream() if stream is None else stream), "cham_step_scalars_set")
 
     def side(self):
         """Context manager: run the enclosed launches on the side stream (or inline when overlap is disabled)."""
@@ -1050,6 +1068,10 @@ class NARModuleModel:
                 block.record_stream(main)         # allocated on the upload stream, consumed on the compute stream
             for k, a in arrs.items():
                 out[k] = block[offs[k]:offs[k] + a.nbytes].view(_TORCH_DTYPE[a.dtype.str]).view(a.shape)
+            # the packed device block and its layout: a batch of the same shape can be copied into a persistent input slot with ONE
+            # device-to-device copy (GraphedTrainStep)
+            out['_block'], out['_total'] = block, total
+            out['_layout'] = tuple((k, offs[k], a.dtype.str, a.shape) for k, a in arrs.items())
         else:
             for k, a in arrs.items():
                 x = torch.from_numpy(a)
@@ -1066,9 +1088,16 @@ class NARModuleModel:
             ring.end(up if up is not None else main)
         return out
 
-    def _neg_sample(self, pl, d, step, k, stream):
-        """K0 negative sampling (nar_model.py:265-276) of batch d with key `step` into the plan's sampler-output set k."""
+    def _neg_sample(self, pl, d, step, k, stream, which=None):
+        """K0 negative sampling (nar_model.py:265-276) of batch d with key `step` into the plan's sampler-output set k.  which = 0 / 1: the key
+        is the .step / .step_next field of the runtime's step-scalar record (device) instead of the argument."""
         rt, st, o = self.rt, self._dev_state, pl._samp[k]
+        if which is not None:
+            check(rt.lib.cham_neg_sample_dev(ptr(d['aci']), d['Bg'], d['T'] + 1, ptr(st['buffer']), st['buffer'].numel(),
+                                             rt.tf_random_seed, ptr(rt.scalars), which, d['row_begin'], d['B'], self.negative_samples,
+                                             self.negative_sample_from_buffer, ptr(o['neg_ids']), ptr(o['neg_slot']), ptr(o['pool']),
+                                             ptr(o['canon']), ptr(o['meta']), ptr(pl.sampler_ws), pl.ws_bytes, stream), "cham_neg_sample_dev")
+            return
         check(rt.lib.cham_neg_sample(ptr(d['aci']), d['Bg'], d['T'] + 1, ptr(st['buffer']), st['buffer'].numel(),
                                      rt.tf_random_seed, step, d['row_begin'], d['B'], self.negative_samples,
                                      self.negative_sample_from_buffer, ptr(o['neg_ids']), ptr(o['neg_slot']), ptr(o['pool']),
@@ -1085,11 +1114,14 @@ class NARModuleModel:
             return False
         pl = rt.plan(d['B'], d['T'], self.negative_samples, self.negative_sample_from_buffer, d['Bg'])
         k, step = 1 - pl._samp_cur, rt.global_step
-        state.stream.wait_event(pl.created)
-        state.stream.wait_event(d['uploaded'])
-        d['aci'].record_stream(state.stream)
+        if not rt.capturing:      # (events recorded outside a capture are not waited for inside one: the replay is stream-ordered behind them)
+            state.stream.wait_event(pl.created)
+            if d.get('uploaded') is not None:
+                state.stream.wait_event(d['uploaded'])
+            d['aci'].record_stream(state.stream)
         with torch.cuda.stream(state.stream):      # in order behind the state update it must see
-            self._neg_sample(pl, d, step, k, state.stream.cuda_stream)
+            # (captured step: the key is the record's .step_next - this call runs behind the step whose key is .step)
+            self._neg_sample(pl, d, step, k, state.stream.cuda_stream, which=1 if rt.capturing else None)
             ev = torch.cuda.Event()
             ev.record()
         d['_presampled'] = (pl, k, step, ev)
@@ -1113,7 +1145,8 @@ class NARModuleModel:
         self._plan, self._d = pl, d
         pl.used_p3 = False
         check(lib.cham_set_log_bases(self.elapsed_days_smooth_log_base, self.popularity_smooth_log_base), "cham_set_log_bases")
-        torch.cuda.current_stream().wait_event(d['uploaded'])
+        if d.get('uploaded') is not None:
+            torch.cuda.current_stream().wait_event(d['uploaded'])
         s = _stream()
         # weight shadows (planes of W2 / W2^T, the row-norm bound of Ws1, bf16 shadows): four small launches that depend on the weights only -
         # on the side lane (idle at the head of a step) behind the previous step's Adam, beside this lane's feature kernels (round 4: the
@@ -1137,11 +1170,15 @@ class NARModuleModel:
         # K0 negative sampling (nar_model.py:265-276) - unless presample() already drew this batch's negatives for this key
         _roctx.push("K0 negative sampling")
         ps = d.pop('_presampled', None)
+        dsc = rt.dev_scalars          # per-step launch scalars from the device record (NARRuntime.__init__)
+        if dsc:
+            rt.set_step_scalars(step, d['max_ts'], d['sum_mask'], fields=3, stream=s)
         if ps is not None and ps[0] is pl and ps[2] == step and st.get('device'):
             pl.use_sampler_set(ps[1])
-            torch.cuda.current_stream().wait_event(ps[3])
+            if ps[3] is not None:
+                torch.cuda.current_stream().wait_event(ps[3])
         else:
-            self._neg_sample(pl, d, step, pl._samp_cur, s)
+            self._neg_sample(pl, d, step, pl._samp_cur, s, which=0 if dsc else None)
         if rt.dp_mode in ('sparse', 'sparse_rs') and getattr(rt, 'dp_active', rt.dp_world > 1):
             # item rows this step can touch on ANY rank (parallel.py, mode "sparse"): GLOBAL clicked ids + candidate pool + pad item,
             # as int32 row indices in a buffer of the plan (nothing is allocated or freed around the collective)
@@ -1165,8 +1202,12 @@ class NARModuleModel:
         # K1 item row set = [clicked ; positives ; pool slots ; pad item 0]
         _roctx.pop(); _roctx.push("K1 features (gather, normalise, scale / center)")
         # (one launch - round 5: eight copy / fill launches before - also seq_len and the position mask of the stages below)
-        check(lib.cham_step_ints(ptr(d['ic_rows']), ptr(d['ln_rows']), ptr(pl.pool), ptr(d['ets_rows']), int(d['max_ts']), BT, pmax, ptr(d['seq_len']),
-                                 B, ptr(d['mask']), ptr(pl.ids_all), ptr(pl.ref_ts), ptr(pl.seq_len), ptr(pl.mask), s), "cham_step_ints")
+        if dsc:
+            check(lib.cham_step_ints_dev(ptr(d['ic_rows']), ptr(d['ln_rows']), ptr(pl.pool), ptr(d['ets_rows']), ptr(rt.scalars), BT, pmax, ptr(d['seq_len']),
+                                         B, ptr(d['mask']), ptr(pl.ids_all), ptr(pl.ref_ts), ptr(pl.seq_len), ptr(pl.mask), s), "cham_step_ints_dev")
+        else:
+            check(lib.cham_step_ints(ptr(d['ic_rows']), ptr(d['ln_rows']), ptr(pl.pool), ptr(d['ets_rows']), int(d['max_ts']), BT, pmax, ptr(d['seq_len']),
+                                     B, ptr(d['mask']), ptr(pl.ids_all), ptr(pl.ref_ts), ptr(pl.seq_len), ptr(pl.mask), s), "cham_step_ints")
         pl.grouped_ev = None
         if self.is_training:      # rows of equal id made contiguous: the embedding-gradient sums of the backward pass (depends on ids only)
             if rt.overlap:        # ~10 launches nobody needs before the end of the backward: on the side lane, behind the id copies above
@@ -1183,7 +1224,11 @@ class NARModuleModel:
                                           pl.group_ws.numel() * 4, s), "cham_group_rows")
         check(lib.cham_item_dynamic_raw(ptr(pl.ids_all), ptr(pl.ref_ts), RV, ptr(rt.created), ptr(st['pop_norm']),
                                         ptr(pl.rec_raw), ptr(pl.nov_raw), s), "cham_item_dynamic_raw")
-        if st['n_last'] > 0 and st.get('device'):
+        if st['n_last'] > 0 and st.get('device') and dsc:
+            check(lib.cham_norm_stats_from_buffer_dev(ptr(st['last']), st['n_last'], ptr(rt.scalars), ptr(rt.created),
+                                                      ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
+                  "cham_norm_stats_from_buffer_dev")
+        elif st['n_last'] > 0 and st.get('device'):
             check(lib.cham_norm_stats_from_buffer(ptr(st['last']), st['n_last'], d['max_ts'], ptr(rt.created),
                                                   ptr(st['pop_norm']), ptr(pl.stat_scratch), ptr(pl.stats), s),
                   "cham_norm_stats_from_buffer")
@@ -1336,8 +1381,12 @@ class NARModuleModel:
                           ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
                           ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
         check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
-        check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
-              "cham_loss_finalize")
+        if dsc:
+            check(lib.cham_loss_finalize_dev(ptr(pl.nll), BT, ptr(rt.scalars), ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
+                  "cham_loss_finalize_dev")
+        else:
+            check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
+                  "cham_loss_finalize")
         _roctx.pop()
         self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
         if not self.is_training and st.get('device'):
@@ -1403,10 +1452,16 @@ class NARModuleModel:
 
         rt.grads[:L.emb_end].zero_()
         e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
-        check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
-            ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), d['sum_mask'],
-            ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
-            ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
+        if rt.dev_scalars:      # sum(mask) from the step-scalar record (written by this step's forward)
+            check((lib.cham_score_softmax_bwd_b16_dev if b16 else lib.cham_score_softmax_bwd_dev)(
+                ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), ptr(rt.scalars),
+                ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
+                ptr(pl.nov_aux), s), "cham_score_softmax_bwd_dev")
+        else:
+            check((lib.cham_score_softmax_bwd_b16 if b16 else lib.cham_score_softmax_bwd)(
+                ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), d['sum_mask'],
+                ptr(pl.ds), ptr(pl.dS3), self.novelty_reg_factor, ptr(neg_ids), ptr(self._dev_state['pop_norm']), ptr(pl.logits),
+                ptr(pl.nov_aux), s), "cham_score_softmax_bwd")
         if self._dev_state.get('device'):
             self.articles_recent_pop_norm.note_consumed(d['aci'])      # last read of the state in a TRAIN step
         # scorer dgrad chain on this lane (three short GEMMs); the side lane takes the layer-1 weight gradient FIRST - 65 GFLOP of
@@ -1725,15 +1780,26 @@ class NARModuleModel:
         if e_auxdone is not None:
             main_stream.wait_event(e_auxdone)
 
+    def adam_lr_t(self, t):
+        """tf.train.AdamOptimizer's bias-corrected learning rate of optimizer step t (>= 1)."""
+        return self.lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+
     def apply_gradients(self):
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
         rt, L = self.rt, self.rt.layout
         rt.global_step += 1           # (also invalidates the bf16 weight shadows: NARRuntime.refresh_shadows keys on it)
         t = rt.global_step
-        lr_t = self.lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        lr_t = self.adam_lr_t(t)
+        if rt.dev_scalars:
+            rt.set_step_scalars(lr_t=lr_t, fields=4)
 
         def adam(a, b, grads, g_off):       # Adam on the parameter range [a, b); grads[g_off + i] pairs with flat[a + i]
             n_reg = min(max(L.n_reg - a, 0), b - a)
+            if rt.dev_scalars:      # lr_t from the step-scalar record
+                check(rt.lib.cham_adam_tf_dev(rt.flat.data_ptr() + 4 * a, grads.data_ptr() + 4 * g_off, rt.m.data_ptr() + 4 * a,
+                                              rt.v.data_ptr() + 4 * a, b - a, n_reg, float(self.reg_weight_decay), ptr(rt.scalars),
+                                              0.9, 0.999, 1e-8, _stream()), "cham_adam_tf_dev")
+                return
             check(rt.lib.cham_adam_tf(rt.flat.data_ptr() + 4 * a, grads.data_ptr() + 4 * g_off, rt.m.data_ptr() + 4 * a,
                                       rt.v.data_ptr() + 4 * a, b - a, n_reg, float(self.reg_weight_decay), float(lr_t),
                                       0.9, 0.999, 1e-8, _stream()), "cham_adam_tf")
@@ -1854,6 +1920,142 @@ class NARModuleModel:
         return dict(loss=pl.loss.cpu().numpy(), logits=pl.full_rows(pl.logits).view(pl.B, pl.T, pl.NC).cpu().numpy(),
                     probs=pl.full_rows(pl.probs).view(pl.B, pl.T, pl.NC).cpu().numpy(), neg_items=pl.neg_ids.cpu().numpy(),
                     neg_slot=pl.neg_slot.cpu().numpy(), pool=pl.pool.cpu().numpy(), meta=pl.meta.cpu().numpy())
+
+
+class GraphedTrainStep:
+    """One training step of a NARModuleModel - forward, backward, TF-Adam, the recent-clicks state update and the NEXT batch's negative
+    sampling - captured ONCE in a hipGraph (torch.cuda.CUDAGraph: stream capture of the step's lanes) and replayed per step.  The reference
+    runs a step as ONE session.run (nar_model.py:1434-1470); eagerly this runtime submits ~135 launches through ctypes (0.9-1.0 ms of host
+    time per step: what bounds a 32-session data-parallel shard or short sessions); a replay submits three: [the batch -> the step's input
+    slot (one device-to-device copy of the packed block), cham_step_scalars_set, graph launch].
+
+    What makes the step capturable: its launches carry no per-step host value - sampler key, max time stamp, sum(mask) and Adam's lr_t are
+    read from the device record (csrc/common.h ChamStepScalars) - and its inputs sit at fixed addresses (the slot).  Limits (checked by
+    supports()): one batch shape per object (B, T, global batch, row offset; NOT compacted - i.e. every position valid, or CHAM_COMPACT=0),
+    device-resident ClickedItemsState, keep_prob 1, no data-parallel exchange inside the step, pinned upload ring (the packed block).
+    Results are BIT-IDENTICAL to the eager step (tests/test_graph_step_gpu.py): same kernels, same arguments, same order per lane.
+
+    Sampler hand-over: the graph's forward reads sampler-output set A; behind the state update the graph draws the NEXT batch's negatives
+    (key .step_next) into set B from the `next` input slot and, as its last node, copies B -> A.  The first replay is preceded by an eager
+    draw of the first batch's negatives into A."""
+
+    def __init__(self, model, state):
+        self.model, self.state, self.rt = model, state, model.rt
+        self.graph, self.key, self.slots, self._expect = None, None, None, None
+        self.replays = 0
+
+    @staticmethod
+    def shape_key(d):
+        return (d['B'], d['T'], d['Bg'], d['row_begin'], d['P'], d.get('_total'), d.get('_layout'))
+
+    def supports(self, d):
+        """None when batch d can go through the captured step, else the reason (str)."""
+        m, rt = self.model, self.rt
+        if not rt.dev_scalars:
+            return "CHAM_DEV_SCALARS=0"
+        if d.get('pos') is not None or d['P'] != d['B'] * d['T']:
+            return "compacted batch (the valid-position count varies from batch to batch)"
+        if d.get('_block') is None:
+            return "no packed device block (pinned upload ring off)"
+        if not getattr(self.state, 'is_device', False) or self.state.stream is None:
+            return "host-side ClickedItemsState"
+        if self.state.n_updates < 1:
+            return "empty recent-clicks state (the very first batch takes its normalisation statistics from its own rows: another launch sequence)"
+        if getattr(rt, 'dp_active', False):
+            return "data-parallel exchange inside the step"
+        if m.keep_prob < 1.0 or m.eval_cold_start or not m.is_training or not rt.presample:
+            return "dropout / cold-start analysis / presampling off"
+        if self.key is not None and self.shape_key(d) != self.key:
+            return "another batch shape than the captured one"
+        return None
+
+    def _make_slot(self, d):
+        blk = torch.zeros(max(d['_total'], 256), dtype=torch.uint8, device=self.rt.device)
+        slot = dict(B=d['B'], T=d['T'], Bg=d['Bg'], row_begin=d['row_begin'], sum_mask=None, max_ts=None, P=d['P'], pos=None, uploaded=None,
+                    _block=blk, _total=d['_total'], _layout=d['_layout'])
+        for k, off, dt, shape in d['_layout']:
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            slot[k] = blk[off:off + n].view(_TORCH_DTYPE[dt]).view(shape)
+        slot.update(ic_rows=slot['item_clicked'].view(-1), ln_rows=slot['label_next'].view(-1), ets_rows=slot['event_ts'].view(-1))
+        return slot
+
+    def _load(self, slot, d):
+        torch.cuda.current_stream().wait_event(d['uploaded'])
+        slot['_block'][:d['_total']].copy_(d['_block'][:d['_total']], non_blocking=True)
+
+    def _capture(self, d, d_next):
+        m, rt, state = self.model, self.rt, self.state
+        self.key = self.shape_key(d)
+        cur, nxt = self._make_slot(d), self._make_slot(d_next)
+        self.slots = (cur, nxt)
+        pl = rt.plan(d['B'], d['T'], m.negative_samples, m.negative_sample_from_buffer, d['Bg'])
+        self._load(cur, d); self._load(nxt, d_next)
+        m.feed_state(state, state)
+        # the first batch's negatives, eagerly, into the set the captured forward reads (key by value: this is step rt.global_step)
+        a = pl._samp_cur
+        cur_scalars = dict(cur, max_ts=d['max_ts'], sum_mask=d['sum_mask'])
+        m._neg_sample(pl, cur_scalars, rt.global_step, a, _stream())
+        torch.cuda.synchronize()
+        state.updated_event = state.consumed_event = None          # (everything has finished: no event of the eager past is waited for inside the capture)
+        pl.grouped_ev = None
+        g = torch.cuda.CUDAGraph()
+        rt.capturing = True
+        step0, upd0 = rt.global_step, state.n_updates
+        try:
+            with torch.cuda.graph(g):
+                cur['_presampled'] = (pl, a, rt.global_step, None)
+                m.forward(cur)
+                m.backward()
+                m.apply_gradients()                     # (increments rt.global_step: undone below - nothing has executed)
+                state.update_from_device_batch(cur['aci'], cur['g_event_ts'])
+                ok = m.presample(nxt)                   # -> set 1 - a, key .step_next
+                assert ok, "presample() declined inside the capture"
+                ev = nxt.pop('_presampled')[3]
+                main = torch.cuda.current_stream()
+                main.wait_event(ev)
+                if state.updated_event is not None:
+                    main.wait_event(state.updated_event)
+                for name in ('neg_ids', 'neg_slot', 'pool', 'canon', 'meta'):
+                    pl._samp[a][name].copy_(pl._samp[1 - a][name], non_blocking=True)
+                # ... and the next batch becomes the current one: the host loads ONE slot per step
+                cur['_block'].copy_(nxt['_block'], non_blocking=True)
+        finally:      # (also when the capture fails: nothing of it has executed, the eager step remains usable)
+            rt.capturing = False
+            rt.global_step, state.n_updates = step0, upd0
+            state.updated_event = state.consumed_event = None
+            pl.grouped_ev = None
+            pl.use_sampler_set(a)
+            cur.pop('_presampled', None); nxt.pop('_presampled', None)
+        self.graph, self.plan = g, pl
+        return g
+
+    def step(self, d, d_next):
+        """One optimizer step on batch d; d_next = the batch of the following step (its negatives are drawn behind this step).  Returns the
+        device loss tensor [total, xe, reg] (as train_step)."""
+        why = self.supports(d) or self.supports(d_next)
+        if why is not None:
+            raise RuntimeError("GraphedTrainStep: %s" % why)
+        m, rt, state = self.model, self.rt, self.state
+        if self.graph is None:
+            self._capture(d, d_next)
+        else:
+            if d is not self._expect:
+                # not the batch the previous replay moved into the current slot and drew negatives for: load it and draw them now,
+                # eagerly, with this step's key by value (what the eager forward does for a batch that was not presampled)
+                self._load(self.slots[0], d)
+                m._neg_sample(self.plan, d, rt.global_step, self.plan._samp_cur, _stream())
+            self._load(self.slots[1], d_next)
+        self._expect = d_next
+        t = rt.global_step + 1
+        check(rt.lib.cham_step_scalars_set(ptr(rt.scalars), rt.global_step & 0xFFFFFFFF, (rt.global_step + 1) & 0xFFFFFFFF, int(d['max_ts']),
+                                           float(d['sum_mask']), float(m.adam_lr_t(t)), 7, _stream()), "cham_step_scalars_set")
+        self.graph.replay()
+        rt.global_step = t
+        state.n_updates += 1
+        state.updated_event = state.consumed_event = None
+        self.replays += 1
+        m._plan, m._d, m.total_loss = self.plan, self.slots[0], self.plan.loss
+        return m.total_loss
 
 
 class ItemsStateUpdaterHook:

@@ -424,6 +424,38 @@ size_t cham_colsum_workspace_bytes(int R, int F);
 int cham_colsum(const float* X, int ld, int R, int F, const float* w, float* out, int accumulate, float* workspace,
                 size_t workspace_bytes, void* stream);
 
+
+/* --- STEP SCALARS in device memory (round 6): a graph-capturable step.  The reference executes a training step as ONE session.run
+ * (nar_model.py:1434-1470); the launch parameters of this library's step that change from one optimizer step to the next - the sampler
+ * key (global step), the batch's max event time stamp (:235), sum(mask) (:664) and Adam's bias-corrected learning rate (:708) - can
+ * live in one 32-byte DEVICE record {uint32 step, uint32 step_next, int64 max_ts, int64 reserved, float sum_mask, float lr_t} instead of
+ * travelling by value: the `*_dev` entry points below are their by-value namesakes with that record in place of the scalar, the same
+ * arithmetic on the same values (bit-identical results).  A step enqueued through them carries no per-step host value, so it can be
+ * captured in a hipGraph once and replayed: the host then submits [copy the batch into the step's input slot, cham_step_scalars_set,
+ * graph launch] instead of ~135 launches (chameleon_recsys_amd/nar/nar_model.py GraphedTrainStep).
+ *   cham_step_scalars_set: a one-thread kernel taking the values by value (nothing on the host to keep alive), stream-ordered in front
+ *   of the step; fields: bit 0 = the sampler keys, bit 1 = max_ts + sum_mask, bit 2 = lr_t (fields not selected keep their values).
+ *   cham_neg_sample_dev: which = 0 -> .step, 1 -> .step_next (the next batch's negatives, drawn behind the current step). */
+int cham_step_scalars_bytes(void);
+int cham_step_scalars_set(void* rec, uint32_t step, uint32_t step_next, int64_t max_ts, float sum_mask, float lr_t, int fields, void* stream);
+int cham_neg_sample_dev(const int64_t* aci, int Bg, int T1, const int64_t* buffer, int buf_size, uint32_t seed, const void* scalars, int which,
+                        int row_begin, int row_count, int N, int n_from_buffer, int64_t* neg_ids, int32_t* neg_slot, int64_t* pool, int32_t* canon,
+                        int32_t* meta, void* workspace, size_t workspace_bytes, void* stream);
+int cham_step_ints_dev(const int64_t* ic_rows, const int64_t* ln_rows, const int64_t* pool, const int64_t* ets_rows, const void* scalars, int BT,
+                       int pmax, const int32_t* seq_len_in, int B, const uint8_t* mask_in, int64_t* ids_all, int64_t* ref_ts, int32_t* seq_len,
+                       uint8_t* mask, void* stream);
+int cham_norm_stats_from_buffer_dev(const int64_t* buffer_ids, int n_prefix, const void* scalars, const int64_t* created, const float* pop_norm,
+                                    float* scratch, float* stats, void* stream);
+int cham_score_softmax_bwd_dev(const float* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N, float tau,
+                               const void* scalars, float* ds, float* dS3, float novelty_reg_factor, const int64_t* neg_ids, const float* pop_norm,
+                               const float* logits, const float* nov_aux, void* stream);
+int cham_score_softmax_bwd_b16_dev(const void* S3, int K3, const float* w4, const float* probs, const uint8_t* mask, int BT, int N, float tau,
+                                   const void* scalars, float* ds, void* dS3, float novelty_reg_factor, const int64_t* neg_ids,
+                                   const float* pop_norm, const float* logits, const float* nov_aux, void* stream);
+int cham_loss_finalize_dev(const float* nll, int BT, const void* scalars, const float* sumsq_partial, float lambda, float* loss, void* stream);
+int cham_adam_tf_dev(float* params, const float* grads, float* m, float* v, size_t n, size_t n_reg, float lambda, const void* scalars,
+                     float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
