@@ -401,6 +401,39 @@ def hitrate_parity(seed):
                         "weights / inputs / negatives on both sides; cpu_oracle_on_hip_weights = the oracle evaluating the HIP-trained weights"}
 
 
+def hip_graph_arm(model, state, dev_batches, one_step, first, Bg, gstep, n=20):
+    """The same step replayed from ONE captured hipGraph (nar_model.GraphedTrainStep): ms/step over `n` replays and the host's submission
+    cost per step, beside the eager numbers of the same process.  Bit-identical training (tests/test_graph_step_gpu.py), so the eager
+    legs that follow continue the same trajectory."""
+    import torch
+    from chameleon_recsys_amd.nar.nar_model import GraphedTrainStep
+    nd = len(dev_batches)
+    gs = GraphedTrainStep(model, state)
+    why = gs.supports(dev_batches[first % nd])
+    if why is not None:
+        return {"used": False, "reason": why}
+    try:
+        torch.cuda.synchronize()
+        gstep[0] = gs
+        for i in range(4):                      # capture + first replays
+            one_step(first + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            one_step(first + 4 + i)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"used": True, "steps": n, "ms_per_step": round(dt / n * 1e3, 3), "value": round(Bg * n / dt, 2), "unit": "sessions/s",
+               "host_submit_ms_per_step": round(t_host / n * 1e3, 3),
+               "what": "forward + backward + TF-Adam + state update + next batch's negatives as ONE hipGraph; per step the host submits "
+                       "[batch -> input slot (one D2D copy), cham_step_scalars_set, graph launch]"}
+    except Exception as ex:                     # (a failed capture has executed nothing: the eager step carries on)
+        out = {"used": False, "reason": "capture failed: %s: %s" % (type(ex).__name__, str(ex)[:300])}
+    gstep[0] = None
+    return out
+
+
 XGMI_LINKS, XGMI_LINK_GBPS = 7, 153.0          # MI355X: 7 point-to-point links x ~153 GB/s per GPU (MI355X_MICROARCH.md)
 
 
@@ -469,9 +502,10 @@ def main():
     ap.add_argument("--state", default="device", choices=["device", "host"],
                     help="recent-clicks state: device-resident (csrc/state.hip) or the host numpy class fed every step")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="timed steps replayed from a hipGraph (nar_model.GraphedTrainStep; bit-identical to the eager step): auto = when the step is "
-                         "capturable (one GPU, full-length sessions, device state) and the capture succeeds, else eager with the reason recorded")
+    ap.add_argument("--graph", default="arm", choices=["arm", "on", "off"],
+                    help="the step replayed from ONE captured hipGraph (nar_model.GraphedTrainStep; bit-identical to the eager step).  arm (default): "
+                         "the timed steps are eager - measured faster on ROCm 7.2: the graph's nodes overlap less than the hand-scheduled lanes, "
+                         "profiles/r06_notes.md section 3 - and the replay is timed as an extra leg (hip_graph_arm); on: the timed steps ARE replays")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: until it is printed, file descriptor 1 points at stderr, so that nothing a library
@@ -563,7 +597,7 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     # ---- the timed steps as replays of ONE captured hipGraph (the reference: one session.run per step) when the step is capturable
-    if args.graph != "off":
+    if args.graph == "on":
         from chameleon_recsys_amd.nar.nar_model import GraphedTrainStep
         gs = GraphedTrainStep(model, state)
         k0 = args.warmup % n_distinct
@@ -605,6 +639,8 @@ def main():
     host_enqueue_ms = (time.perf_counter() - t_h) / 3 * 1e3
     torch.cuda.synchronize()
     host_enqueue_eager_ms = host_enqueue_ms
+    if args.graph == "arm" and world == 1 and args.state == "device":
+        graph["arm"] = hip_graph_arm(model, state, dev_batches, one_step, args.warmup + args.steps + 3, Bg, gstep)
     if gstep[0] is not None:         # the legs below (per-launch HIP events, arms) drive the EAGER step; its host cost beside the replay's
         graph["graph_replays_timed"] = gstep[0].replays
         gstep[0] = None

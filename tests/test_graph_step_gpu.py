@@ -34,8 +34,11 @@ def _run(p, batches, n_eager, graphed, monkeypatch=None, dev_scalars="1"):
             model.presample(dev[i + 1])
     torch.cuda.synchronize()
     pl = model._plan
-    out = dict(losses=torch.stack(losses).cpu(), flat=model.rt.flat.cpu().clone(), m=model.rt.m.cpu().clone(), v=model.rt.v.cpu().clone(),
-               buf=st.buf_ids.cpu().clone(), buf_ts=st.buf_ts.cpu().clone(), pop=st.pop_norm.cpu().clone(), neg=pl.neg_ids.cpu().clone(),
+    # the negatives drawn for the NEXT batch (key = the next step): eagerly they sit in the sampler set that is not the current one, after a
+    # replay in the set the captured forward reads (the graph's last nodes copy them there)
+    neg_next = pl._samp[pl._samp_cur if (graphed and gs.replays) else 1 - pl._samp_cur]['neg_ids']
+    out = dict(neg_next=neg_next.cpu().clone(), losses=torch.stack(losses).cpu(), flat=model.rt.flat.cpu().clone(), m=model.rt.m.cpu().clone(), v=model.rt.v.cpu().clone(),
+               buf=st.buf_ids.cpu().clone(), buf_ts=st.buf_ts.cpu().clone(), pop=st.pop_norm.cpu().clone(),
                logits=pl.logits.cpu().clone(), step=model.rt.global_step, n_updates=st.n_updates)
     return out, gs, model, st, dev
 
@@ -50,7 +53,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(gpu, C, neg):
     graph, gs, model, st, dev = _run(p, batches, 2, True)
     assert gs.graph is not None and gs.replays == 8
     assert eager['step'] == graph['step'] == 10 and eager['n_updates'] == graph['n_updates']
-    for k in ('losses', 'flat', 'm', 'v', 'buf', 'buf_ts', 'pop', 'neg', 'logits'):
+    for k in ('losses', 'flat', 'm', 'v', 'buf', 'buf_ts', 'pop', 'neg_next', 'logits'):
         assert torch.equal(eager[k], graph[k]), k
     # ... and an EAGER step after the replays continues the same trajectory (python-side bookkeeping of the replays: global step, state)
     model.feed_state(st, st)
@@ -67,7 +70,7 @@ def test_device_scalar_record_matches_the_by_value_entry_points(gpu, monkeypatch
     a, _, ma, _, _ = _run(p, batches, 6, False, monkeypatch, "1")
     b, _, mb, _, _ = _run(p, batches, 6, False, monkeypatch, "0")
     assert ma.rt.dev_scalars and not mb.rt.dev_scalars
-    for k in ('losses', 'flat', 'm', 'v', 'buf', 'pop', 'neg'):
+    for k in ('losses', 'flat', 'm', 'v', 'buf', 'pop', 'neg_next'):
         assert torch.equal(a[k], b[k]), k
 
 
