@@ -143,7 +143,7 @@ def gemm_symbol(r):
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)
         return "void k_dm_mulpred_fused<%d>(DmfParams)" % (2 if r.get('bf16') else (3 if r.get('f16p') else (1 if r.get('h2out') else 0)))
     if r.get('h2w'):      # ... NT form on the 64-byte-source-piece kernel (round 5)
-        return "void gemm_h2w_kernel<%d>(H2Params)" % epi
+        return "void gemm_h2w_kernel<%d, %s>(H2Params)" % (epi, tf(bool(r.get('h2blk'))))
     if r.get('h2'):       # plane products over operands stored as two fp16 planes + a power-of-two scale (csrc/gemm_h2.hip)
         return "void gemm_h2_kernel<%s, %d>(H2Params)" % (tf(bool(r['transA'])), epi)
     if r.get('p3'):       # plane products over operands that already are three bf16 planes in HBM (csrc/gemm_p3.hip)
@@ -152,6 +152,8 @@ def gemm_symbol(r):
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2)}[r['tile']]
         rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
         return "void gemm_x3_kernel<%d, %d, %d, %d, %s, %s, %d, %s, %d>(GemmParams)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(rs), 2 if r.get('x2h') else 3)
+    if r['tile'] == 5:    # small-output TN weight gradients: v_mfma_f32_32x32x2_f32 fed straight from global memory (csrc/gemm.hip, round 6)
+        return "void gemm_tn_small_kernel<%d, %d>(GemmParams)" % (1 if r['M'] <= 32 else 2, 1 if r['N'] <= 32 else 2)
     bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 256, 4, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile'] % 8]
     rs = r['rowscale'] and ((epi == 1 and ak and not bkc) or (epi in (0, 6) and not ak and not bkc))
     if r['bf16']:

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // Launch counters per tile instance (tests assert that a shape really ran on the instance it is meant to cover):
-// [0] 128x128, [1] 256x128, [2] 256x256, [3] 256x64, [4] 256x32; +8 for the bf16 kernels; [14] = epilogue variant (EPI) and
+// [0] 128x128, [1] 256x128, [2] 256x256, [3] 256x64, [4] 256x32, [5] the small-output TN VALU kernel; +8 for the bf16 kernels; [14] = epilogue variant (EPI) and
 // [15] = K-splits of the LAST launch (bench.py reconstructs the kernel symbol of a timed launch).  Not thread-safe (test / bench aid).
 static long long g_tile_launches[16];
 extern "C" void cham_gemm_launch_counts(long long* out16, int reset) {
@@ -530,6 +530,128 @@ extern "C" int cham_gemm_bf16(const float* A, int lda, int transA, const float* 
                          accumulate, workspace, workspace_bytes, splits_hint, stream);
 }
 
+// ================================================================================================================================
+// SMALL-OUTPUT weight gradients (round 6): C[M, N] = A[K, M]^T B[K, N] with M <= 128 and a long reduction - the scorer's layer-3 / layer-2
+// weight gradients (64 x 32 and 128 x 64 over K = B T (1 + N) = 248 064 candidate rows, nar_model.py:452-468 under :718) and the
+// user-context share of the PreCAR kernel's (72 x 1024 over K = B T).  On the MFMA tile kernels above these shapes waste three quarters of
+// a 256-row tile and - worse - their workgroups need 32-110 KB of LDS: launched beside the W2 weight gradient (one workgroup per CU holding
+// 128 KB of the CU's 160 KB) they do not become resident until that kernel's workgroups retire.  Measured in the step
+// (profiles/r06_notes.md section 5): 0.75-0.89 ms for the 64 x 32 gradient (95 MB of operands: 25 us at HBM speed) and 0.47-0.54 ms for the
+// 72 x 1024 one on the critical tail of the main lane.  Here: v_mfma_f32_32x32x2_f32 fed STRAIGHT FROM GLOBAL MEMORY (see the kernel), four
+// waves per workgroup over quarters of its K chunk, their accumulators added in wave order through <= 24 KB of LDS at the end - no staging,
+// no barrier in the loop, ~100 VGPRs: a workgroup fits beside anything.  (A first version - fp32 FMAs on the VALU over 16-row LDS stages -
+// took 0.52 ms for the 64 x 32 gradient: one 6 KB stage in flight per workgroup is latency-, not bandwidth-bound.)  K-splits write partials
+// in the shared layout ([split][M][N]) and the shared fixed-order reduction adds them: deterministic.
+template <int TMT, int TNT>
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(GemmParams p) {
+    // One wave = a (32 TMT) x (32 TNT) block of C over a quarter of the workgroup's K chunk, straight from global memory: the operands of
+    // v_mfma_f32_32x32x2_f32 for a TN product are lane (k = l / 32, m or n = l % 32) - i.e. lanes 0-31 read 128 consecutive bytes of k-row
+    // k0, lanes 32-63 of k-row k0 + 1: coalesced dword loads, no LDS staging, no transposition, no barrier in the loop.  U k-pairs of loads
+    // are issued back to back (memory-level parallelism: (TMT + TNT) U dwords in flight per lane) before their MFMAs.
+    constexpr int U = (TMT * TNT >= 8) ? 4 : 8;
+    __shared__ float red[TMT * TNT * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kl = lane >> 5, cl = lane & 31;
+    const int n0 = blockIdx.x * (32 * TNT), split = blockIdx.y, m0 = blockIdx.z * (32 * TMT);
+    const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    const int quarter = (((kend - kbeg + 3) / 4) + 1) & ~1;          // rows per wave, even
+    const int wbeg = kbeg + wave * quarter, wend = min(kend, wbeg + quarter);
+    floatx16 acc[TMT][TNT];
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // buffer descriptors over the operands' K rows of this wave (32-bit offsets; a row at or beyond the wave's end, a column beyond the
+    // matrix: out-of-range offset -> the load returns 0 without a branch)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (unsigned)min((size_t)p.K * p.lda * 4, (size_t)0x7FFFFFF0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (unsigned)min((size_t)p.K * p.ldb * 4, (size_t)0x7FFFFFF0u), 0x00020000);
+    unsigned ca[TMT], cb[TNT];
+#pragma unroll
+    for (int i = 0; i < TMT; ++i) ca[i] = m0 + 32 * i + cl < p.M ? (unsigned)(m0 + 32 * i + cl) * 4u : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) cb[j] = n0 + 32 * j + cl < p.N ? (unsigned)(n0 + 32 * j + cl) * 4u : 0x80000000u;
+    const unsigned sa = (unsigned)p.lda * 4u, sb = (unsigned)p.ldb * 4u;
+    for (int k0 = wbeg; k0 < wend; k0 += 2 * U) {
+        float a[U][TMT], b[U][TNT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned row = (unsigned)(k0 + 2 * u + kl);
+            const unsigned oob = (int)row < wend ? 0u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < TMT; ++i) a[u][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (row * sa + ca[i]) | oob, 0, 0));
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) b[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (row * sb + cb[j]) | oob, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    }
+    // waves 1, 2, 3 hand their accumulators to wave 0 one after the other through ONE buffer (<= 16 KB: the workgroup must fit into the
+    // 32 KB of LDS that are free beside a plane GEMM's 128 KB): ascending wave order = a fixed summation order
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((i * TNT + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * TNT + j) * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave > 0) return;
+    // acc[i][j][e] = C(row m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 kl, column n0 + 32 j + cl)
+    const bool part = p.splits > 1;
+    float* dst = part ? p.partial + (size_t)split * p.M * p.N : p.C;
+    const int ld = part ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            const int n = n0 + 32 * j + cl;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                if (m >= p.M) continue;
+                float v = acc[i][j][e];
+                if (!part && p.accumulate) v += dst[(size_t)m * ld + n];
+                dst[(size_t)m * ld + n] = v;
+            }
+        }
+}
+
+// [5] of cham_gemm_launch_counts: launches of the small-output TN kernel.  CHAM_GEMM_TN_SMALL=0 (environment, read once): off (A/B arm).
+static int tn_small_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("CHAM_GEMM_TN_SMALL"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on;
+}
+template <int TMT, int TNT>
+static int launch_tn_small(GemmParams& p, hipStream_t st) {
+    constexpr int BNt = 32 * TNT;
+    ++g_tile_launches[5]; g_tile_launches[14] = p.splits > 1 ? 6 : 0; g_tile_launches[15] = p.splits;
+    hipLaunchKernelGGL((gemm_tn_small_kernel<TMT, TNT>), dim3((p.N + BNt - 1) / BNt, p.splits, (p.M + 32 * TMT - 1) / (32 * TMT)), dim3(256), 0, st, p);
+    if (p.splits > 1) launch_splitk_reduce(p, st);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
 static int gemm_dispatch(int precision, const float* A, int lda, int transA, const float* B, int ldb, int transB,
                              float* C, int ldc, int M, int N, int K,
                              const float* bias, int act,
@@ -538,6 +660,21 @@ static int gemm_dispatch(int precision, const float* A, int lda, int transA, con
                              int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
                              void* stream) {
     GemmParams p;
+    // small-output weight gradient (see gemm_tn_small_kernel): plain TN, M <= 128, a reduction long enough to matter
+    if (precision == 0 && transA && !transB && M <= 128 && K >= 512 && !bias && act == ACT_NONE && !dref && !rowscale && tn_small_enabled()) {
+        const int rc0 = gemm_plan(p, A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, dref, ldr, dact, rowscale, ldrs, rs_div,
+                                  accumulate, workspace, workspace_bytes, splits_hint);
+        if (rc0 != CHAM_OK) return rc0;
+        hipStream_t st0 = (hipStream_t)stream;
+        // a wave owns at most 2 x 2 tiles of 32 x 32 (64 accumulator registers: the kernel stays under the ~160 VGPRs that are free beside the
+        // plane GEMMs' two waves per SIMD); more row tiles go to blockIdx.z (their workgroups re-read the B block: a few MB through L2)
+        if ((size_t)K * (lda > ldb ? lda : ldb) * 4 >= 0x7FFFFFF0ull) { /* 32-bit operand offsets: leave it to the tile kernels below */ }
+        else {
+            const int mt = (M + 31) / 32;
+            if (N <= 32) return mt == 1 ? launch_tn_small<1, 1>(p, st0) : launch_tn_small<2, 1>(p, st0);
+            return mt == 1 ? launch_tn_small<1, 2>(p, st0) : launch_tn_small<2, 2>(p, st0);
+        }
+    }
     const int rc = gemm_plan(p, A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, dref, ldr, dact, rowscale, ldrs, rs_div,
                              accumulate, workspace, workspace_bytes, splits_hint);
     if (rc != CHAM_OK) return rc;

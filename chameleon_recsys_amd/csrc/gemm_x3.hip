@@ -516,7 +516,9 @@ extern "C" int cham_gemm_f32x3(const float* A, int lda, int transA, const float*
                                const float* rowscale, int ldrs, int rs_div,
                                int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
                                void* stream) {
-    if (N <= 64) {          // narrow outputs (scorer layers 2-3 and their twins) are HBM-bound: the native fp32 kernels already stream them
+    // narrow outputs (scorer layers 2-3 and their twins) are HBM-bound: the native fp32 kernels already stream them; plain TN products with
+    // M <= 128 (small-output weight gradients over a long reduction) go to csrc/gemm.hip's VALU kernel through the same entry point
+    if (N <= 64 || (transA && !transB && M <= 128 && K >= 512 && !bias && act == ACT_NONE && !dref && !rowscale)) {
         ++g_x3_launches[3];
         return cham_gemm_f32(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, act, dref, ldr, dact, rowscale, ldrs, rs_div,
                              accumulate, workspace, workspace_bytes, splits_hint, stream);

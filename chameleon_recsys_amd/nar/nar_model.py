@@ -594,7 +594,7 @@ class NARRuntime:
             c = (ctypes.c_longlong * 8)()
             self.lib.cham_gemm_h2_launch_counts(c, 0)
             prof.append(dict(M=M, N=N, K=K, transA=tn, transB=0 if tn else 1, splits=int(c[7]), act=act, dref=dref_h is not None, dact=dact,
-                             bias=bias is not None, rowscale=False, bf16=False, h2=True, h2w=bool(c[2] > c0[2]), tile=0, epi=int(c[6]), ev=(e0, e1)))
+                             bias=bias is not None, rowscale=False, bf16=False, h2=True, h2w=bool(c[2] > c0[2]), h2blk=bool(c[3] > c0[3]), tile=0, epi=int(c[6]), ev=(e0, e1)))
 
     def _tile_counts_b16(self):
         import ctypes

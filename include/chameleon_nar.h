@@ -305,6 +305,9 @@ void cham_gemm_b16_launch_counts(long long* out8, int reset);
 /* tuning hook (bench / autotune only): selects the tile configuration used for N > 64 */
 void cham_gemm_set_variant(int variant);
 /* test aid: launches per tile instance since the last reset - out16[0..4] = fp32 128x128, 256x128, 256x256, 256x64, 256x32;
+ * out16[5] = the small-output TN kernel (round 6: plain C = A^T B with M <= 128 and K >= 512 - the scorer's layer-2 / layer-3 weight
+ * gradients, the user-context share of the PreCAR kernel's - runs as fp32 FMAs on the VALU with 6-12 KB of LDS, so that it becomes
+ * resident BESIDE the one-workgroup-per-CU plane GEMMs instead of behind them; cham_gemm_f32x3 hands such shapes over too);
  * out16[8..12] = the same tiles of the bf16 kernels; out16[14] / out16[15] = epilogue variant / K-splits of the last launch.
  * Parity tests assert that a shape ran on the instance it is meant to cover; bench.py names the kernel symbol of a timed launch. */
 void cham_gemm_launch_counts(long long* out16, int reset);

@@ -283,3 +283,30 @@ def test_nt_narrow_output_with_split_hint(gpu, N, x3, bf16):
     assert _run(gpu, 96, N, 4096, transB=1, splits=0, x3=x3, bf16=bf16) < tol
     assert _run(gpu, 96, N, 4096, transB=1, splits=5, x3=x3, bf16=bf16) < tol
     assert _run(gpu, 96, N, 4096, transB=1, dref=True, dact=1, splits=0, x3=x3, bf16=bf16) < tol
+
+
+# ---- small-output TN weight gradients on the VALU kernel (csrc/gemm.hip gemm_tn_small_kernel, round 6): M <= 128, long reduction
+@pytest.mark.parametrize("M,N,K,splits", [(64, 32, 20000, 0), (128, 64, 20000, 0), (72, 1024, 4864, 0), (64, 32, 600, 1), (128, 128, 512, 1), (4, 4, 5000, 0),
+                                          (60, 36, 3001, 0), (100, 200, 777, 0), (128, 72, 2049, 3)])
+@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_small_output_tn_kernel(gpu, M, N, K, splits, x3, accumulate):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    before = _counts(lib)
+    err = _run(gpu, M, N, K, transA=1, accumulate=accumulate, splits=splits, seed=M + N, x3=x3)
+    after = _counts(lib)
+    assert after[5] == before[5] + 1, (before, after)              # the small-output kernel took it (through either entry point)
+    assert err < 2e-6, err                                          # fp32 products and accumulation: a K-term fp32 sum against float64
+
+
+def test_small_output_tn_kernel_is_repeatable_and_leaves_other_shapes_alone(gpu):
+    from chameleon_recsys_amd import _lib
+    lib = _lib.load()
+    a = [_run(gpu, 64, 32, 50000, transA=1, splits=0, seed=9) for _ in range(2)]
+    assert a[0] == a[1]                                             # fixed summation order (no atomics)
+    before = _counts(lib)
+    _run(gpu, 256, 64, 5000, transA=1, splits=0)                   # M > 128: the MFMA tile kernels
+    _run(gpu, 64, 32, 256, transA=1)                               # short reduction
+    _run(gpu, 64, 32, 5000, transA=1, bias=False, rowscale=3, splits=0)      # row-broadcast scale on A: the MFMA kernels' staging
+    assert _counts(lib)[5] == before[5]
