@@ -165,7 +165,7 @@ def child_arm(args, extra):
     """This script as a child process for another configuration; returns its headline, its G1-like-lengths leg and its roofline entry."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 20))), "--warmup", str(args.warmup),
-           "--seed", str(args.seed), "--no-cpu-baseline", "--no-boundary-leg", "--no-native-arm", "--no-arms"] + extra
+           "--seed", str(args.seed), "--no-cpu-baseline", "--no-boundary-leg", "--no-native-arm", "--no-arms", "--graph", "off"] + extra
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
@@ -327,7 +327,7 @@ def pmc_traffic_live(symbol, seed):
         return None, "rocprofv3 not found"
     d = tempfile.mkdtemp(prefix="cham_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--seed", str(seed), "--no-cpu-baseline",
-             "--no-ragged-leg", "--no-boundary-leg", "--no-arms", "--no-native-arm", "--no-pmc"]
+             "--no-ragged-leg", "--no-boundary-leg", "--no-arms", "--no-native-arm", "--no-pmc", "--graph", "off"]
     vals = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

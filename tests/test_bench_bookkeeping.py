@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _stats_names():
-    with open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv")) as fh:
         return {r["Name"] for r in csv.DictReader(fh)}
 
 
@@ -23,15 +23,16 @@ def test_rebuilt_gemm_symbols_are_the_names_rocprof_lists():
             dict(base, dmf=True, h2out=True, f16p=True, epi=0),          # -> k_dm_mulpred_fused<3>
             dict(base, x3=True, tile=1, epi=1, transA=0, transB=0, rowscale=True),          # scorer layer 1 forward (row-scale prologue), six bf16 products
             dict(base, x3=True, x2h=True, tile=0, epi=6, transA=1, transB=0, rowscale=True),          # its weight gradient, two fp16 planes
-            dict(base, x3=True, tile=0, epi=6, transA=1, transB=0)]                                   # bf16x3 (the other wide weight gradients)
+            dict(base, x3=True, tile=0, epi=6, transA=1, transB=0),                                   # bf16x3 (the other wide weight gradients)
+            dict(base, tile=5, epi=6, transA=1, transB=0, M=64, N=32), dict(base, tile=5, epi=6, transA=1, transB=0, M=128, N=64)]      # small-output TN kernel (round 6)
     for r in recs:
         sym = bench.gemm_symbol(r)
-        assert sym in names, "%s is not a kernel of profiles/r05_kernel_stats.csv" % sym
+        assert sym in names, "%s is not a kernel of profiles/r06_kernel_stats.csv" % sym
 
 
 def test_committed_traffic_file_has_the_dominant_kernels():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read())
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench.json")).read())
     dom = line["roofline"]["kernel"].split(" = ")[0]
     assert dom in d and d[dom]["traffic_bytes_per_launch"] > line["roofline"]["algorithmic_bytes_per_launch"] * 0.9
     for g in line["roofline"]["top_gemms"]:
