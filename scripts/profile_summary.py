@@ -48,7 +48,7 @@ def main():
     traffic = {}
     tf = os.path.join(P, tag + "_pmc_traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf))
+        traffic = {k: v for k, v in json.load(open(tf)).items() if isinstance(v, dict)}
     for x in rows[:16]:
         out.append("| `%s` | %.1f | %.3f | %.1f | %.1f %% |" % (x["Name"].split("(")[0].replace("void ", "")[:80], int(x["Calls"]) / steps,
                                                              float(x["TotalDurationNs"]) / 1e6 / steps, float(x["AverageNs"]) / 1e3, float(x["Percentage"])))
