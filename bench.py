@@ -138,6 +138,8 @@ def gemm_symbol(r):
     if r.get('b16'):      # bf16-resident kernels (csrc/gemm_b16.hip)
         bm, bn, wm, wn = {0: (128, 128, 2, 2), 1: (256, 128, 4, 2), 2: (256, 128, 2, 2), 3: (256, 64, 4, 1), 4: (256, 32, 4, 1)}[r['tile']]
         return "void gemm_b16_kernel<%d, %d, %d, %d, %s, %s, %d, %s>(B16Params)" % (bm, bn, wm, wn, tf(ak), tf(bkc), epi, tf(r['out_f32'] or epi == 6))
+    if r.get('b1w'):      # ... its NT forms on the 64-byte-source-piece kernel (round 6)
+        return "void gemm_b1w_kernel<%d>(P3Params)" % epi
     if r.get('b1'):       # bf16-resident operands on the LDS-DMA core (csrc/gemm_p3.hip, gemm_b1_kernel)
         return "void gemm_b1_kernel<%s, %d>(P3Params)" % (tf(bool(r['transA'])), epi)
     if r.get('dmf'):      # scorer layer-1 dgrad fused with the cand (.) pred backward (csrc/dm_fused.hip)

@@ -45,6 +45,7 @@ _SIGNATURES = {
                              P, c_size_t, c_int, P]),
     "cham_gemm_b16_dma": (c_int, [P, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "cham_gemm_p3_launch_counts": (None, [P, c_int]),
+    "cham_gemm_b16_dma_set_nt_wide": (c_int, [c_int]),
     "cham_split3": (c_int, [P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, c_int, P]),
     "cham_combine_fwd_p3": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
     "cham_mulpred_bwd_p3": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int64, P, P]),
@@ -147,6 +148,8 @@ def load():
     # library-wide kernel switches, set ONCE per process at load (not per runtime: a second NARRuntime must not flip the kernels of the
     # first - ADVICE r05).  CHAM_H2_NT_WIDE=0: the 32-byte-piece NT kernels of round 4 (bit-identical results; A/B arm)
     lib.cham_gemm_h2_set_nt_wide(1 if os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" else 0)
+    # CHAM_B16_NT_WIDE=0: the bf16 configuration's NT CAR GEMMs on gemm_b1_kernel (32-byte pieces) instead of gemm_b1w_kernel (round 6; A/B arm)
+    lib.cham_gemm_b16_dma_set_nt_wide(1 if os.environ.get("CHAM_B16_NT_WIDE", "1") == "1" else 0)
     _lib = lib
     return lib
 

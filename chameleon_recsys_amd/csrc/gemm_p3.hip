@@ -355,6 +355,134 @@ __device__ __forceinline__ unsigned b1_pack(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// The NT epilogue of the bf16-resident kernels (accumulators of SWAPPED products: acc[i][j][e] = row m0 + wm0 + 32 i + fl, column n0 + wn0 +
+// 32 j + 8 (e >> 2) + 4 kl + (e & 3)); shared by gemm_b1_kernel<false, .> and gemm_b1w_kernel.  Needs the kernel's 128 KB of dynamic LDS.
+template <int EPI>
+__device__ __forceinline__ void b1_nt_epilogue(const P3Params& p, floatx16 (&acc)[4][2], int m0, int n0, int wm0, int wn0, int lane, int wave) {
+    constexpr int TM = 4, TNN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kl = lane_e >> 5, fl = lane_e & 31;
+    {
+        // acc[i][j][e]: row m = wm0 + 32 i + fl, column n = wn0 + 32 j + 8 (e >> 2) + 4 kl + (e & 3)
+        const int limM = p.M - m0, limN = p.N - n0;
+        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+        const __amdgpu_buffer_rsrc_t cw = make_window(Cb + (size_t)m0 * p.ldc + n0);
+        const __amdgpu_buffer_rsrc_t dw = make_window(EPI == 13 ? (const void*)(p.dref + (size_t)m0 * p.ldr + n0) : (const void*)Cb);
+        const __amdgpu_buffer_rsrc_t bw = make_window(EPI == 12 ? (const void*)(p.bias + n0) : (const void*)Cb);
+        // ---- interior wave tiles: the epilogue goes THROUGH LDS (round 5).  With swapped operands a lane owns a ROW and four consecutive
+        // columns: its 8-byte stores (and the dgrad's 8-byte loads of the saved activation) hit 32 different rows per instruction - 32
+        // sixteen-byte fragments of 32 different lines.  Measured with the stores compiled out: 0.548 ms against 0.713 ms for the plain
+        // NT product, and another 0.15 ms for the dgrad's loads (profiles/r05_notes.md section 6): the NT forms' gap to the TN form is this
+        // access pattern.  Here a wave packs its 128 x 64 bf16 outputs into 16 KB of the (now free) ring - row pitch 128 bytes, 16-byte piece
+        // q of row r at slot q ^ ((r >> 1) & 7), the two 8-byte halves of a piece swapped on rows with bit 4 set (ds_write_b64 of 32 rows x one
+        // column group: 32 different bank pairs) - reads it back 16 bytes per lane (8 lanes = one whole 128-byte row segment; two rows per 16
+        // lanes = all 64 banks) and stores / loads global memory in whole lines: 16 b128 accesses per lane instead of 32 b64.
+        // The dgrad (EPI 13) works in two halves of 64 rows: [saved activation | outputs] share the wave's 16 KB.
+        p3_barrier();                 // every wave is past its last fragment read; no DMA in flight (vmcnt(0) above): the ring is free
+        if (limM >= wm0 + 128 && limN >= wn0 + 64) {          // wave-uniform
+            unsigned char* Rg = p3_smem + (unsigned)wave * 16384u;
+            const unsigned lr = (unsigned)(lane >> 3), ls = (unsigned)(lane & 7);
+            auto slot_off = [](unsigned r, unsigned pp, unsigned half) -> unsigned {
+                return r * 128u + (((pp ^ (r >> 1)) & 7u) << 4) + (((half ^ (r >> 4)) & 1u) << 3);
+            };
+            if constexpr (EPI != 13) {
+#pragma unroll
+                for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4 bv;
+                        if constexpr (EPI == 12) bv = __builtin_amdgcn_raw_buffer_load_b128(bw, (unsigned)(wn0 + j * 32 + 8 * q + 4 * kl) * 4u, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            if constexpr (EPI == 12) {
+                                v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
+                                v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
+                            }
+                            u32x2 w;
+                            w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(Rg + slot_off((unsigned)(32 * i + fl), (unsigned)(4 * j + q), (unsigned)kl)) = w;
+                        }
+                    }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const unsigned r = 8u * t + lr;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(Rg + r * 128u + ls * 16u);
+                    if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
+                    const unsigned pp = (ls ^ (r >> 1)) & 7u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                }
+            } else {
+                unsigned char* Dg = Rg;                     // saved activation, 64 rows
+                unsigned char* Og = Rg + 8192;              // outputs, 64 rows
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned r = 8u * t + lr, pp = (ls ^ (r >> 1)) & 7u;
+                        u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(dw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldr + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                        if ((r >> 4) & 1u) { const unsigned a = y.x, b = y.y; y.x = y.z; y.y = y.w; y.z = a; y.w = b; }
+                        *reinterpret_cast<u32x4*>(Dg + r * 128u + ls * 16u) = y;
+                    }
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int i = 2 * h + ih;
+                                const unsigned off = slot_off((unsigned)(32 * ih + fl), (unsigned)(4 * j + q), (unsigned)kl);
+                                const u32x2 y = *reinterpret_cast<const u32x2*>(Dg + off);
+                                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                                v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
+                                v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
+                                u32x2 w;
+                                w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                                *reinterpret_cast<u32x2*>(Og + off) = w;
+                            }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned r = 8u * t + lr;
+                        u32x4 v = *reinterpret_cast<const u32x4*>(Og + r * 128u + ls * 16u);
+                        if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
+                        const unsigned pp = (ls ^ (r >> 1)) & 7u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = wm0 + i * 32 + fl;
+            const bool mok = m < limM;
+#pragma unroll
+            for (int j = 0; j < TNN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = wn0 + j * 32 + 8 * q + 4 * kl;
+                    const bool ok = mok && n < limN;              // N % 4 == 0: a group of 4 columns is in or out as a whole
+                    float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    if constexpr (EPI == 12) {
+                        const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(bw, ok ? (unsigned)n * 4u : OOB_OFF, 0, 0);
+                        v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
+                        v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
+                    }
+                    if constexpr (EPI == 13) {
+                        const u32x2 y = __builtin_amdgcn_raw_buffer_load_b64(dw, ok ? ((unsigned)m * (unsigned)p.ldr + (unsigned)n) * 2u : OOB_OFF, 0, 0);
+                        v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
+                        v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
+                    }
+                    u32x2 w;
+                    w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, cw, ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB_OFF, 0, 0);
+                }
+        }
+    }
+}
+
 template <bool TN, int EPI>
 __global__ __launch_bounds__(512) void gemm_b1_kernel(P3Params p) {
     constexpr int BM = 256, BN = 256, KS = 48, TM = 4, TNN = 2;
@@ -507,132 +635,163 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(P3Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may outlive the workgroup's LDS allocation
     }
 
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int kl = lane_e >> 5, fl = lane_e & 31;
     if constexpr (SWAP) {
-        // acc[i][j][e]: row m = wm0 + 32 i + fl, column n = wn0 + 32 j + 8 (e >> 2) + 4 kl + (e & 3)
-        const int limM = p.M - m0, limN = p.N - n0;
-        __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
-        const __amdgpu_buffer_rsrc_t cw = make_window(Cb + (size_t)m0 * p.ldc + n0);
-        const __amdgpu_buffer_rsrc_t dw = make_window(EPI == 13 ? (const void*)(p.dref + (size_t)m0 * p.ldr + n0) : (const void*)Cb);
-        const __amdgpu_buffer_rsrc_t bw = make_window(EPI == 12 ? (const void*)(p.bias + n0) : (const void*)Cb);
-        // ---- interior wave tiles: the epilogue goes THROUGH LDS (round 5).  With swapped operands a lane owns a ROW and four consecutive
-        // columns: its 8-byte stores (and the dgrad's 8-byte loads of the saved activation) hit 32 different rows per instruction - 32
-        // sixteen-byte fragments of 32 different lines.  Measured with the stores compiled out: 0.548 ms against 0.713 ms for the plain
-        // NT product, and another 0.15 ms for the dgrad's loads (profiles/r05_notes.md section 6): the NT forms' gap to the TN form is this
-        // access pattern.  Here a wave packs its 128 x 64 bf16 outputs into 16 KB of the (now free) ring - row pitch 128 bytes, 16-byte piece
-        // q of row r at slot q ^ ((r >> 1) & 7), the two 8-byte halves of a piece swapped on rows with bit 4 set (ds_write_b64 of 32 rows x one
-        // column group: 32 different bank pairs) - reads it back 16 bytes per lane (8 lanes = one whole 128-byte row segment; two rows per 16
-        // lanes = all 64 banks) and stores / loads global memory in whole lines: 16 b128 accesses per lane instead of 32 b64.
-        // The dgrad (EPI 13) works in two halves of 64 rows: [saved activation | outputs] share the wave's 16 KB.
-        p3_barrier();                 // every wave is past its last fragment read; no DMA in flight (vmcnt(0) above): the ring is free
-        if (limM >= wm0 + 128 && limN >= wn0 + 64) {          // wave-uniform
-            unsigned char* Rg = p3_smem + (unsigned)wave * 16384u;
-            const unsigned lr = (unsigned)(lane >> 3), ls = (unsigned)(lane & 7);
-            auto slot_off = [](unsigned r, unsigned pp, unsigned half) -> unsigned {
-                return r * 128u + (((pp ^ (r >> 1)) & 7u) << 4) + (((half ^ (r >> 4)) & 1u) << 3);
-            };
-            if constexpr (EPI != 13) {
-#pragma unroll
-                for (int j = 0; j < TNN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u32x4 bv;
-                        if constexpr (EPI == 12) bv = __builtin_amdgcn_raw_buffer_load_b128(bw, (unsigned)(wn0 + j * 32 + 8 * q + 4 * kl) * 4u, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                            if constexpr (EPI == 12) {
-                                v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
-                                v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
-                            }
-                            u32x2 w;
-                            w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
-                            *reinterpret_cast<u32x2*>(Rg + slot_off((unsigned)(32 * i + fl), (unsigned)(4 * j + q), (unsigned)kl)) = w;
-                        }
-                    }
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const unsigned r = 8u * t + lr;
-                    u32x4 v = *reinterpret_cast<const u32x4*>(Rg + r * 128u + ls * 16u);
-                    if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
-                    const unsigned pp = (ls ^ (r >> 1)) & 7u;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
-                }
-            } else {
-                unsigned char* Dg = Rg;                     // saved activation, 64 rows
-                unsigned char* Og = Rg + 8192;              // outputs, 64 rows
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const unsigned r = 8u * t + lr, pp = (ls ^ (r >> 1)) & 7u;
-                        u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(dw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldr + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
-                        if ((r >> 4) & 1u) { const unsigned a = y.x, b = y.y; y.x = y.z; y.y = y.w; y.z = a; y.w = b; }
-                        *reinterpret_cast<u32x4*>(Dg + r * 128u + ls * 16u) = y;
-                    }
-#pragma unroll
-                    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-                        for (int j = 0; j < TNN; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int i = 2 * h + ih;
-                                const unsigned off = slot_off((unsigned)(32 * ih + fl), (unsigned)(4 * j + q), (unsigned)kl);
-                                const u32x2 y = *reinterpret_cast<const u32x2*>(Dg + off);
-                                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                                v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
-                                v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
-                                u32x2 w;
-                                w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
-                                *reinterpret_cast<u32x2*>(Og + off) = w;
-                            }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const unsigned r = 8u * t + lr;
-                        u32x4 v = *reinterpret_cast<const u32x4*>(Og + r * 128u + ls * 16u);
-                        if ((r >> 4) & 1u) { const unsigned a = v.x, b = v.y; v.x = v.z; v.y = v.w; v.z = a; v.w = b; }
-                        const unsigned pp = (ls ^ (r >> 1)) & 7u;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, cw, ((unsigned)(wm0 + 64 * h + r) * (unsigned)p.ldc + (unsigned)(wn0 + 8 * pp)) * 2u, 0, 0);
-                    }
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = wm0 + i * 32 + fl;
-            const bool mok = m < limM;
-#pragma unroll
-            for (int j = 0; j < TNN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = wn0 + j * 32 + 8 * q + 4 * kl;
-                    const bool ok = mok && n < limN;              // N % 4 == 0: a group of 4 columns is in or out as a whole
-                    float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    if constexpr (EPI == 12) {
-                        const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(bw, ok ? (unsigned)n * 4u : OOB_OFF, 0, 0);
-                        v[0] = cham_tanhf(v[0] + __uint_as_float(bv.x)); v[1] = cham_tanhf(v[1] + __uint_as_float(bv.y));
-                        v[2] = cham_tanhf(v[2] + __uint_as_float(bv.z)); v[3] = cham_tanhf(v[3] + __uint_as_float(bv.w));
-                    }
-                    if constexpr (EPI == 13) {
-                        const u32x2 y = __builtin_amdgcn_raw_buffer_load_b64(dw, ok ? ((unsigned)m * (unsigned)p.ldr + (unsigned)n) * 2u : OOB_OFF, 0, 0);
-                        v[0] *= b1_lo(y.x) > 0.f ? 1.f : 0.2f; v[1] *= b1_hi(y.x) > 0.f ? 1.f : 0.2f;
-                        v[2] *= b1_lo(y.y) > 0.f ? 1.f : 0.2f; v[3] *= b1_hi(y.y) > 0.f ? 1.f : 0.2f;
-                    }
-                    u32x2 w;
-                    w.x = b1_pack(v[0], v[1]); w.y = b1_pack(v[2], v[3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(w, cw, ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB_OFF, 0, 0);
-                }
-        }
+        b1_nt_epilogue<EPI>(p, acc, m0, n0, wm0, wn0, lane, wave);
     } else {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int kl = lane_e >> 5, fl = lane_e & 31;
         GemmParams g;
         g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
         g.bias = nullptr; g.act = ACT_NONE; g.dref = nullptr; g.ldr = 0; g.dact = ACT_NONE; g.rs = nullptr; g.ldrs = 0; g.rs_div = 1;
         g.accumulate = p.accumulate; g.kchunk = p.kchunk; g.splits = p.splits; g.partial = p.partial; g.nbm = p.nbm; g.nbn = p.nbn; g.xcd_split = p.xcd_split;
         gemm_epilogue<EPI, TM, TNN>(g, acc, m0, n0, wm0, wn0, split, kl, fl);
     }
+}
+
+// ================================================================================================================================
+// NT with 64-BYTE SOURCE PIECES for the bf16-resident operands (round 6; what gemm_h2w_kernel is to gemm_h2_kernel).  gemm_b1_kernel's NT
+// requests fetch 32 rows x 32 bytes - a quarter of each 128-byte line, the next quarter a stage later when the vector L1 has long dropped
+// the line: per workgroup and 64 k, 4 096 cycles of L1 line fills (64 B / clk) against 2 048 cycles of MFMA work - which is why the NT
+// forms took 0.84 / 0.79 ms where the TN form of the same FLOPs takes 0.46 ms (profiles/r06_bf16_kernel_stats.csv).  Here a request
+// fetches 16 rows x 64 bytes; the ring holds TWO buffers of 64 k = four 16-k chunks:
+//   buffer = [A k 0..31 | A k 32..63 | B k 0..31 | B k 32..63], each slab [256 rows][64 bytes] = 16 KB (gemm_h2w_kernel's slab: LDS piece q of
+//   row r holds source piece q ^ ((r >> 2) & 3); the k-half of a 32-k slab: fragment offset ^ 32)
+//   per buffer D_j and wave: top  the B slabs of D_{j+1} (4 requests: the L2-resident operand)
+//                            chunks 0, 1, 2 - fragment reads of the next chunk, then 8 MFMAs
+//                            s_waitcnt vmcnt(0) + barrier (D_{j+1} has landed, every wave is past its last fragment read of D_j)
+//                            the A slabs of D_{j+2} into D_j's buffer (4 requests: the HBM-streamed operand, a whole buffer time to land)
+//                            chunk 3's MFMAs | fragment reads of chunk 0 of D_{j+1}
+// One barrier per 64 k, 32 MFMAs, 8 DMA requests.  K % 64 == 0 (the caller keeps gemm_b1_kernel otherwise).  Same products in another
+// grouping of the K loop: NOT bit-identical to gemm_b1_kernel (48-k stages: another summation order) - fp32 accumulation either way.
+#define B1W_SLAB 16384
+#define B1W_BUF (4 * B1W_SLAB)
+
+// four requests of one operand: the two 16-row halves of a wave's 32 rows, in the k 0..31 slab (descriptor r0) and the k 32..63 slab (r1 =
+// the same rows 64 bytes further)
+__device__ __forceinline__ void b1w_dma4(unsigned l0, unsigned l1, unsigned v0, unsigned v1, const u32x4& r0, const u32x4& r1) {
+    unsigned keep;
+    const unsigned l0b = l0 + 1024u, l1b = l1 + 1024u;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, 0 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, 0 offen lds\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, 0 offen lds\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(l0), "s"(l0b), "s"(l1), "s"(l1b), "v"(v0), "v"(v1), "s"(r0), "s"(r1)
+        : "memory");
+}
+
+// EPI: 12 = + bias -> tanh -> bf16, 13 = x leaky'(saved bf16 activation) -> bf16, 10 = plain -> bf16
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_b1w_kernel(P3Params p) {
+    constexpr int BM = 256, BN = 256, TM = 4, TNN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char p3_smem[];
+    const int nwg = p.nbm * p.nbn;
+    const int id = blockIdx.x;
+    const int q8 = nwg / 8, rr = nwg % 8, xcd = id % 8;       // XCD-aware bijective swizzle: the column tiles of an A panel share an L2
+    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + id / 8;
+    const int tile_m = swz / p.nbn, tile_n = swz % p.nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nd = p.K >> 6;                                   // 64-k buffers
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+    // descriptors: [0] = the rows from k = 0, [1] = the same rows 32 k (64 bytes) further; rows beyond the operand arrive as zeros
+    u32x4 ra[2], rb[2];
+    const size_t aall = (size_t)max(p.M - m0, 0) * p.lda * 2, ball = (size_t)max(p.N - n0, 0) * p.ldb * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ra[q] = p3_rsrc(p.A + (size_t)m0 * p.lda + 32 * q, (unsigned)min(aall > 64u * q ? aall - 64u * q : (size_t)0, (size_t)0xFFFFFFF0u));
+        rb[q] = p3_rsrc(p.B + (size_t)n0 * p.ldb + 32 * q, (unsigned)min(ball > 64u * q ? ball - 64u * q : (size_t)0, (size_t)0xFFFFFFF0u));
+    }
+    // lane l of wave w, request half r: LDS piece (row 32 w + 16 r + l / 4, piece l & 3) <- source piece (l & 3) ^ ((row >> 2) & 3)
+    const unsigned row = 32u * (unsigned)wave + (unsigned)(lane >> 2), sp = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+    unsigned va0 = (row * (unsigned)p.lda + 8u * sp) * 2u, va1 = va0 + 16u * (unsigned)p.lda * 2u;
+    unsigned vb0 = (row * (unsigned)p.ldb + 8u * sp) * 2u, vb1 = vb0 + 16u * (unsigned)p.ldb * 2u;
+
+    unsigned fa0[TM], fb0[TNN], fa1[TM], fb1[TNN];             // fragment offsets inside a slab: k-half 0, k-half 1 (^ 32)
+    {
+        const int l31 = lane & 31;
+        const unsigned fo = (unsigned)l31 * 64u + (unsigned)((lane >> 5) ^ ((l31 >> 2) & 3)) * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { fa0[i] = (unsigned)(wm0 + 32 * i) * 64u + fo; fa1[i] = fa0[i] ^ 32u; }
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) { fb0[j] = (unsigned)(wn0 + 32 * j) * 64u + fo; fb1[j] = fb0[j] ^ 32u; }
+    }
+
+    floatx16 acc[TM][TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_u8*)p3_smem;
+    const unsigned wave_off = (unsigned)wave * 2048u;
+    bf16x8 A0[TM], A1[TM], B0[TNN], B1[TNN];
+
+    auto mma = [&](const bf16x8 (&X)[TM], const bf16x8 (&Y)[TNN]) {          // swapped operands: accumulator = C^T (as gemm_b1_kernel's NT form)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[j], X[ii], acc[ii][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto rd = [&](bf16x8 (&X)[TM], bf16x8 (&Y)[TNN], const unsigned char* S, int slab, const unsigned (&fa)[TM], const unsigned (&fb)[TNN]) {
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii) X[ii] = *reinterpret_cast<const bf16x8*>(S + slab * B1W_SLAB + fa[ii]);
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) Y[j] = *reinterpret_cast<const bf16x8*>(S + (2 + slab) * B1W_SLAB + fb[j]);
+    };
+    auto dma_a = [&](unsigned buf) {
+        b1w_dma4(lds_base + buf + 0 * B1W_SLAB + wave_off, lds_base + buf + 1 * B1W_SLAB + wave_off, va0, va1, ra[0], ra[1]);
+        va0 += 128u; va1 += 128u;
+    };
+    auto dma_b = [&](unsigned buf) {
+        b1w_dma4(lds_base + buf + 2 * B1W_SLAB + wave_off, lds_base + buf + 3 * B1W_SLAB + wave_off, vb0, vb1, rb[0], rb[1]);
+        vb0 += 128u; vb1 += 128u;
+    };
+
+    if (nd > 0) {
+        dma_a(0u); dma_b(0u);
+        if (nd > 1) {
+            dma_a((unsigned)B1W_BUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        p3_barrier();
+        rd(A0, B0, p3_smem, 0, fa0, fb0);                        // chunk 0 of D_0
+        for (int j = 0; j < nd; ++j) {
+            const unsigned b0 = (unsigned)(j & 1) * (unsigned)B1W_BUF, b1 = (unsigned)B1W_BUF - b0;
+            const unsigned char* S0 = p3_smem + b0;
+            const unsigned char* S1 = p3_smem + b1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < nd) dma_b(b1);                           // (its buffer's last B reads are behind the barrier of iteration j - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            rd(A1, B1, S0, 0, fa1, fb1);                         // chunk 1: slab 0, k-half 1
+            mma(A0, B0);
+            rd(A0, B0, S0, 1, fa0, fb0);                         // chunk 2: slab 1, k-half 0
+            mma(A1, B1);
+            rd(A1, B1, S0, 1, fa1, fb1);                         // chunk 3
+            mma(A0, B0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // D_{j+1}: this wave's requests have landed; after the barrier every wave's have,
+            p3_barrier();                                         // and every wave is past its last fragment read of D_j
+            if (j + 2 < nd) dma_a(b0);                           // the A slabs of D_{j+2} into D_j's buffer
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < nd) rd(A0, B0, S1, 0, fa0, fb0);         // chunk 0 of D_{j+1}
+            mma(A1, B1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    b1_nt_epilogue<EPI>(p, acc, m0, n0, wm0, wn0, lane, wave);
 }
 
 // ---- split3 of an fp32 matrix into planes (weights, once per step; test helper for whole operands)
@@ -765,6 +924,20 @@ static int b1_launch(P3Params& p, hipStream_t st) {
     return CHAM_OK;
 }
 
+// NT launches take the 64-byte-piece kernel (gemm_b1w_kernel) when K % 64 == 0, unless switched off (A/B arm, tests): launch counter [4]
+static int g_b1_nt_wide = 1;
+extern "C" int cham_gemm_b16_dma_set_nt_wide(int on) { const int was = g_b1_nt_wide; g_b1_nt_wide = on ? 1 : 0; return was; }
+template <int EPI>
+static int b1w_launch(P3Params& p, hipStream_t st) {
+    g_p3_launches[6] = EPI; g_p3_launches[7] = 1; ++g_p3_launches[4];
+    constexpr int smem = 2 * B1W_BUF;
+    auto k = gemm_b1w_kernel<EPI>;
+    CHAM_SET_DYNAMIC_LDS(k, smem);
+    hipLaunchKernelGGL(k, dim3(p.nbm * p.nbn, 1, 1), dim3(512), smem, st, p);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+
 extern "C" int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb, int tn, void* C, int ldc, int M, int N, int K,
                                  const float* bias, int act, const void* dref, int ldr, int dact, int accumulate, float* workspace,
                                  size_t workspace_bytes, int splits_hint, void* stream) {
@@ -783,16 +956,17 @@ extern "C" int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb,
         if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;
         p.kchunk = K; p.splits = 1;
         ++g_p3_launches[2];
+        const bool wide = g_b1_nt_wide && (K & 63) == 0;
         if (dref) {
             if (bias || act != ACT_NONE || dact != ACT_LEAKY) return -CHAM_ERR_ARG;
-            return b1_launch<false, 13>(p, st);
+            return wide ? b1w_launch<13>(p, st) : b1_launch<false, 13>(p, st);
         }
         if (bias) {
             if (act != ACT_TANH) return -CHAM_ERR_ARG;
-            return b1_launch<false, 12>(p, st);
+            return wide ? b1w_launch<12>(p, st) : b1_launch<false, 12>(p, st);
         }
         if (act != ACT_NONE) return -CHAM_ERR_ARG;
-        return b1_launch<false, 10>(p, st);
+        return wide ? b1w_launch<10>(p, st) : b1_launch<false, 10>(p, st);
     }
     if ((M & 255) || (N & 255) || bias || act != ACT_NONE || dref) return -CHAM_ERR_ARG;
     if ((size_t)48 * lda * 2 >= (1ull << 31) || (size_t)48 * ldb * 2 >= (1ull << 31)) return -CHAM_ERR_ARG;

@@ -531,6 +531,10 @@ class NARRuntime:
             c0 = self._tile_counts_b16()
             e0.record()
         if dma:
+            if prof is not None:
+                import ctypes
+                cw0 = (ctypes.c_longlong * 8)()
+                self.lib.cham_gemm_p3_launch_counts(cw0, 0)
             check(self.lib.cham_gemm_b16_dma(ptr(A), lda, ptr(B), ldb, transA, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref), ldr, dact,
                                              accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()), "cham_gemm_b16_dma")
             if prof is not None:
@@ -539,7 +543,8 @@ class NARRuntime:
                 c = (ctypes.c_longlong * 8)()
                 self.lib.cham_gemm_p3_launch_counts(c, 0)
                 prof.append(dict(M=M, N=N, K=K, transA=transA, transB=transB, splits=int(c[7]), act=act, dref=dref is not None, dact=dact,
-                                 bias=bias is not None, rowscale=False, bf16=True, b1=True, out_f32=int(transA), tile=0, epi=int(c[6]), ev=(e0, e1)))
+                                 bias=bias is not None, rowscale=False, bf16=True, b1=True, b1w=bool(c[4] > cw0[4]), out_f32=int(transA), tile=0, epi=int(c[6]),
+                                 ev=(e0, e1)))
             return
         check(self.lib.cham_gemm_b16(ptr(A), lda, transA, ptr(B), ldb, transB, ptr(C), ldc, out_f32, M, N, K, ptr(bias), act, ptr(dref),
                                      ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, _stream()),

@@ -188,6 +188,11 @@ int cham_gemm_b16_dma(const void* A, int lda, const void* B, int ldb, int tn, vo
                       int act, const void* dref, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes,
                       int splits_hint, void* stream);
 void cham_gemm_p3_launch_counts(long long* out8, int reset);
+/* cham_gemm_b16_dma, NT forms with K % 64 == 0 (round 6): gemm_b1w_kernel stages 64-byte source pieces (16 rows x 64 bytes per LDS-DMA request,
+ * two 64-k buffers) where gemm_b1_kernel fetches a quarter of each 128-byte line per request; same products, another grouping of the K
+ * loop (fp32 accumulation either way; not bit-identical).  out8[4] of cham_gemm_p3_launch_counts counts its launches;
+ * cham_gemm_b16_dma_set_nt_wide(0) = always gemm_b1_kernel (A/B arm, tests); returns the previous setting. */
+int cham_gemm_b16_dma_set_nt_wide(int on);
 /* split3 of an fp32 matrix X [R, Cc] (row stride ld) into bf16 planes: dst[q][r][c] (planes plane_stride elements apart, row stride
  * ldd) and / or dstT[q][c][r] (the transposed matrix); either may be NULL.  a = h + m + l exactly (tests/test_split3_cpu.py). */
 int cham_split3(const float* X, int R, int Cc, int ld, void* dst, long long plane_stride, int ldd, void* dstT, long long plane_strideT,

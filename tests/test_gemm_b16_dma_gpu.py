@@ -163,3 +163,34 @@ def test_car_shapes_match_the_register_staged_kernels(gpu, which):
     d = (a.float() - b.float()).abs()
     assert float(d.max()) <= 2.0 ** -7 * float(a.float().abs().max())          # at most one bf16 ulp apart
     assert float((d > 0).float().mean()) < 2e-3                                # and only on boundary cases
+
+
+@pytest.mark.parametrize("M,N,K,kw", [(512, 256, 1024, {}), (1000, 512, 1024, dict(bias=True, act=2)), (1000, 512, 1024, dict(dref=True)), (300, 260, 64, {}),
+                                      (777, 1024, 128, dict(bias=True, act=2)), (256, 256, 192, dict(dref=True)), (2048, 1024, 1024, dict(ragged_ld=64))])
+def test_nt_wide_pieces_kernel_against_the_narrow_one(gpu, M, N, K, kw):
+    """gemm_b1w_kernel (round 6: 64-byte source pieces, K % 64 == 0) and gemm_b1_kernel (32-byte pieces, 48-k stages) on the same operands: each
+    within the float64 tolerance of _nt(), and within one bf16 ulp of each other (another grouping of the K loop: fp32 sums differ in the last
+    bits, the bf16 rounding of the output may then differ by one ulp); launch counter [4] proves which kernel ran."""
+    lib = _lib()
+    assert lib.cham_gemm_b16_dma_set_nt_wide(1) in (0, 1)
+    try:
+        c0 = _counts(lib)
+        wide = _nt(gpu, M, N, K, seed=K + M, **kw)
+        assert _counts(lib)[4] == c0[4] + 1
+        lib.cham_gemm_b16_dma_set_nt_wide(0)
+        c0 = _counts(lib)
+        narrow = _nt(gpu, M, N, K, seed=K + M, **kw)
+        assert _counts(lib)[4] == c0[4]
+    finally:
+        lib.cham_gemm_b16_dma_set_nt_wide(1)
+    d = (wide.float() - narrow.float()).abs()
+    assert bool((d <= narrow.float().abs() * 2.0 ** -7 + 1e-6).all()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.05          # ... and on few entries
+
+
+def test_nt_wide_kernel_is_not_taken_when_k_is_no_multiple_of_64(gpu):
+    lib = _lib()
+    c0 = _counts(lib)
+    _nt(gpu, 256, 256, 1040, seed=3)
+    _nt(gpu, 256, 256, 48, seed=4)
+    assert _counts(lib)[4] == c0[4]
