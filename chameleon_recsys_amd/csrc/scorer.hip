@@ -149,9 +149,15 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__
         const float4 a = pin[k];
         const float4 p0 = ld4(pc + 4 * k);
         float4 s = make_float4(a.x + p0.x, a.y + p0.y, a.z + p0.z, a.w + p0.w);
-        for (int c = 1; c <= N; ++c) {
-            const float4 x = ld4(pc + (size_t)c * C + 4 * k);
-            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        // eight candidate rows in flight per thread (round 6: left to the compiler the loop issued one 8- / 16-byte load at a time - 0.44 ms for the
+        // 0.5 GB of the bf16 configuration, 1.1 TB/s, on the main lane's tail); the adds stay in ascending row order: same sums, bit for bit
+        for (int c = 1; c <= N; c += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = ld4(pc + (size_t)min(c + u, N) * C + 4 * k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c + u <= N) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
         }
         reinterpret_cast<float4*>(dU + (size_t)bt * C)[k] = s;
         reinterpret_cast<float4*>(dV + (size_t)bt * C)[k] = a;

@@ -1793,6 +1793,8 @@ class NARModuleModel:
         """tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8).apply_gradients (nar_model.py:708-722) + the dense L2 term."""
         rt, L = self.rt, self.rt.layout
         rt.global_step += 1           # (also invalidates the bf16 weight shadows: NARRuntime.refresh_shadows keys on it)
+        if not rt.capturing and getattr(self, '_plan', None) is not None:
+            self._plan.eager_steps = getattr(self._plan, 'eager_steps', 0) + 1      # (GraphedTrainStep captures warm shapes only)
         t = rt.global_step
         lr_t = self.adam_lr_t(t)
         if rt.dev_scalars:
@@ -1972,6 +1974,11 @@ class GraphedTrainStep:
             return "dropout / cold-start analysis / presampling off"
         if self.key is not None and self.shape_key(d) != self.key:
             return "another batch shape than the captured one"
+        if self.graph is None:      # capture needs a warm shape: buffers, workspaces, the step-scalar record and the kernels' dynamic-LDS
+            # attributes are set up by the first eager step - none of that belongs inside a stream capture
+            pl = rt._plans.get((d['B'], d['T'], m.negative_samples, m.negative_sample_from_buffer, d['Bg'], rt.p3, rt.h2))
+            if pl is None or getattr(pl, 'eager_steps', 0) < 1 or rt.scalars is None:
+                return "no eager training step has run on this batch shape yet (run one train_step first)"
         return None
 
     def _make_slot(self, d):

@@ -86,6 +86,9 @@ def test_what_is_not_capturable_is_refused_with_a_reason(gpu):
     d_full, d_ragged = model.upload_batch(*full[0]), model.upload_batch(*ragged[0])
     assert "empty recent-clicks state" in gs.supports(d_full)
     st.update_from_device_batch(d_full['aci'], d_full['g_event_ts'])
+    assert "no eager training step" in gs.supports(d_full)            # the shape is cold: buffers / kernel attributes are set up by an eager step
+    model.feed_state(st, st)
+    model.train_step(d_full)
     assert gs.supports(d_full) is None
     assert "compacted" in gs.supports(d_ragged)
     with pytest.raises(RuntimeError, match="compacted"):
