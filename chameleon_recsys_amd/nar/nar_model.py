@@ -213,8 +213,9 @@ class NARRuntime:
         # 1.44 -> 1.375 ms), the TN weight gradient loses 2.5 % stand-alone and 6-19 % in the step, the plane-writing combine 0.09 ms: the step is
         # 0.05 ms SLOWER (7.89 vs 7.84 ms) - the NT forms were power-limited, not line-fill-limited.  Hence OFF by default; CHAM_H2_BLOCKED=1 is
         # the arm (needs the 64-byte-piece NT kernel, CHAM_H2_NT_WIDE=1).
-        self.h2_blocked = (self.h2 and os.environ.get("CHAM_H2_BLOCKED", "0") == "1" and os.environ.get("CHAM_H2_NT_WIDE", "1") == "1"
-                           and self.layout.C % 32 == 0)
+        blk = os.environ.get("CHAM_H2_BLOCKED", "0")          # 1 = both matrices, dz2 / z1 = only that one (A/B arms)
+        self.h2_blocked = (self.h2 and blk in ("1", "dz2", "z1") and os.environ.get("CHAM_H2_NT_WIDE", "1") == "1" and self.layout.C % 32 == 0)
+        self.h2_blocked_which = blk if self.h2_blocked else "0"
         # NT forms of those GEMMs (CAR forward, CAR dgrad) on the 64-byte-source-piece kernel (csrc/gemm_h2.hip gemm_h2w_kernel, round 5);
         # CHAM_H2_NT_WIDE=0: the 32-byte-piece kernel of round 4 (bit-identical results, A/B arm).  A LIBRARY-wide setting, made once per
         # process when the library is loaded (chameleon_recsys_amd/_lib.py): constructing a second runtime never flips the kernels of the first
@@ -774,8 +775,8 @@ class StepPlan:
                 # whole (+ one: a workgroup of the fused dgrad addresses two tiles from its first row's), zero-initialised.
                 tiles = -(-Rc // 256) + 1
                 if rt.h2_blocked:
-                    self.z1_tiles = tiles
-                    self.dz2_tiles = tiles if (rt.dm_fused and 32 <= NC <= 256) else 0
+                    self.z1_tiles = tiles if rt.h2_blocked_which in ("1", "z1") else 0
+                    self.dz2_tiles = tiles if (rt.dm_fused and 32 <= NC <= 256 and rt.h2_blocked_which in ("1", "dz2")) else 0
                 self.Z1p = (torch.zeros(2, blocked_plane_elements(self.z1_tiles, C), dtype=torch.float16, device=dev) if self.z1_tiles
                             else torch.zeros(2, Rc, C, dtype=torch.float16, device=dev))
                 self.dZ2p = (torch.zeros(2, blocked_plane_elements(self.dz2_tiles, C), dtype=torch.float16, device=dev) if self.dz2_tiles
