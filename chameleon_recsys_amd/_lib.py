@@ -24,6 +24,8 @@ _SIGNATURES = {
     "cham_item_assemble": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
     "cham_item_assemble_lds": (c_int, [P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, c_int, P, c_int, P, c_int, P, P, P, P, P, P]),
     "cham_feature_bwd": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "cham_feature_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "cham_feature_bwd_ws": (c_int, [P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "cham_emb_grad_scan": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     "cham_group_rows_workspace_bytes": (c_size_t, [c_int]),
     "cham_group_rows_segments_len": (c_size_t, [c_int]),

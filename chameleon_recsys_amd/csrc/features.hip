@@ -684,9 +684,72 @@ extern "C" int cham_item_assemble_lds(const int64_t* ids, int R, int g1_begin, i
     return CHAM_OK;
 }
 
+// The same column sums with COALESCED reads (round 6).  k_scale_bwd_cols gives every column a workgroup whose lanes walk the ROWS: each
+// load touches 4 bytes of a different 128-byte line - 32 x read amplification (164 MB of HBM / 1.1 GB of L2 traffic for the 17 MB item
+// matrix) and 0.06-0.13 ms per call on the serial tail of the step, behind the W2 weight gradient, where nothing else runs.  Here a
+// workgroup owns 64 COLUMNS x a chunk of rows: wave w adds rows r0 + w, r0 + w + 4, ... (lanes = 64 consecutive columns: 256-byte row
+// segments, eight loads in flight), writes its partial sums; a second launch adds the partials of a column in ascending (chunk, wave)
+// order: deterministic (another order than k_scale_bwd_cols': the sums differ in the last bits).  workspace: SBW_CHUNKS x 4 x 2 x F floats.
+#define SBW_CHUNKS 64
+__global__ __launch_bounds__(256) void k_scale_bwd_part(const float* __restrict__ dxs, const float* __restrict__ xraw, int R, int F, int rows_per_chunk,
+                                                        float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float sg = 0.f, sb = 0.f;
+    if (c < F) {
+        for (int r = r0 + w; r < r1; r += 16) {
+            float g[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = min(r + 4 * u, r1 - 1);
+                g[u] = dxs[(size_t)rr * F + c]; x[u] = xraw[(size_t)rr * F + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 4 * u < r1) { sg += g[u] * x[u]; sb += g[u]; }
+        }
+        float* o = part + ((size_t)(chunk * 4 + w) * 2) * F;
+        o[c] = sg; o[F + c] = sb;
+    }
+}
+__global__ __launch_bounds__(256) void k_scale_bwd_fin(const float* __restrict__ part, int F, int nparts, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    float sg = 0.f, sb = 0.f;
+    for (int q = 0; q < nparts; q += 8) {
+        float g[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* o = part + ((size_t)min(q + u, nparts - 1) * 2) * F;
+            g[u] = o[c]; b[u] = o[F + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q + u < nparts) { sg += g[u]; sb += b[u]; }
+    }
+    dgamma[c] = sg; dbeta[c] = sb;
+}
+
 extern "C" int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, void* stream) {
     if (!dxs || !xraw || !dgamma || !dbeta || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
     hipLaunchKernelGGL(k_scale_bwd_cols, dim3(F), dim3(256), 0, (hipStream_t)stream, dxs, xraw, R, F, dgamma, dbeta);
+    CHAM_CHECK_LAUNCH();
+    return CHAM_OK;
+}
+extern "C" size_t cham_feature_bwd_workspace_bytes(int F) { return (size_t)SBW_CHUNKS * 4 * 2 * (size_t)F * sizeof(float); }
+// cham_feature_bwd through the coalesced two-launch form above (workspace >= cham_feature_bwd_workspace_bytes(F); private to the call's stream)
+extern "C" int cham_feature_bwd_ws(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, float* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!dxs || !xraw || !dgamma || !dbeta || R <= 0 || F <= 0) return -CHAM_ERR_ARG;
+    if (!workspace || workspace_bytes < cham_feature_bwd_workspace_bytes(F)) return -CHAM_ERR_ARG;
+    int rows_per_chunk = (R + SBW_CHUNKS - 1) / SBW_CHUNKS;
+    if (rows_per_chunk < 32) rows_per_chunk = 32;
+    const int nch = (R + rows_per_chunk - 1) / rows_per_chunk;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scale_bwd_part, dim3((F + 63) / 64, nch), dim3(256), 0, st, dxs, xraw, R, F, rows_per_chunk, workspace);
+    hipLaunchKernelGGL(k_scale_bwd_fin, dim3((F + 255) / 256), dim3(256), 0, st, workspace, F, nch * 4, dgamma, dbeta);
     CHAM_CHECK_LAUNCH();
     return CHAM_OK;
 }

@@ -354,9 +354,15 @@ __global__ __launch_bounds__(256) void k_combine_bwd_pad_final(const float* __re
                                                                float* __restrict__ dv_row) {
     for (int k = threadIdx.x; k < C / 4; k += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = 0; c < nchunk; ++c) {
-            const float4 x = reinterpret_cast<const float4*>(partial + (size_t)c * C)[k];
-            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        // ONE workgroup adds the ~120 chunk partials of the pad slot: sixteen loads in flight per thread (round 6: one at a time this was a
+        // chain of ~120 dependent L2 / HBM latencies - 0.11-0.14 ms on the critical chain of the backward tail); ascending chunk order kept
+        for (int c = 0; c < nchunk; c += 16) {
+            float4 x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = reinterpret_cast<const float4*>(partial + (size_t)min(c + u, nchunk - 1) * C)[k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c + u < nchunk) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         reinterpret_cast<float4*>(dv_row)[k] = acc;
     }

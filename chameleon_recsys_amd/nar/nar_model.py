@@ -185,6 +185,10 @@ class NARRuntime:
         # CHAM_DEV_SCALARS=0: the by-value entry points (A/B arm; bit-identical results).  capturing: a graph capture is in progress - the
         # record is NOT written by the step's code (the replay writes it in front of every launch of the graph).
         self.dev_scalars = os.environ.get("CHAM_DEV_SCALARS", "1") == "1"
+        # round 6, the serial tail of the backward pass (profiles/r06_notes.md section 5b): dgamma / dbeta column sums with coalesced reads
+        # through a workspace (CHAM_FEATURE_BWD_WS), the user-context half of the PreCAR input's backward on the third lane (CHAM_TAIL_SPLIT)
+        self.feature_bwd_ws = os.environ.get("CHAM_FEATURE_BWD_WS", "1") == "1"
+        self.tail_split = os.environ.get("CHAM_TAIL_SPLIT", "1") == "1"
         self.capturing = False
         self.scalars = None
         # 'f32': exact fp32 MFMA (BASELINE config 2, the default); 'bf16': operands of every Dense / matmul rounded to bf16 on
@@ -1755,29 +1759,56 @@ class NARModuleModel:
             else:
                 check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
                       "cham_combine_bwd")
-            if not drop:
-                rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
-                rt.colsum(pl.dU, C, BT, C, g('b1'))
-                rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
-                rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
-                rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
-            # scale/center + embedding tables (fixed summation order: the step is bit-reproducible)
-            check(lib.cham_feature_bwd(ptr(pl.dXc), ptr(pl.Xc_raw), BT, Fc, ptr(g('gamma_ctx')), ptr(g('beta_ctx')), st), "cham_feature_bwd")
-            check(lib.cham_feature_bwd(ptr(pl.dXi), ptr(pl.Xi_raw), RV, Fi, ptr(g('gamma_item')), ptr(g('beta_item')), st), "cham_feature_bwd")
             n_rows_cat = d['cat'].shape[1]
-            for kind, feat, c0, dim, card, off in rt.ctx_emb_groups:
-                check(lib.cham_emb_grad_scan(ptr(pl.dXc), BT, Fc, c0, dim, ptr(p('gamma_ctx')), d['cat'].data_ptr() + 8 * feat * n_rows_cat,
-                                             None, card, rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
-            for kind, feat, c0, dim, card, off in rt.item_emb_groups:
-                if kind == COL_ITEMEMB:
-                    if getattr(pl, 'grouped_ev', None) is not None:
-                        torch.cuda.current_stream().wait_event(pl.grouped_ev)
-                    check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')), ptr(pl.ids_all), ptr(pl.perm),
-                                                    ptr(pl.seg), rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_grouped")
+
+            def feature_bwd(dX, Xraw, R, F, gname, bname):
+                # dgamma / dbeta column sums: the coalesced two-launch form through this lane's workspace (CHAM_FEATURE_BWD_WS=0: one workgroup per column)
+                if rt.feature_bwd_ws:
+                    wsl = rt._lane_ws('gemm_ws')
+                    check(lib.cham_feature_bwd_ws(ptr(dX), ptr(Xraw), R, F, ptr(g(gname)), ptr(g(bname)), ptr(wsl), wsl.numel() * 4, _stream()),
+                          "cham_feature_bwd_ws")
                 else:
-                    check(lib.cham_emb_grad_scan(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')),
-                                                 rt.meta_cat.data_ptr() + 8 * feat * rt.n_items, ptr(pl.ids_all), card,
-                                                 rt.grads.data_ptr() + 4 * off, st), "cham_emb_grad_scan")
+                    check(lib.cham_feature_bwd(ptr(dX), ptr(Xraw), R, F, ptr(g(gname)), ptr(g(bname)), _stream()), "cham_feature_bwd")
+
+            def ctx_chain():      # user-context half of the PreCAR input: weight gradient, bias, d(features), scale / center, embedding tables
+                if not drop:
+                    rt.gemm(pl.Xc_s, pl.dU, g('W1c'), Fc, C, BT, Fc, C, C, transA=1, splits=0)
+                    rt.colsum(pl.dU, C, BT, C, g('b1'))
+                    rt.gemm(pl.dU, p('W1c'), pl.dXc, BT, Fc, C, C, C, Fc, transB=1)
+                feature_bwd(pl.dXc, pl.Xc_raw, BT, Fc, 'gamma_ctx', 'beta_ctx')
+                for kind, feat, c0, dim, card, off in rt.ctx_emb_groups:
+                    check(lib.cham_emb_grad_scan(ptr(pl.dXc), BT, Fc, c0, dim, ptr(p('gamma_ctx')), d['cat'].data_ptr() + 8 * feat * n_rows_cat,
+                                                 None, card, rt.grads.data_ptr() + 4 * off, _stream()), "cham_emb_grad_scan")
+
+            def item_chain():     # item half
+                if not drop:
+                    rt.gemm(pl.Xi_s, pl.dV, g('W1i'), Fi, C, RV, Fi, C, C, transA=1, splits=0)
+                    rt.gemm(pl.dV, p('W1i'), pl.dXi, RV, Fi, C, C, C, Fi, transB=1)
+                feature_bwd(pl.dXi, pl.Xi_raw, RV, Fi, 'gamma_item', 'beta_item')
+                for kind, feat, c0, dim, card, off in rt.item_emb_groups:
+                    if kind == COL_ITEMEMB:
+                        if getattr(pl, 'grouped_ev', None) is not None:
+                            torch.cuda.current_stream().wait_event(pl.grouped_ev)
+                        check(lib.cham_emb_grad_grouped(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')), ptr(pl.ids_all), ptr(pl.perm),
+                                                        ptr(pl.seg), rt.grads.data_ptr() + 4 * off, _stream()), "cham_emb_grad_grouped")
+                    else:
+                        check(lib.cham_emb_grad_scan(ptr(pl.dXi), RV, Fi, c0, dim, ptr(p('gamma_item')),
+                                                     rt.meta_cat.data_ptr() + 8 * feat * rt.n_items, ptr(pl.ids_all), card,
+                                                     rt.grads.data_ptr() + 4 * off, _stream()), "cham_emb_grad_scan")
+
+            # Round 6: the two halves are independent once dU / dV exist, and they are the SERIAL tail of the step - ~25 latency-bound launches
+            # behind the W2 weight gradient with the chip otherwise idle.  The user-context half goes to the third lane, the item half
+            # stays here (CHAM_TAIL_SPLIT=0: both on this lane, the order of rounds 1-5).  Same kernels, same arguments: same results.
+            if on and rt.tail_split and not drop and st == main_stream.cuda_stream:
+                e_duv = mark()
+                with aux(e_duv):
+                    ctx_chain()
+                    e_ctx = mark()
+                item_chain()
+                main_stream.wait_event(e_ctx)
+            else:
+                ctx_chain()
+                item_chain()
 
         if on:
             main_wait(e_dZ1in)

@@ -85,6 +85,11 @@ int cham_item_assemble_lds(const int64_t* ids, int R, int g1_begin, int g2_begin
                            const float* params, const float* gamma, const float* beta, float* xraw, float* xs, void* stream);
 /* backward of the two above, scale/center part (nar_model.py:887-907): dgamma[c] = sum_r dxs[r,c] * xraw[r,c], dbeta[c] = sum_r dxs[r,c] */
 int cham_feature_bwd(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, void* stream);
+/* the same column sums with coalesced reads, two launches through a workspace private to the call's stream (round 6: the one-workgroup-
+ * per-column form reads 4 bytes of every 128-byte line); deterministic, another summation order than cham_feature_bwd */
+size_t cham_feature_bwd_workspace_bytes(int F);
+int cham_feature_bwd_ws(const float* dxs, const float* xraw, int R, int F, float* dgamma, float* dbeta, float* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* --- K6 embedding-table gradients (the IndexedSlices TF builds for tf.nn.embedding_lookup, nar_model.py:741, 918), DETERMINISTIC:
  * rows of dxs that looked up the same table row are summed in a fixed order, no float atomics.

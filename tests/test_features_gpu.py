@@ -93,3 +93,33 @@ def test_item_assemble_lds_equals_elementwise(gpu, dataset, n_items, D, R):
     segs = rt.item_segs.cpu().numpy()
     ace_seg = [sg for sg in segs if sg[0] == 0][0]
     assert torch.equal(outs[1][0][:, ace_seg[1]:ace_seg[1] + ace_seg[2]], rt.ace.cpu()[ids.cpu()])
+
+
+@pytest.mark.parametrize("R,F", [(10729, 408), (4864, 72), (37, 8), (1, 4), (5000, 1024), (300, 100)])
+def test_feature_bwd_coalesced_column_sums(gpu, R, F):
+    """cham_feature_bwd_ws (round 6: 64 columns x a row chunk per workgroup, coalesced row segments, partials added in a fixed order) against
+    float64 and against cham_feature_bwd (one workgroup per column): dgamma = sum_r dxs * xraw, dbeta = sum_r dxs; repeatable bit for bit."""
+    import torch
+    from chameleon_recsys_amd import _lib
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator(device=gpu).manual_seed(R + F)
+    dxs = torch.randn(R, F, device=gpu, generator=g)
+    xraw = torch.randn(R, F, device=gpu, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    need = lib.cham_feature_bwd_workspace_bytes(F)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=gpu)
+    outs = []
+    for _ in range(2):
+        dg, db = torch.full((F,), float('nan'), device=gpu), torch.full((F,), float('nan'), device=gpu)
+        check(lib.cham_feature_bwd_ws(ptr(dxs), ptr(xraw), R, F, ptr(dg), ptr(db), ptr(ws), need, st), "cham_feature_bwd_ws")
+        outs.append((dg.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dg0, db0 = torch.empty(F, device=gpu), torch.empty(F, device=gpu)
+    check(lib.cham_feature_bwd(ptr(dxs), ptr(xraw), R, F, ptr(dg0), ptr(db0), st), "cham_feature_bwd")
+    rg, rb = (dxs.double() * xraw.double()).sum(0), dxs.double().sum(0)
+    tol = 1e-6 * max(1.0, R ** 0.5) * 4
+    for got, ref, old in ((outs[0][0], rg, dg0), (outs[0][1], rb, db0)):
+        assert float((got.double() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+        assert float((got - old).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+    assert lib.cham_feature_bwd_ws(ptr(dxs), ptr(xraw), R, F, ptr(dg0), ptr(db0), ptr(ws), need - 4, st) == -22      # workspace too small
