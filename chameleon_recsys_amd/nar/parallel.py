@@ -10,6 +10,8 @@ embedding tables; CHAM_DP_MODE=sharded reduce-scatters the whole buffer to owner
 the touched rows of the item table - see DataParallelNAR).  The state update after the step is applied identically on every rank from the
 replicated ids - no communication.
 """
+import logging
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -78,6 +80,10 @@ class DataParallelNAR:
                              "is for the allreduce / sparse / sparse_rs modes")
         self.comm_bf16 = self.mode != "sharded" and (want == "bf16" or (want == "auto" and getattr(rt, 'gemm_dtype', 'f32') == 'bf16'))
         self._comm16, self._early16 = None, None
+        if self.comm_bf16 and self.world > 1 and self.rank == 0:
+            logging.getLogger(__name__).info("data-parallel dense gradients are exchanged and summed in bf16 (CHAM_DP_GRAD_DTYPE=%s, "
+                                             "gemm_dtype=%s); CHAM_DP_GRAD_DTYPE=f32 keeps the exchange in fp32", want,
+                                             getattr(rt, 'gemm_dtype', 'f32'))
         self.last_exchange_bytes = 0       # payload this rank handed to the collectives of the last step (all modes; bookkeeping only)
         # how often each collective ran (tests assert the reduce-scatter / all-gather branches really executed with world > 1;
         # bench.py's "dp" object reports them)
