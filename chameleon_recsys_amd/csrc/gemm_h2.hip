@@ -49,7 +49,13 @@ struct H2Params {
     // TILE-BLOCKED operands (common.h h2b_index; round 6): *_tiles > 0 = the operand's planes are stored [row tiles][ld / 32][256][32] with
     // that many row tiles ALLOCATED (rows beyond the matrix: zeros); 0 = row-major.  NT: A only (B = the weight planes); TN: A and / or B.
     int a_tiles, b_tiles, r_blk;               // r_blk: the dgrad's saved-activation h plane (dref) is tile-blocked
+    // GROUP SUMS in the dgrad epilogue (EPI 3; round 6): rows come in groups of `ggrp` consecutive rows (one click's candidates) whose column
+    // sums the caller needs next (dU of the PreCAR combine, csrc/scorer.hip) - 1 GB of fp32 C re-read by a kernel of its own before.  Every
+    // wave adds up what its 128-row chunk q = row / 128 holds of each group it touches and writes piece (q, k) = k-th group of the chunk
+    // (group (128 q) / ggrp + k) to gsum[(q * H2_GS_K + k) * N + column]; the consumer adds the <= 3 pieces of a group in chunk order.
+    float* gsum; int ggrp;
 };
+#define H2_GS_K 5                  // groups a 128-row chunk can touch when ggrp >= 32: floor(127 / ggrp) + 2
 
 #define H2_SLAB 8192
 #define H2_STAGE (4 * H2_SLAB)
@@ -133,13 +139,67 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
         const __amdgpu_buffer_rsrc_t dw = make_window(rb ? p.dref + ((size_t)(m0 >> 8) * (size_t)(p.ldr >> 5) + (size_t)(n0 >> 5)) * H2B_BLOCK
                                                          : p.dref + (size_t)m0 * p.ldr + n0);
         const int rstride = rb ? 64 : p.ldr * 2;              // bytes from a row to the next inside the window
+        // ---- group sums (see H2Params::gsum).  Per 32-row block i the rows split at most once (ggrp >= 32): local rows < bnd belong to the
+        // group the block starts in, the rest to the next one.  Lane (kl, fl) holds column fl, local rows 4 kl + (e & 3) + 8 (e >> 2): it adds its
+        // values in ascending e, the two halves of the wave are added at the end of a group (a + b = b + a: both halves hold the same sum).
+        const bool gs = p.gsum != nullptr;
+        const int G = gs ? p.ggrp : 1, rbase = m0 + wm0;
+        float* gw = gs ? p.gsum + (size_t)(rbase >> 7) * H2_GS_K * (size_t)p.N + n0 + wn0 + fl : nullptr;
+        float cur[TNN], hik[TNN];
+#pragma unroll
+        for (int j = 0; j < TNN; ++j) { cur[j] = 0.f; hik[j] = 0.f; }
+        int kk = 0;
+        auto emit = [&]() {
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) {
+                const float x = cur[j] + __shfl_xor(cur[j], 32, 64);
+                if (kl == 0 && wn0 + j * 32 + fl < limN) gw[(size_t)kk * p.N + j * 32] = x;
+            }
+            ++kk;
+        };
+        int bnd = 64;
+        auto block_begin = [&](int i) {           // wave-uniform
+            if (!gs) return;
+            const int s0 = rbase + 32 * i, gf = s0 / G;
+            bnd = (gf + 1) * G - s0;
+            if (i > 0 && bnd == G) {              // the block starts a group: the running sum is the previous group's
+                emit();
+#pragma unroll
+                for (int j = 0; j < TNN; ++j) cur[j] = 0.f;
+            }
+        };
+        auto block_add = [&](int j, const float (&v)[16]) {
+            if (!gs) return;
+            float lo = 0.f;
+            if (bnd >= 32) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lo += v[e];
+            } else {
+                float hi = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool first = (e & 3) + 8 * (e >> 2) + 4 * kl < bnd;
+                    lo += first ? v[e] : 0.f;
+                    hi += first ? 0.f : v[e];
+                }
+                hik[j] = hi;
+            }
+            cur[j] += lo;
+        };
+        auto block_end = [&]() {
+            if (!gs || bnd >= 32) return;
+            emit();
+#pragma unroll
+            for (int j = 0; j < TNN; ++j) cur[j] = hik[j];
+        };
         if (limM >= wm0 + TM * 32 && limN >= wn0 + TNN * 32) {
             // interior wave tile (wave-uniform test; round 5): the row part of an element's address is uniform - c(e) * ld with
             // c(e) = (e & 3) + 8 (e >> 2) - and rides in the SGPR soffset of the buffer instructions, one VGPR offset per 32x32 block
             // and matrix: no per-element address arithmetic or range selects (the generic form below: ~10 VALU per element of an
             // epilogue that is VALU-bound; same device as gemm_epilogue's interior path)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                block_begin(i);
 #pragma unroll
                 for (int j = 0; j < TNN; ++j) {
                     const unsigned col = (unsigned)(wn0 + j * 32 + fl), rowb = (unsigned)(wm0 + i * 32 + 4 * kl);
@@ -152,17 +212,23 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
                         const int ce = (e & 3) + 8 * (e >> 2);
                         y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, voffr, ce * rstride, 0);
                     }
+                    float v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ce = (e & 3) + 8 * (e >> 2);
-                        const float v = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, voff, ce * p.ldc * 4, 0);
+                        v[e] = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), cw, voff, ce * p.ldc * 4, 0);
                     }
+                    block_add(j, v);
                 }
+                block_end();
+            }
+            if (gs) emit();
             return;
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            block_begin(i);
 #pragma unroll
             for (int j = 0; j < TNN; ++j) {
                 const int col = wn0 + j * 32 + fl;
@@ -178,12 +244,18 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
                                            : ((unsigned)row * (unsigned)p.ldr + (unsigned)col) * 2u;
                     y[e] = __builtin_amdgcn_raw_buffer_load_b16(dw, ok ? ro : OOB_OFF, 0, 0);
                 }
+                float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), cw, offs[e], 0, 0);
+                    // (rows at or beyond M: the operand's rows arrive as zeros - v = 0, nothing is added to a group sum)
+                    v[e] = acc[i][j][e] * ((short)y[e] > 0 ? 1.f : 0.2f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), cw, offs[e], 0, 0);
                 }
+                block_add(j, v);
             }
+            block_end();
+        }
+        if (gs) emit();
     } else {
         GemmParams g;
         g.A = nullptr; g.B = nullptr; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = 0; g.ldb = 0; g.ldc = p.ldc;
@@ -795,11 +867,17 @@ static int h2_launch(H2Params& p, hipStream_t st) {
 // the matrix ZERO; plane stride >= tiles * 256 * ld); 0: row-major.  dref_blocked: the dgrad's saved-activation plane likewise.
 //   NT: A may be blocked (needs K % 32 == 0 and the 64-byte-piece kernel, ld == K); B (the weight planes) is row-major.
 //   TN: A and B independently.  Results are bit-identical to the row-major operands' (tests/test_gemm_h2_gpu.py).
-extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
-                             int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
-                             const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
-                             int a_tiles, int b_tiles, int dref_blocked, void* stream) {
+extern "C" size_t cham_gemm_h2_groupsum_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)2 * ((M + 255) / 256) * H2_GS_K * (size_t)N * sizeof(float);
+}
+static int h2_run(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                  int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                  const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                  int a_tiles, int b_tiles, int dref_blocked, int group_rows, float* groupsum, size_t groupsum_bytes, void* stream) {
     if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0 || a_tiles < 0 || b_tiles < 0) return -CHAM_ERR_ARG;
+    if (groupsum && (tn || !dref_h || group_rows < 32 || groupsum_bytes < cham_gemm_h2_groupsum_bytes(M, N) || ((uintptr_t)groupsum & 15)))
+        return -CHAM_ERR_ARG;
     {   // tile-blocked operands: whole column blocks, enough row tiles, planes that do not overlap
         const long a_rows = tn ? K : M, b_rows = tn ? K : N;
         if (a_tiles && ((lda & 31) || (long)a_tiles * 256 < a_rows || a_plane_stride < (long long)a_tiles * (lda >> 5) * H2B_BLOCK)) return -CHAM_ERR_ARG;
@@ -816,6 +894,7 @@ extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, c
     p.dref = reinterpret_cast<const unsigned short*>(dref_h); p.ldr = ldr; p.partial = workspace; p.xcd_split = 0; p.accumulate = 0;
     p.nbm = (M + 255) / 256; p.nbn = (N + 255) / 256;
     p.a_tiles = a_tiles; p.b_tiles = b_tiles; p.r_blk = dref_blocked ? 1 : 0;
+    p.gsum = groupsum; p.ggrp = group_rows;
     hipStream_t st = (hipStream_t)stream;
     if (!tn) {
         if ((K & 15) || accumulate) return -CHAM_ERR_ARG;
@@ -868,6 +947,24 @@ extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, c
     }
     p.accumulate = accumulate;
     return h2_launch<true, 0>(p, st);
+}
+
+extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                             int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                             const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
+                             int a_tiles, int b_tiles, int dref_blocked, void* stream) {
+    return h2_run(A, a_plane_stride, lda, a_scale, B, b_plane_stride, ldb, b_scale, tn, C, ldc, M, N, K, bias, act, dref_h, ldr, dact, accumulate,
+                  workspace, workspace_bytes, splits_hint, a_tiles, b_tiles, dref_blocked, 0, nullptr, 0, stream);
+}
+// The CAR dgrad (NT, x leaky'(dref_h)) with GROUP SUMS from its epilogue: rows come in groups of `group_rows` >= 32 consecutive rows; every
+// 128-row chunk q writes the column sums of what it holds of its k-th group (group (128 q) / group_rows + k) to
+// groupsum[(q * 5 + k) * N + column] (cham_gemm_h2_groupsum_bytes(M, N) bytes; consumer: cham_combine_bwd_gs).  C is written as by cham_gemm_h2b.
+extern "C" int cham_gemm_h2_dgrad_gs(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
+                                     int ldb, const float* b_scale, float* C, int ldc, int M, int N, int K, const void* dref_h, int ldr,
+                                     int a_tiles, int dref_blocked, int group_rows, float* groupsum, size_t groupsum_bytes, void* stream) {
+    if (!groupsum) return -CHAM_ERR_ARG;
+    return h2_run(A, a_plane_stride, lda, a_scale, B, b_plane_stride, ldb, b_scale, 0, C, ldc, M, N, K, nullptr, ACT_NONE, dref_h, ldr, ACT_LEAKY, 0,
+                  nullptr, 0, 1, a_tiles, 0, dref_blocked, group_rows, groupsum, groupsum_bytes, stream);
 }
 
 extern "C" int cham_gemm_h2(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,

@@ -165,6 +165,32 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__
     }
 }
 
+// The same from the GROUP SUMS the CAR dgrad's epilogue left (cham_gemm_h2_dgrad_gs, csrc/gemm_h2.hip H2Params::gsum): the candidate rows
+// of click bt are rows [bt G, (bt + 1) G), G = N + 1 >= 32, of the dgrad's output; 128-row chunk q holds piece k = bt - (128 q) / G of
+// that group at gsum[(q * GS_K + k) * C + column].  dU[bt] = dpre[input bt] + the group's pieces in chunk order (<= 3 of them): the
+// 1 GB of candidate rows is not read again (only row (bt, 0) for dV_pos).
+#define COMBINE_GS_K 5             // = H2_GS_K of csrc/gemm_h2.hip
+__global__ __launch_bounds__(256) void k_combine_bwd_u_gs(const float* __restrict__ dpre_in, const float* __restrict__ dpre_cand, int C, int BT,
+                                                          int N, const float* __restrict__ gsum, float* __restrict__ dU, float* __restrict__ dV) {
+    const int bt = blockIdx.x, G = N + 1;
+    const long r0 = (long)bt * G, r1 = r0 + G - 1;
+    const int q0 = (int)(r0 >> 7), q1 = (int)(r1 >> 7);
+    const float4* pin = reinterpret_cast<const float4*>(dpre_in + (size_t)bt * C);
+    const float4* pc = reinterpret_cast<const float4*>(dpre_cand + (size_t)r0 * C);
+    for (int k = threadIdx.x; k < C / 4; k += 256) {
+        const float4 a = pin[k], p0 = pc[k];
+        float4 s = a;
+        for (int q = q0; q <= q1; ++q) {
+            const int piece = bt - (int)(((long)q << 7) / G);
+            const float4 x = reinterpret_cast<const float4*>(gsum + ((size_t)q * COMBINE_GS_K + piece) * C)[k];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+        reinterpret_cast<float4*>(dU + (size_t)bt * C)[k] = s;
+        reinterpret_cast<float4*>(dV + (size_t)bt * C)[k] = a;
+        reinterpret_cast<float4*>(dV + ((size_t)BT + bt) * C)[k] = p0;
+    }
+}
+
 // dV[2BT + s] = sum over the candidate rows that reference pool slot s - deterministic (rows are summed in ascending position
 // order, no float atomics) and without a size assumption (round-1 version: every (slot, row-chunk) workgroup scanned its 64-KB
 // chunk of the slot table - 1 GB of L2 reads per step, hot slots serialised, and a fixed-size match list that silently
@@ -651,7 +677,7 @@ extern "C" size_t cham_combine_bwd_workspace_bytes(int C, int BT, int N, int pma
 
 template <typename T>
 static int combine_bwd_impl(const float* dpre_in, const T* dpre_cand, int C, int BT, int N, int pmax, const int32_t* neg_slot,
-                            float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
+                            float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream, const float* gsum = nullptr) {
     if (!dpre_in || !dpre_cand || !neg_slot || !dU || !dV || !workspace || (C & 3) || BT <= 0 || N <= 0 || pmax <= 0) return -CHAM_ERR_ARG;
     if (workspace_bytes < cham_combine_bwd_workspace_bytes(C, BT, N, pmax) || ((uintptr_t)workspace & 15)) return -CHAM_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -660,7 +686,12 @@ static int combine_bwd_impl(const float* dpre_in, const T* dpre_cand, int C, int
     float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes);
     float* pad_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + w.bitmap_bytes + w.partial_bytes);
     const size_t n = (size_t)BT * N;
-    hipLaunchKernelGGL(k_combine_bwd_u<T>, dim3(BT), dim3(256), 0, st, dpre_in, dpre_cand, C, BT, N, dU, dV);
+    if constexpr (sizeof(T) == 4) {
+        if (gsum) hipLaunchKernelGGL(k_combine_bwd_u_gs, dim3(BT), dim3(256), 0, st, dpre_in, reinterpret_cast<const float*>(dpre_cand), C, BT, N, gsum, dU, dV);
+        else hipLaunchKernelGGL(k_combine_bwd_u<T>, dim3(BT), dim3(256), 0, st, dpre_in, dpre_cand, C, BT, N, dU, dV);
+    } else {
+        hipLaunchKernelGGL(k_combine_bwd_u<T>, dim3(BT), dim3(256), 0, st, dpre_in, dpre_cand, C, BT, N, dU, dV);
+    }
     if (hipMemsetAsync(bitmap, 0, (size_t)pmax * w.W * sizeof(unsigned), st) != hipSuccess) return -CHAM_ERR_LAUNCH;
     hipLaunchKernelGGL(k_slot_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, neg_slot, n, N, pmax, w.W, bitmap);
     hipLaunchKernelGGL(k_slot_reduce<T>, dim3(pmax, w.nchunk), dim3(256), 0, st, dpre_cand, C, BT, N, neg_slot, bitmap, w.W, pmax, partial, dV);
@@ -676,6 +707,16 @@ extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pma
                                 float* dU, float* dV, float* workspace, size_t workspace_bytes, void* stream) {
     if (!dpre || BT <= 0 || C <= 0) return -CHAM_ERR_ARG;
     return combine_bwd_impl<float>(dpre, dpre + (size_t)BT * C, C, BT, N, pmax, neg_slot, dU, dV, workspace, workspace_bytes, stream);
+}
+// The per-click sums from the CAR dgrad's group sums (cham_gemm_h2_dgrad_gs with group_rows = N + 1 >= 32 over M = BT (N + 1) rows and C
+// columns; groupsum_bytes >= cham_gemm_h2_groupsum_bytes(M, C)): same outputs as cham_combine_bwd, the candidate rows are read once (by the
+// slot sums) instead of twice.  Another - equally fixed - summation order for dU than cham_combine_bwd's.
+extern "C" int cham_combine_bwd_gs(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
+                                   float* workspace, size_t workspace_bytes, const float* groupsum, size_t groupsum_bytes, void* stream) {
+    if (!dpre || BT <= 0 || C <= 0 || !groupsum || N + 1 < 32 || ((uintptr_t)groupsum & 15)) return -CHAM_ERR_ARG;
+    const size_t rows = (size_t)BT * (N + 1);
+    if (groupsum_bytes < (size_t)2 * ((rows + 255) / 256) * COMBINE_GS_K * (size_t)C * sizeof(float)) return -CHAM_ERR_ARG;
+    return combine_bwd_impl<float>(dpre, dpre + (size_t)BT * C, C, BT, N, pmax, neg_slot, dU, dV, workspace, workspace_bytes, stream, groupsum);
 }
 // bf16 configuration: clicked-input rows fp32 [BT, C], candidate rows bf16 [BT*(1+N), C]
 extern "C" int cham_combine_bwd_b16(const float* dpre_in, const void* dpre_cand, int C, int BT, int N, int pmax, const int32_t* neg_slot,

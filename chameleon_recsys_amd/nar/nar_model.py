@@ -185,6 +185,8 @@ class NARRuntime:
         # CHAM_DEV_SCALARS=0: the by-value entry points (A/B arm; bit-identical results).  capturing: a graph capture is in progress - the
         # record is NOT written by the step's code (the replay writes it in front of every launch of the graph).
         self.dev_scalars = os.environ.get("CHAM_DEV_SCALARS", "1") == "1"
+        # round 6: per-click sums of dZ1 in the CAR dgrad's epilogue instead of a second pass over its 1 GB (CHAM_DGRAD_GROUPSUM=0: k_combine_bwd_u)
+        self.dgrad_groupsum = os.environ.get("CHAM_DGRAD_GROUPSUM", "1") == "1"
         # round 6, the serial tail of the backward pass (profiles/r06_notes.md section 5b): dgamma / dbeta column sums with coalesced reads
         # through a workspace (CHAM_FEATURE_BWD_WS), the user-context half of the PreCAR input's backward on the third lane (CHAM_TAIL_SPLIT)
         self.feature_bwd_ws = os.environ.get("CHAM_FEATURE_BWD_WS", "1") == "1"
@@ -583,9 +585,10 @@ class NARRuntime:
                              bias=bias is not None, rowscale=False, bf16=False, p3=True, tile=0, epi=int(c[6]), ev=(e0, e1)))
 
     def gemm_h2(self, A, a_ps, lda, a_sc, B, b_ps, ldb, b_sc, tn, C, ldc, M, N, K, bias=None, act=ACT_NONE, dref_h=None, ldr=0, dact=ACT_NONE,
-                accumulate=0, splits=1, a_tiles=0, b_tiles=0, dref_blocked=0):
+                accumulate=0, splits=1, a_tiles=0, b_tiles=0, dref_blocked=0, group_rows=0, groupsum=None):
         """Plane-product GEMM over two fp16 planes + scale records (csrc/gemm_h2.hip): NT (tn=0) or TN (tn=1, split-K).  a_tiles / b_tiles > 0:
-        that operand is TILE-BLOCKED with this many row tiles per plane (include/chameleon_nar.h cham_gemm_h2b), dref_blocked: dref_h likewise."""
+        that operand is TILE-BLOCKED with this many row tiles per plane (include/chameleon_nar.h cham_gemm_h2b), dref_blocked: dref_h likewise.
+        groupsum (dgrad only): the epilogue also leaves the column sums of every group of `group_rows` rows (cham_gemm_h2_dgrad_gs)."""
         ws = None
         if splits != 1:
             ws = self._lane_ws('gemm_ws')
@@ -596,9 +599,13 @@ class NARRuntime:
             self.lib.cham_gemm_h2_launch_counts(c0, 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(self.lib.cham_gemm_h2b(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
-                                     ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, a_tiles, b_tiles, dref_blocked,
-                                     _stream()), "cham_gemm_h2b")
+        if groupsum is not None:
+            check(self.lib.cham_gemm_h2_dgrad_gs(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), ptr(C), ldc, M, N, K, ptr(dref_h), ldr,
+                                                 a_tiles, dref_blocked, group_rows, ptr(groupsum), groupsum.numel() * 4, _stream()), "cham_gemm_h2_dgrad_gs")
+        else:
+            check(self.lib.cham_gemm_h2b(ptr(A), a_ps, lda, ptr(a_sc), ptr(B), b_ps, ldb, ptr(b_sc), tn, ptr(C), ldc, M, N, K, ptr(bias), act, ptr(dref_h),
+                                         ldr, dact, accumulate, ptr(ws), ws.numel() * 4 if ws is not None else 0, splits, a_tiles, b_tiles, dref_blocked,
+                                         _stream()), "cham_gemm_h2b")
         if prof is not None:
             e1.record()
             c = (ctypes.c_longlong * 8)()
@@ -788,6 +795,10 @@ class StepPlan:
                 self.sc_z1 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_dz2 = torch.zeros(8, dtype=torch.float32, device=dev)
                 self.sc_ds1 = torch.zeros(8, dtype=torch.float32, device=dev)          # dS1 itself (operand of the Ws1 weight gradient)
+                # per-click column sums of dZ1 from the CAR dgrad's epilogue (round 6; csrc/gemm_h2.hip H2Params::gsum): dU without a second
+                # pass over the 1 GB of candidate rows
+                self.gsum = (torch.empty(int(rt.lib.cham_gemm_h2_groupsum_bytes(Rc, C)) // 4, dtype=torch.float32, device=dev)
+                             if rt.dgrad_groupsum and NC >= 32 and Rc > 0 else None)
             else:
                 self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)
             self.p3_ps = Rc * C                                   # plane stride of a row-major operand ...
@@ -1597,8 +1608,9 @@ class NARModuleModel:
             else:
                 rt.gemm_p3(pl.Z1p, pl.p3_ps, C, pl.dZ2p, pl.p3_ps, C, 1, g('W2'), C, C, C, Rc, splits=splits)
         if h2:          # planes of dZ2 x planes of W2 as stored; leaky' from the sign of Z1's h plane
+            gsum = getattr(pl, 'gsum', None) if not drop else None
             rt.gemm_h2(pl.dZ2p, pl.dz2_ps, C, pl.sc_dz2, rt.w2p, C * C, C, rt.sc_w2, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY,
-                       a_tiles=pl.dz2_tiles, dref_blocked=1 if pl.z1_tiles else 0)
+                       a_tiles=pl.dz2_tiles, dref_blocked=1 if pl.z1_tiles else 0, group_rows=NC, groupsum=gsum)
         elif use_p3:
             rt.gemm_p3(pl.dZ2p, pl.p3_ps, C, rt.w2p, C * C, C, 0, pl.dZ1[BT:], C, Rc, C, C, dref_h=pl.Z1p, ldr=C, dact=ACT_LEAKY)
         elif not b16 and Rc > 0:
@@ -1756,6 +1768,9 @@ class NARModuleModel:
             elif b16:
                 check(lib.cham_combine_bwd_b16(ptr(pl.dZ1), ptr(pl.dZ1c), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws),
                                                ws.numel() * 4, st), "cham_combine_bwd_b16")
+            elif h2 and getattr(pl, 'gsum', None) is not None:      # dU from the group sums of the CAR dgrad's epilogue
+                check(lib.cham_combine_bwd_gs(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4,
+                                              ptr(pl.gsum), pl.gsum.numel() * 4, st), "cham_combine_bwd_gs")
             else:
                 check(lib.cham_combine_bwd(ptr(pl.dZ1), C, BT, N, pmax, ptr(neg_slot), ptr(pl.dU), ptr(pl.dV), ptr(ws), ws.numel() * 4, st),
                       "cham_combine_bwd")

@@ -584,3 +584,74 @@ def test_blocked_plane_producers_write_the_row_major_planes_bit_for_bit(gpu, BT,
         assert Dr.abs().max() > 0
         assert torch.equal(un[:, :R].view(torch.int16), Dr.view(torch.int16)) and not un[:, R:].any(), f16
         assert torch.equal(dpr, dpb) and torch.equal(b2r, b2b)
+
+
+@pytest.mark.parametrize("BT,N,C,K", [(7, 50, 256, 64), (40, 50, 1024, 128), (64, 31, 256, 96), (5, 100, 512, 64), (3, 127, 256, 32), (2, 300, 256, 64),
+                                      (97, 50, 260, 64), (1, 50, 256, 64)])
+@pytest.mark.parametrize("wide", [1, 0])
+def test_h2_dgrad_group_sums(gpu, BT, N, C, K, wide):
+    """Round 6: the CAR dgrad's epilogue leaves the column sums of every click's N + 1 candidate rows (cham_gemm_h2_dgrad_gs), and
+    cham_combine_bwd_gs builds dU from those pieces instead of reading the rows again.  The dgrad's own output must be bit-identical to the
+    plain launch; dU must agree with float64 sums of THAT output to fp32 summation accuracy; dV (rows copied / slot sums) bit-identical to
+    cham_combine_bwd's.  Shapes: groups of 32 ... 301 rows against the 128-row chunks and 256-row tiles, a ragged last tile, ragged columns
+    (260), one click, both NT kernels."""
+    from chameleon_recsys_amd._lib import check, ptr
+    lib = _lib_()
+    st = torch.cuda.current_stream().cuda_stream
+    G, M = N + 1, BT * (N + 1)
+    g = torch.Generator(device='cpu').manual_seed(BT * 1000 + N)
+    A = torch.randn(M, K, generator=g).to(gpu)
+    W = torch.randn(C, K, generator=g).to(gpu) * 0.1
+    Y = torch.randn(M, C, generator=g).to(gpu)
+    Ap, ra = split2h_dev(A)
+    Wp, rw = split2h_dev(W)
+    Yp, _ = split2h_dev(Y)
+    was = lib.cham_gemm_h2_set_nt_wide(wide)
+    try:
+        dpre0 = torch.zeros(BT + M, C, device=gpu)
+        dpre1 = torch.zeros(BT + M, C, device=gpu)
+        dpre_in = torch.randn(BT, C, generator=g).to(gpu)
+        dpre0[:BT] = dpre_in; dpre1[:BT] = dpre_in
+        _gemm(lib, Ap, M * K, K, ra, Wp, C * K, K, rw, 0, dpre0[BT:], C, M, C, K, dref=Yp, ldr=C, dact=1)
+        gs = torch.full((int(lib.cham_gemm_h2_groupsum_bytes(M, C)) // 4,), float('nan'), device=gpu)
+        check(lib.cham_gemm_h2_dgrad_gs(ptr(Ap), M * K, K, ptr(ra), ptr(Wp), C * K, K, ptr(rw), ptr(dpre1[BT:]), C, M, C, K, ptr(Yp), C, 0, 0, G,
+                                        ptr(gs), gs.numel() * 4, st), "cham_gemm_h2_dgrad_gs")
+    finally:
+        lib.cham_gemm_h2_set_nt_wide(was)
+    assert torch.equal(dpre0, dpre1)
+    pmax = 11
+    gi = torch.Generator(device='cpu').manual_seed(5)
+    neg_slot = torch.randint(0, pmax + 1, (BT, N), generator=gi, dtype=torch.int32)
+    for b in range(BT):       # a click holds a pool slot at most once (the sampler's contract); the rest is the zero-padding slot
+        seen = set()
+        for n in range(N):
+            s = int(neg_slot[b, n])
+            if s < pmax and s in seen:
+                neg_slot[b, n] = pmax
+            seen.add(s)
+    neg_slot = neg_slot.to(gpu)
+    RV = 2 * BT + pmax + 1
+    ws = torch.zeros(int(lib.cham_combine_bwd_workspace_bytes(C, BT, N, pmax)) // 4 + 64, device=gpu)
+    dU0, dV0 = torch.zeros(BT, C, device=gpu), torch.zeros(RV, C, device=gpu)
+    dU1, dV1 = torch.zeros(BT, C, device=gpu), torch.zeros(RV, C, device=gpu)
+    if C % 4 == 0:
+        check(lib.cham_combine_bwd(ptr(dpre0), C, BT, N, pmax, ptr(neg_slot), ptr(dU0), ptr(dV0), ptr(ws), ws.numel() * 4, st), "cham_combine_bwd")
+        check(lib.cham_combine_bwd_gs(ptr(dpre1), C, BT, N, pmax, ptr(neg_slot), ptr(dU1), ptr(dV1), ptr(ws), ws.numel() * 4, ptr(gs), gs.numel() * 4, st),
+              "cham_combine_bwd_gs")
+        assert torch.equal(dV0, dV1)
+        ref = dpre_in.double() + dpre1[BT:].double().view(BT, G, C).sum(1)
+        mag = dpre_in.double().abs() + dpre1[BT:].double().abs().view(BT, G, C).sum(1)
+        err = ((dU1.double() - ref).abs() / mag).max().item()
+        err0 = ((dU0.double() - ref).abs() / mag).max().item()
+        assert err < 4e-7 and err <= 4 * max(err0, 1e-8), (err, err0)
+        # every piece the consumer read was written (no NaN left in the sums), and the run is repeatable bit for bit
+        assert torch.isfinite(dU1).all()
+        gs2 = torch.full_like(gs, float('nan'))
+        check(lib.cham_gemm_h2_dgrad_gs(ptr(Ap), M * K, K, ptr(ra), ptr(Wp), C * K, K, ptr(rw), ptr(dpre1[BT:]), C, M, C, K, ptr(Yp), C, 0, 0, G,
+                                        ptr(gs2), gs2.numel() * 4, st), "cham_gemm_h2_dgrad_gs")
+        assert torch.equal(torch.nan_to_num(gs, nan=-1.0), torch.nan_to_num(gs2, nan=-1.0))
+    # argument checks: groups under 32 rows, a short buffer, the TN form
+    assert lib.cham_gemm_h2_dgrad_gs(ptr(Ap), M * K, K, ptr(ra), ptr(Wp), C * K, K, ptr(rw), ptr(dpre1[BT:]), C, M, C, K, ptr(Yp), C, 0, 0, 31,
+                                     ptr(gs), gs.numel() * 4, st) < 0
+    assert lib.cham_gemm_h2_dgrad_gs(ptr(Ap), M * K, K, ptr(ra), ptr(Wp), C * K, K, ptr(rw), ptr(dpre1[BT:]), C, M, C, K, ptr(Yp), C, 0, 0, G,
+                                     ptr(gs), gs.numel() * 4 - 4, st) < 0
