@@ -80,7 +80,7 @@ _SIGNATURES = {
     "cham_combine_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cham_combine_bwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "cham_combine_bwd_gs": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P, c_size_t, P]),
-    "cham_gemm_h2_groupsum_bytes": (c_size_t, [c_int, c_int]),
+    "cham_gemm_h2_groupsum_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cham_gemm_h2_dgrad_gs": (c_int, [P, c_int64, c_int, P, P, c_int64, c_int, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P,
                                       c_size_t, P]),
     "cham_combine_fwd_b16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),

@@ -52,10 +52,10 @@ struct H2Params {
     // GROUP SUMS in the dgrad epilogue (EPI 3; round 6): rows come in groups of `ggrp` consecutive rows (one click's candidates) whose column
     // sums the caller needs next (dU of the PreCAR combine, csrc/scorer.hip) - 1 GB of fp32 C re-read by a kernel of its own before.  Every
     // wave adds up what its 128-row chunk q = row / 128 holds of each group it touches and writes piece (q, k) = k-th group of the chunk
-    // (group (128 q) / ggrp + k) to gsum[(q * H2_GS_K + k) * N + column]; the consumer adds the <= 3 pieces of a group in chunk order.
-    float* gsum; int ggrp;
+    // (group (128 q) / ggrp + k) to gsum[(q * gsk + k) * N + column], gsk = 127 / ggrp + 2 = the groups a 128-row chunk can touch (<= 5 for
+    // ggrp >= 32); the consumer adds the pieces of a group in chunk order.
+    float* gsum; int ggrp, gsk;
 };
-#define H2_GS_K 5                  // groups a 128-row chunk can touch when ggrp >= 32: floor(127 / ggrp) + 2
 
 #define H2_SLAB 8192
 #define H2_STAGE (4 * H2_SLAB)
@@ -144,7 +144,7 @@ __device__ __forceinline__ void h2_epilogue(const H2Params& p, floatx16 (&acc)[T
         // values in ascending e, the two halves of the wave are added at the end of a group (a + b = b + a: both halves hold the same sum).
         const bool gs = p.gsum != nullptr;
         const int G = gs ? p.ggrp : 1, rbase = m0 + wm0;
-        float* gw = gs ? p.gsum + (size_t)(rbase >> 7) * H2_GS_K * (size_t)p.N + n0 + wn0 + fl : nullptr;
+        float* gw = gs ? p.gsum + (size_t)(rbase >> 7) * (size_t)p.gsk * (size_t)p.N + n0 + wn0 + fl : nullptr;
         float cur[TNN], hik[TNN];
 #pragma unroll
         for (int j = 0; j < TNN; ++j) { cur[j] = 0.f; hik[j] = 0.f; }
@@ -867,16 +867,16 @@ static int h2_launch(H2Params& p, hipStream_t st) {
 // the matrix ZERO; plane stride >= tiles * 256 * ld); 0: row-major.  dref_blocked: the dgrad's saved-activation plane likewise.
 //   NT: A may be blocked (needs K % 32 == 0 and the 64-byte-piece kernel, ld == K); B (the weight planes) is row-major.
 //   TN: A and B independently.  Results are bit-identical to the row-major operands' (tests/test_gemm_h2_gpu.py).
-extern "C" size_t cham_gemm_h2_groupsum_bytes(int M, int N) {
-    if (M <= 0 || N <= 0) return 0;
-    return (size_t)2 * ((M + 255) / 256) * H2_GS_K * (size_t)N * sizeof(float);
+extern "C" size_t cham_gemm_h2_groupsum_bytes(int M, int N, int group_rows) {
+    if (M <= 0 || N <= 0 || group_rows < 32) return 0;
+    return (size_t)2 * ((M + 255) / 256) * (size_t)(127 / group_rows + 2) * (size_t)N * sizeof(float);
 }
 static int h2_run(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
                   int ldb, const float* b_scale, int tn, float* C, int ldc, int M, int N, int K, const float* bias, int act,
                   const void* dref_h, int ldr, int dact, int accumulate, float* workspace, size_t workspace_bytes, int splits_hint,
                   int a_tiles, int b_tiles, int dref_blocked, int group_rows, float* groupsum, size_t groupsum_bytes, void* stream) {
     if (!A || !B || !C || !a_scale || !b_scale || M <= 0 || N <= 0 || K <= 0 || a_tiles < 0 || b_tiles < 0) return -CHAM_ERR_ARG;
-    if (groupsum && (tn || !dref_h || group_rows < 32 || groupsum_bytes < cham_gemm_h2_groupsum_bytes(M, N) || ((uintptr_t)groupsum & 15)))
+    if (groupsum && (tn || !dref_h || group_rows < 32 || groupsum_bytes < cham_gemm_h2_groupsum_bytes(M, N, group_rows) || ((uintptr_t)groupsum & 15)))
         return -CHAM_ERR_ARG;
     {   // tile-blocked operands: whole column blocks, enough row tiles, planes that do not overlap
         const long a_rows = tn ? K : M, b_rows = tn ? K : N;
@@ -894,7 +894,7 @@ static int h2_run(const void* A, long long a_plane_stride, int lda, const float*
     p.dref = reinterpret_cast<const unsigned short*>(dref_h); p.ldr = ldr; p.partial = workspace; p.xcd_split = 0; p.accumulate = 0;
     p.nbm = (M + 255) / 256; p.nbn = (N + 255) / 256;
     p.a_tiles = a_tiles; p.b_tiles = b_tiles; p.r_blk = dref_blocked ? 1 : 0;
-    p.gsum = groupsum; p.ggrp = group_rows;
+    p.gsum = groupsum; p.ggrp = group_rows; p.gsk = groupsum ? 127 / group_rows + 2 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (!tn) {
         if ((K & 15) || accumulate) return -CHAM_ERR_ARG;
@@ -903,6 +903,7 @@ static int h2_run(const void* A, long long a_plane_stride, int lda, const float*
         if (dref_h && (bias || act != ACT_NONE || dact != ACT_LEAKY)) return -CHAM_ERR_ARG;
         if (act != ACT_NONE && !(bias && act == ACT_TANH)) return -CHAM_ERR_ARG;
         ++g_h2_launches[0];
+        if (groupsum) ++g_h2_launches[5];
         if (g_h2_nt_wide && (K & 31) == 0) {
             if (dref_h) return h2w_launch<3>(p, st);
             if (bias) return act == ACT_TANH ? h2w_launch<2>(p, st) : h2w_launch<5>(p, st);
@@ -958,7 +959,7 @@ extern "C" int cham_gemm_h2b(const void* A, long long a_plane_stride, int lda, c
 }
 // The CAR dgrad (NT, x leaky'(dref_h)) with GROUP SUMS from its epilogue: rows come in groups of `group_rows` >= 32 consecutive rows; every
 // 128-row chunk q writes the column sums of what it holds of its k-th group (group (128 q) / group_rows + k) to
-// groupsum[(q * 5 + k) * N + column] (cham_gemm_h2_groupsum_bytes(M, N) bytes; consumer: cham_combine_bwd_gs).  C is written as by cham_gemm_h2b.
+// groupsum[(q * (127 / group_rows + 2) + k) * N + column] (cham_gemm_h2_groupsum_bytes(M, N, group_rows) bytes; consumer: cham_combine_bwd_gs).  C is written as by cham_gemm_h2b.
 extern "C" int cham_gemm_h2_dgrad_gs(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride,
                                      int ldb, const float* b_scale, float* C, int ldc, int M, int N, int K, const void* dref_h, int ldr,
                                      int a_tiles, int dref_blocked, int group_rows, float* groupsum, size_t groupsum_bytes, void* stream) {

@@ -167,12 +167,11 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u(const float* __restrict__
 
 // The same from the GROUP SUMS the CAR dgrad's epilogue left (cham_gemm_h2_dgrad_gs, csrc/gemm_h2.hip H2Params::gsum): the candidate rows
 // of click bt are rows [bt G, (bt + 1) G), G = N + 1 >= 32, of the dgrad's output; 128-row chunk q holds piece k = bt - (128 q) / G of
-// that group at gsum[(q * GS_K + k) * C + column].  dU[bt] = dpre[input bt] + the group's pieces in chunk order (<= 3 of them): the
-// 1 GB of candidate rows is not read again (only row (bt, 0) for dV_pos).
-#define COMBINE_GS_K 5             // = H2_GS_K of csrc/gemm_h2.hip
+// that group at gsum[(q * (127 / G + 2) + k) * C + column].  dU[bt] = dpre[input bt] + the group's pieces in chunk order (<= 3 of them
+// at the G1 shape): the 1 GB of candidate rows is not read again (only row (bt, 0) for dV_pos).
 __global__ __launch_bounds__(256) void k_combine_bwd_u_gs(const float* __restrict__ dpre_in, const float* __restrict__ dpre_cand, int C, int BT,
                                                           int N, const float* __restrict__ gsum, float* __restrict__ dU, float* __restrict__ dV) {
-    const int bt = blockIdx.x, G = N + 1;
+    const int bt = blockIdx.x, G = N + 1, gsk = 127 / G + 2;
     const long r0 = (long)bt * G, r1 = r0 + G - 1;
     const int q0 = (int)(r0 >> 7), q1 = (int)(r1 >> 7);
     const float4* pin = reinterpret_cast<const float4*>(dpre_in + (size_t)bt * C);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(256) void k_combine_bwd_u_gs(const float* __restric
         float4 s = a;
         for (int q = q0; q <= q1; ++q) {
             const int piece = bt - (int)(((long)q << 7) / G);
-            const float4 x = reinterpret_cast<const float4*>(gsum + ((size_t)q * COMBINE_GS_K + piece) * C)[k];
+            const float4 x = reinterpret_cast<const float4*>(gsum + ((size_t)q * gsk + piece) * C)[k];
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
         reinterpret_cast<float4*>(dU + (size_t)bt * C)[k] = s;
@@ -709,13 +708,13 @@ extern "C" int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pma
     return combine_bwd_impl<float>(dpre, dpre + (size_t)BT * C, C, BT, N, pmax, neg_slot, dU, dV, workspace, workspace_bytes, stream);
 }
 // The per-click sums from the CAR dgrad's group sums (cham_gemm_h2_dgrad_gs with group_rows = N + 1 >= 32 over M = BT (N + 1) rows and C
-// columns; groupsum_bytes >= cham_gemm_h2_groupsum_bytes(M, C)): same outputs as cham_combine_bwd, the candidate rows are read once (by the
+// columns; groupsum_bytes >= cham_gemm_h2_groupsum_bytes(M, C, N + 1)): same outputs as cham_combine_bwd, the candidate rows are read once (by the
 // slot sums) instead of twice.  Another - equally fixed - summation order for dU than cham_combine_bwd's.
 extern "C" int cham_combine_bwd_gs(const float* dpre, int C, int BT, int N, int pmax, const int32_t* neg_slot, float* dU, float* dV,
                                    float* workspace, size_t workspace_bytes, const float* groupsum, size_t groupsum_bytes, void* stream) {
     if (!dpre || BT <= 0 || C <= 0 || !groupsum || N + 1 < 32 || ((uintptr_t)groupsum & 15)) return -CHAM_ERR_ARG;
     const size_t rows = (size_t)BT * (N + 1);
-    if (groupsum_bytes < (size_t)2 * ((rows + 255) / 256) * COMBINE_GS_K * (size_t)C * sizeof(float)) return -CHAM_ERR_ARG;
+    if (groupsum_bytes < (size_t)2 * ((rows + 255) / 256) * (size_t)(127 / (N + 1) + 2) * (size_t)C * sizeof(float)) return -CHAM_ERR_ARG;
     return combine_bwd_impl<float>(dpre, dpre + (size_t)BT * C, C, BT, N, pmax, neg_slot, dU, dV, workspace, workspace_bytes, stream, groupsum);
 }
 // bf16 configuration: clicked-input rows fp32 [BT, C], candidate rows bf16 [BT*(1+N), C]

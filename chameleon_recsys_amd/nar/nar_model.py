@@ -797,7 +797,7 @@ class StepPlan:
                 self.sc_ds1 = torch.zeros(8, dtype=torch.float32, device=dev)          # dS1 itself (operand of the Ws1 weight gradient)
                 # per-click column sums of dZ1 from the CAR dgrad's epilogue (round 6; csrc/gemm_h2.hip H2Params::gsum): dU without a second
                 # pass over the 1 GB of candidate rows
-                self.gsum = (torch.empty(int(rt.lib.cham_gemm_h2_groupsum_bytes(Rc, C)) // 4, dtype=torch.float32, device=dev)
+                self.gsum = (torch.empty(int(rt.lib.cham_gemm_h2_groupsum_bytes(Rc, C, NC)) // 4, dtype=torch.float32, device=dev)
                              if rt.dgrad_groupsum and NC >= 32 and Rc > 0 else None)
             else:
                 self.Z1p, self.dZ2p = bf(3, Rc, C), bf(3, Rc, C)

@@ -333,10 +333,12 @@ int cham_combine_bwd(const float* dpre, int C, int BT, int N, int pmax, const in
 /* GROUP SUMS from the CAR dgrad's epilogue (round 6; the reference's tf.gradients sums d(tanh pre-activation) over a click's candidates when
  * it differentiates the tiled user context, nar_model.py:356-405).  The dgrad over the candidate rows (NT two-plane GEMM x leaky'(saved
  * activation), M = BT (N + 1) rows in groups of group_rows = N + 1 >= 32 consecutive rows) also writes, per 128-row chunk q and k-th group
- * of that chunk (group (128 q) / group_rows + k), the column sums of the chunk's rows of the group to groupsum[(q * 5 + k) * N + column];
+ * of that chunk (group (128 q) / group_rows + k), the column sums of the chunk's rows of the group to
+ * groupsum[(q * (127 / group_rows + 2) + k) * N + column];
  * cham_combine_bwd_gs = cham_combine_bwd with dU built from those pieces in chunk order: the 1 GB of candidate-row gradients is read once
- * (by the slot sums) instead of twice.  C / dV are bit-identical to the plain entry points'; dU is summed in another, equally fixed order. */
-size_t cham_gemm_h2_groupsum_bytes(int M, int N);
+ * (by the slot sums) instead of twice.  C / dV are bit-identical to the plain entry points'; dU is summed in another, equally fixed order.
+ * cham_gemm_h2_launch_counts out8[5]: dgrad launches that produced group sums. */
+size_t cham_gemm_h2_groupsum_bytes(int M, int N, int group_rows);
 int cham_gemm_h2_dgrad_gs(const void* A, long long a_plane_stride, int lda, const float* a_scale, const void* B, long long b_plane_stride, int ldb,
                           const float* b_scale, float* C, int ldc, int M, int N, int K, const void* dref_h, int ldr, int a_tiles, int dref_blocked,
                           int group_rows, float* groupsum, size_t groupsum_bytes, void* stream);

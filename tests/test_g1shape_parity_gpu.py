@@ -208,6 +208,7 @@ def test_step_parity_g1_shape_headline_batch(gpu, length_dist):
     compare_step_large(model, orc, *batches[3], st, unpinned_max=5e-3)
     assert model.rt.h2 and car_gemm_counts(model) == (2, 1)          # the three candidate-row CAR GEMMs ran on the default (two-plane) kernels
     assert h2_counts(lib)[2] == 2                                    # ... the two NT forms on the 64-byte-source-piece kernel (round 5), the bench's own
+    assert h2_counts(lib)[5] == 1                                    # ... and the dgrad left the per-click sums that dU was built from (round 6)
     rows = model._plan.P * model._plan.NC
     assert rows == (B * 19 * 51 if length_dist == "full" else rows) and rows > 0
 

@@ -613,7 +613,7 @@ def test_h2_dgrad_group_sums(gpu, BT, N, C, K, wide):
         dpre_in = torch.randn(BT, C, generator=g).to(gpu)
         dpre0[:BT] = dpre_in; dpre1[:BT] = dpre_in
         _gemm(lib, Ap, M * K, K, ra, Wp, C * K, K, rw, 0, dpre0[BT:], C, M, C, K, dref=Yp, ldr=C, dact=1)
-        gs = torch.full((int(lib.cham_gemm_h2_groupsum_bytes(M, C)) // 4,), float('nan'), device=gpu)
+        gs = torch.full((int(lib.cham_gemm_h2_groupsum_bytes(M, C, G)) // 4,), float('nan'), device=gpu)
         check(lib.cham_gemm_h2_dgrad_gs(ptr(Ap), M * K, K, ptr(ra), ptr(Wp), C * K, K, ptr(rw), ptr(dpre1[BT:]), C, M, C, K, ptr(Yp), C, 0, 0, G,
                                         ptr(gs), gs.numel() * 4, st), "cham_gemm_h2_dgrad_gs")
     finally:
