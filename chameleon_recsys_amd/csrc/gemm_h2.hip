@@ -722,7 +722,23 @@ __global__ __launch_bounds__(256) void k_h2_scale_rownorm(const float* __restric
     float mx = 0.f;
     if (K == 128) {
         const int hl = lane & 31, hw = lane >> 5;
-        for (long r = 2 * wave_g + hw; r < R; r += 2 * nwaves) {
+        const long stride = 2 * nwaves;
+        long r = 2 * wave_g + hw;
+        // four rows in flight per half-wave (round 6: one 16-byte load per lane and pass left the 127 MB of dS1 at 2.6 TB/s - 49 us on the main
+        // lane between the scorer's backward and the fused dgrad); a maximum: the order does not matter, the record is bit-identical
+        for (; r + 3 * stride < R; r += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(X + (size_t)(r + u * stride) * ld)[hl];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s = v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                mx = fmaxf(mx, s);
+            }
+        }
+        for (; r < R; r += stride) {
             const float4 v = reinterpret_cast<const float4*>(X + (size_t)r * ld)[hl];
             float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll

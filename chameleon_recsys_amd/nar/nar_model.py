@@ -185,6 +185,8 @@ class NARRuntime:
         # CHAM_DEV_SCALARS=0: the by-value entry points (A/B arm; bit-identical results).  capturing: a graph capture is in progress - the
         # record is NOT written by the step's code (the replay writes it in front of every launch of the graph).
         self.dev_scalars = os.environ.get("CHAM_DEV_SCALARS", "1") == "1"
+        # round 6: the loss record's kernels (L2 term, finalize) and the zero fill of the embedding gradients off the main lane (CHAM_LOSS_SIDE=0: on it)
+        self.loss_side = os.environ.get("CHAM_LOSS_SIDE", "1") == "1"
         # round 6: per-click sums of dZ1 in the CAR dgrad's epilogue instead of a second pass over its 1 GB (CHAM_DGRAD_GROUPSUM=0: k_combine_bwd_u)
         self.dgrad_groupsum = os.environ.get("CHAM_DGRAD_GROUPSUM", "1") == "1"
         # round 6, the serial tail of the backward pass (profiles/r06_notes.md section 5b): dgamma / dbeta column sums with coalesced reads
@@ -1401,13 +1403,23 @@ class NARModuleModel:
         check(softmax_fwd(ptr(pl.S3), 32, ptr(p('Ws4')), ptr(p('bs4')), BT, N, float(self.softmax_temperature),
                           ptr(pl.mask), ptr(pl.logits), ptr(pl.probs), ptr(pl.nll), self.novelty_reg_factor,
                           ptr(neg_ids), ptr(st['pop_norm']), ptr(pl.nov_aux), s), "cham_score_softmax_fwd")
-        check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
-        if dsc:
-            check(lib.cham_loss_finalize_dev(ptr(pl.nll), BT, ptr(rt.scalars), ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
-                  "cham_loss_finalize_dev")
+        def loss_kernels(s):
+            check(lib.cham_sumsq_partial(ptr(rt.flat), L.n_reg, ptr(rt.sumsq), s), "cham_sumsq_partial")
+            if dsc:
+                check(lib.cham_loss_finalize_dev(ptr(pl.nll), BT, ptr(rt.scalars), ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
+                      "cham_loss_finalize_dev")
+            else:
+                check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
+                      "cham_loss_finalize")
+        if getattr(self, '_defer_loss', False) and rt.overlap and rt.loss_side:
+            # inside a training step (train_step: forward -> backward -> Adam) the L2 term and the loss record leave the main lane - nothing in
+            # the backward pass reads them, they sat between the softmax and its backward (round 6); the backward's final join covers them
+            e_nll = torch.cuda.Event(); e_nll.record()
+            rt.side_stream.wait_event(e_nll)
+            with torch.cuda.stream(rt.side_stream):
+                loss_kernels(_stream())
         else:
-            check(lib.cham_loss_finalize(ptr(pl.nll), BT, d['sum_mask'], ptr(rt.sumsq), float(self.reg_weight_decay), ptr(pl.loss), s),
-                  "cham_loss_finalize")
+            loss_kernels(s)
         _roctx.pop()
         self.total_loss = pl.loss            # device [total, xe, reg]; xe is this rank's share under data parallel
         if not self.is_training and st.get('device'):
@@ -1471,8 +1483,13 @@ class NARModuleModel:
                 yield
         e_auxdone = None
 
-        rt.grads[:L.emb_end].zero_()
-        e_start = mark()                 # side lane must not run ahead of the previous step's tail / this zero fill
+        e_start = mark()                 # side lane must not run ahead of the previous step's tail
+        if on and rt.loss_side:          # (round 6) the zero fill of the embedding gradients on the side lane: their writers - the last kernels
+            with side(e_start):          # of the main / third lane - come behind e_dZ1in, an event of this lane
+                rt.grads[:L.emb_end].zero_()
+        else:
+            rt.grads[:L.emb_end].zero_()
+            e_start = mark()
         if rt.dev_scalars:      # sum(mask) from the step-scalar record (written by this step's forward)
             check((lib.cham_score_softmax_bwd_b16_dev if b16 else lib.cham_score_softmax_bwd_dev)(
                 ptr(pl.S3), 32, ptr(p('Ws4')), ptr(pl.probs), ptr(pl.mask), BT, N, float(self.softmax_temperature), ptr(rt.scalars),
@@ -1916,7 +1933,11 @@ class NARModuleModel:
             else:
                 d = self.upload_batch(self.inputs, self.labels)
         with _roctx.range_("NAR step: forward (K0 sampler .. loss)"):        # (CHAM_ROCTX=1: roctx ranges for rocprofv3 --marker-trace)
-            pl = self.forward(d)
+            self._defer_loss = True          # the loss record may finish on the side lane: backward() joins it
+            try:
+                pl = self.forward(d)
+            finally:
+                self._defer_loss = False
         if self.eval_cold_start:       # nar_model.py:520: the ranked candidates are also needed while TRAINING for the cold-start analysis
             self._rank_items(pl, d)
         with _roctx.range_("NAR step: backward"):
