@@ -20,8 +20,10 @@ step = rows[a:b]
 t0 = step[0]['s']
 print("step wall %.3f ms, %d kernels, sum of kernel time %.3f ms" % ((rows[b]['s'] - t0) / 1e6, len(step), sum(r['e'] - r['s'] for r in step) / 1e6))
 isg = lambda r: any(k in r['Kernel_Name'] for k in ('gemm_f32_kernel', 'gemm_bf16_kernel', 'gemm_x3_kernel', 'gemm_b16_kernel', 'gemm_p3_kernel', 'gemm_h2_kernel', 'gemm_h2w_kernel', 'gemm_b1_kernel'))
-# union of GEMM-active intervals
-iv = sorted((r['s'], r['e']) for r in step if isg(r))
+# union of GEMM-active intervals, clipped to the step's window (a kernel of the previous step's tail may still run at its head, one of
+# this step's tail beyond its end: the next step's sampler starts under the W2 weight gradient)
+tend = rows[b]['s']
+iv = sorted((max(r['s'], t0), min(r['e'], tend)) for r in rows if isg(r) and r['e'] > t0 and r['s'] < tend)
 merged = []
 for s, e in iv:
     if merged and s <= merged[-1][1]:
