@@ -551,3 +551,54 @@ def test_training_with_tile_blocked_planes_is_bit_identical(gpu, monkeypatch):
     assert counts[1][3] == 2 * len(batches) and counts[1][4] == len(batches), counts      # NT forward + dgrad, TN weight gradient per step
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+
+
+def _train_with_env(monkeypatch, env, p, batches, full_lanes=False):
+    """Four optimizer steps under the given environment switches -> (losses, weights, Adam m, v), all on the host."""
+    from chameleon_recsys_amd.nar.clicked_items_state import DeviceClickedItemsState
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model, _o = H.make_pair(p)
+    st = DeviceClickedItemsState(p['recent_clicks_buffer_hours'], p['recent_clicks_buffer_max_size'], p['recent_clicks_for_normalization'], 1000)
+    dev = [model.upload_batch(f, l) for f, l in batches]
+    losses = []
+    for d in dev:
+        model.feed_state(st, st)
+        losses.append(model.train_step(d).clone())
+        st.update_from_device_batch(d['aci'], d['g_event_ts'])
+    torch.cuda.synchronize()
+    for k in env:
+        monkeypatch.delenv(k)
+    return model, (torch.stack(losses).cpu(), model.rt.flat.cpu().clone(), model.rt.m.cpu().clone(), model.rt.v.cpu().clone())
+
+
+@pytest.mark.parametrize("length_dist", ["g1", "full"])
+def test_round6_schedule_switches_are_bit_identical_and_summation_switches_close(gpu, monkeypatch, length_dist):
+    """The round-6 switches of the backward pass against their `=0` arms over four optimizer steps with the state evolving.
+    SCHEDULE only (which lane a kernel runs on) - CHAM_TAIL_SPLIT, CHAM_LOSS_SIDE: bit-identical losses, weights and Adam slots.
+    Another fixed SUMMATION ORDER - CHAM_DGRAD_GROUPSUM (dU from the CAR dgrad's epilogue), CHAM_FEATURE_BWD_WS (coalesced dgamma / dbeta
+    column sums): same training to fp32 roundoff (losses 2e-5, Adam first moments 1e-4 of the largest), and the group-sum launch counter proves which
+    path produced dU.  `full`: every session full length (the full-batch lane schedule: third lane in use); `g1`: ragged lengths."""
+    import ctypes
+    p = H.tiny_params(C=256, neg=40)
+    batches = synthetic.make_batches(4, 64, 8, 1000, p['session_features_config'], length_dist=length_dist)
+    c = (ctypes.c_longlong * 8)()
+    base_model, base = _train_with_env(monkeypatch, {}, p, batches)
+    base_model.rt.lib.cham_gemm_h2_launch_counts(c, 1)
+    assert base_model.rt.dgrad_groupsum and base_model.rt.loss_side and base_model.rt.tail_split and base_model.rt.feature_bwd_ws
+    for name in ("CHAM_TAIL_SPLIT", "CHAM_LOSS_SIDE"):
+        _m, run = _train_with_env(monkeypatch, {name: "0"}, p, batches)
+        for a, b in zip(base, run):
+            assert torch.equal(a, b), name
+    base_model.rt.lib.cham_gemm_h2_launch_counts(c, 1)
+    m1, _ = _train_with_env(monkeypatch, {}, p, batches)
+    m1.rt.lib.cham_gemm_h2_launch_counts(c, 1)
+    assert c[5] == len(batches), list(c)                     # default: every step's dgrad left the per-click sums
+    for name in ("CHAM_DGRAD_GROUPSUM", "CHAM_FEATURE_BWD_WS"):
+        m0, run = _train_with_env(monkeypatch, {name: "0"}, p, batches)
+        m0.rt.lib.cham_gemm_h2_launch_counts(c, 1)
+        assert c[5] == (0 if name == "CHAM_DGRAD_GROUPSUM" else len(batches)), (name, list(c))
+        assert float((base[0] - run[0]).abs().max()) < 2e-5, name
+        # (weights are no yardstick: one TF-Adam step moves an entry by ~lr whatever |g| is, so where the true gradient is ~0 the sign of the
+        # roundoff decides - tests/helpers.py; Adam's first moments are linear in the gradients)
+        assert float((base[2] - run[2]).abs().max()) < 1e-4 * float(base[2].abs().max()), (name, float((base[2] - run[2]).abs().max()), float(base[2].abs().max()))
